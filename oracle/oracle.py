@@ -1,0 +1,138 @@
+"""ctypes loader for the CPU oracle (oracle/fourier_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (fourier_amd) never imports this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libfourier_oracle.so")
+
+FFT, IFFT, UNSCALED_IFFT, SQRT_SCALED_FFT, SQRT_SCALED_IFFT = range(5)
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "fourier_oracle.cpp")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libfourier_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+        for s in ("float", "double"):
+            getattr(L, f"oracle_fourier_create_{s}").restype = vp
+            getattr(L, f"oracle_fourier_create_{s}").argtypes = [sz]
+            getattr(L, f"oracle_fourier_destroy_{s}").restype = None
+            getattr(L, f"oracle_fourier_destroy_{s}").argtypes = [vp]
+            getattr(L, f"oracle_fourier_size_{s}").restype = sz
+            getattr(L, f"oracle_fourier_size_{s}").argtypes = [vp]
+            getattr(L, f"oracle_fourier_transform_in_place_{s}").restype = None
+            getattr(L, f"oracle_fourier_transform_in_place_{s}").argtypes = [vp, vp, ci]
+            getattr(L, f"oracle_fourier_transform_{s}").restype = None
+            getattr(L, f"oracle_fourier_transform_{s}").argtypes = [vp, vp, vp, ci]
+            getattr(L, f"oracle_fourier_batch_create_{s}").restype = vp
+            getattr(L, f"oracle_fourier_batch_create_{s}").argtypes = [sz, ci]
+            getattr(L, f"oracle_fourier_batch_destroy_{s}").restype = None
+            getattr(L, f"oracle_fourier_batch_destroy_{s}").argtypes = [vp]
+            getattr(L, f"oracle_fourier_batch_run_{s}").restype = None
+            getattr(L, f"oracle_fourier_batch_run_{s}").argtypes = [vp, vp, vp, sz, ci]
+        L.oracle_fourier_counts.restype = ci
+        L.oracle_fourier_counts.argtypes = [sz, ctypes.POINTER(sz)]
+        _lib = L
+    return _lib
+
+
+def _suffix(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.complex64:
+        return "float"
+    if dtype == np.complex128:
+        return "double"
+    raise TypeError(f"oracle supports complex64/complex128, got {dtype}")
+
+
+class OracleFft:
+    """Mirror of the reference's `Fft` trait (fourier-algorithms/src/fft.rs:40-82) over the oracle."""
+
+    def __init__(self, size, dtype=np.complex64):
+        self.dtype = np.dtype(dtype)
+        self._s = _suffix(dtype)
+        self._h = getattr(lib(), f"oracle_fourier_create_{self._s}")(size)
+        if not self._h:
+            raise ValueError(f"oracle: cannot create plan of size {size}")
+        self._n = size
+
+    def size(self):
+        return self._n
+
+    def transform(self, x, transform=FFT):
+        x = np.ascontiguousarray(x, dtype=self.dtype)
+        assert x.shape == (self._n,)
+        out = np.empty_like(x)
+        getattr(lib(), f"oracle_fourier_transform_{self._s}")(self._h, x.ctypes.data, out.ctypes.data, transform)
+        return out
+
+    def transform_in_place(self, x, transform=FFT):
+        assert x.dtype == self.dtype and x.flags.c_contiguous and x.shape == (self._n,)
+        getattr(lib(), f"oracle_fourier_transform_in_place_{self._s}")(self._h, x.ctypes.data, transform)
+        return x
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            getattr(lib(), f"oracle_fourier_destroy_{self._s}")(h)
+
+
+class OracleBatch:
+    """`nthreads` independent plans of one size; run() splits the batch contiguously over them.
+
+    Plan creation happens here, outside any timed region (fourier-bench times `transform` only,
+    fourier-bench/benches/fft_bench.rs:36).
+    """
+
+    def __init__(self, n, dtype=np.complex64, nthreads=1):
+        self._s = _suffix(dtype)
+        self.dtype = np.dtype(dtype)
+        self.n = n
+        self.nthreads = nthreads
+        self._c = getattr(lib(), f"oracle_fourier_batch_create_{self._s}")(n, nthreads)
+        if not self._c:
+            raise ValueError(f"oracle: cannot create plans of size {n}")
+
+    def run(self, x, transform=FFT, out=None):
+        x = np.ascontiguousarray(x, dtype=self.dtype)
+        assert x.ndim == 2 and x.shape[1] == self.n
+        if out is None:
+            out = np.empty_like(x)
+        getattr(lib(), f"oracle_fourier_batch_run_{self._s}")(self._c, x.ctypes.data, out.ctypes.data, x.shape[0], transform)
+        return out
+
+    def __del__(self):
+        c, self._c = getattr(self, "_c", None), None
+        if c:
+            getattr(lib(), f"oracle_fourier_batch_destroy_{self._s}")(c)
+
+
+def transform_batch(x, transform=FFT, nthreads=1):
+    """x: (batch, n) complex array -> oracle transform of every row."""
+    x = np.ascontiguousarray(x)
+    return OracleBatch(x.shape[1], x.dtype, nthreads).run(x, transform)
+
+
+def radix_counts(size):
+    c = (ctypes.c_size_t * 5)()
+    ok = lib().oracle_fourier_counts(size, c)
+    return list(c) if ok else None
