@@ -1,0 +1,579 @@
+// engine.cpp -- host side of libfourier.so: plan factory, pass scheduling, C ABI.
+//
+// Mirrors the reference's plan layer one level up:
+//   create_fft_f32/f64  (fourier/src/lib.rs:31-60)        -> Plan<T>::create      (Stockham, else Bluestein)
+//   Autosort::new       (autosort/mod.rs:104-134)         -> Pow2Engine<T>        (big-radix pass schedule)
+//   initialize_twiddles (autosort/mod.rs:24-46)           -> make_stage_tables / make_two_level (f64 trig, cast)
+//   Bluesteins::new     (bluesteins.rs:109-130, :18-61)   -> Plan<T>::init_bluestein
+//   apply_stages / apply (mod.rs:313-404, bluesteins.rs:215-259) -> Plan<T>::exec
+//   fourier-ffi C ABI   (fourier-ffi/src/lib.rs:14-106)   -> extern "C" block at the end
+// Compiled with hipcc for gfx950; the same file builds against tests/emu/hipemu.h (-DFOURIER_EMU)
+// for CPU-side logic tests only.
+#ifndef FOURIER_EMU
+#include <hip/hip_runtime.h>
+#endif
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "fft_kernels.h"
+#include "../../include/fourier.h"
+
+namespace fourier_hip {
+
+struct EngineError : std::runtime_error {
+  int status;
+  EngineError(int s, const std::string& m) : std::runtime_error(m), status(s) {}
+};
+
+#define HIP_CHECK(expr)                                                                             \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess)                                                                           \
+      throw EngineError(e_ == hipErrorOutOfMemory ? ::fourier::c::FOURIER_HIP_OUT_OF_MEMORY         \
+                                                  : ::fourier::c::FOURIER_HIP_RUNTIME_ERROR,        \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                         \
+  } while (0)
+
+#ifdef FOURIER_EMU
+#define FOURIER_LAUNCH(fn, grid, block, smem, stream, arg) hipemu::launch(dim3((unsigned)(grid)), dim3((unsigned)(block)), (smem), (fn), (arg))
+#else
+#define FOURIER_LAUNCH(fn, grid, block, smem, stream, arg)                                \
+  do {                                                                                    \
+    (fn)<<<dim3((unsigned)(grid)), dim3((unsigned)(block)), (smem), (stream)>>>(arg);     \
+    HIP_CHECK(hipGetLastError());                                                         \
+  } while (0)
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// device memory RAII
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevBuf() {}
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  void ensure(size_t n) {
+    if (n <= bytes) return;
+    release();
+    HIP_CHECK(hipMalloc(&p, n));
+    bytes = n;
+  }
+  template <typename V> void upload(const std::vector<V>& h) {
+    ensure(h.size() * sizeof(V));
+    if (!h.empty()) HIP_CHECK(hipMemcpy(p, h.data(), h.size() * sizeof(V), hipMemcpyHostToDevice));
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// kernel registry: one tile shape (CG) per pass length L
+typedef void (*PassKernel)(PassArgs);
+struct KernelInfo {
+  PassKernel fn = nullptr;
+  int L = 0, CG = 0, NT = 0, COLS = 0, R3 = 0;
+  size_t smem = 0;
+};
+
+template <typename T, int L, int CG, int MODE> static KernelInfo make_info() {
+  using C = TileCfg<T, L, CG>;
+  KernelInfo k;
+  k.fn = &fft_pass_kernel<T, L, CG, MODE>;
+  k.L = L; k.CG = CG; k.NT = C::NT; k.COLS = C::COLS; k.R3 = C::R3;
+  k.smem = C::smem_bytes(MODE);
+  return k;
+}
+
+template <typename T> static KernelInfo get_kernel(int L, int mode) {
+#define FK(LL, CGG)                                                         \
+  case LL:                                                                  \
+    switch (mode) {                                                         \
+      case MODE_FIRST: return make_info<T, LL, CGG, MODE_FIRST>();          \
+      case MODE_MID: return make_info<T, LL, CGG, MODE_MID>();              \
+      case MODE_LAST: return make_info<T, LL, CGG, MODE_LAST>();            \
+      default: return make_info<T, LL, CGG, MODE_ROWS>();                   \
+    }
+#define FK_ROWS_ONLY(LL, CGG) \
+  case LL: return make_info<T, LL, CGG, MODE_ROWS>();
+  switch (L) {
+    FK_ROWS_ONLY(16, 64)
+    FK_ROWS_ONLY(32, 32)
+    FK(64, 16)
+    FK(128, 16)
+    FK(256, 16)
+    FK(512, 8)
+    FK(1024, 8)
+    FK(2048, 4)
+    default: break;
+  }
+#undef FK
+#undef FK_ROWS_ONLY
+  throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "no kernel for pass length " + std::to_string(L));
+}
+
+static inline int ilog2(uint64_t v) { int l = 0; while ((1ull << l) < v) ++l; return l; }
+static inline bool is_pow2(uint64_t v) { return v && !(v & (v - 1)); }
+
+// exp(-2*pi*i*e/size) in f64 (the reference evaluates twiddles in f64 and casts: twiddle.rs:7-19)
+static inline void unit_root(uint64_t e, uint64_t size, double& re, double& im) {
+  e %= size;
+  // octant reduction keeps the argument small so the f64 result is correctly rounded to ~1 ulp
+  const double frac = (double)e / (double)size;  // exact for power-of-two sizes
+  const double ang = 2.0 * M_PI * frac;
+  re = std::cos(ang);
+  im = -std::sin(ang);
+  if (4 * e == size) { re = 0; im = -1; }
+  else if (2 * e == size) { re = -1; im = 0; }
+  else if (4 * e == 3 * size) { re = 0; im = 1; }
+  else if (e == 0) { re = 1; im = 0; }
+}
+
+template <typename T> struct StageTables {
+  DevBuf tw1, tw2;
+};
+
+template <typename T> static void make_stage_tables(int L, StageTables<T>& st) {
+  const int Q = L / 16, R2 = Q >= 16 ? 16 : Q, R3 = Q / (R2 ? R2 : 1);
+  std::vector<cpx<T>> t1((size_t)Q * 16);
+  for (int th = 0; th < Q; ++th)
+    for (int k = 0; k < 16; ++k) {
+      double re, im;
+      unit_root((uint64_t)th * k, (uint64_t)L, re, im);
+      t1[(size_t)th * 16 + k] = {(T)re, (T)im};
+    }
+  st.tw1.upload(t1);
+  if (Q > 1 && R3 > 1) {
+    std::vector<cpx<T>> t2((size_t)R3 * 16);
+    for (int i = 0; i < R3; ++i)
+      for (int k = 0; k < 16; ++k) {
+        double re, im;
+        unit_root((uint64_t)i * k, (uint64_t)Q, re, im);
+        t2[(size_t)i * 16 + k] = {(T)re, (T)im};
+      }
+    st.tw2.upload(t2);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// batched power-of-two FFT: schedule of big-radix Stockham passes
+template <typename T> class Pow2Engine {
+ public:
+  struct Pass {
+    int mode;
+    KernelInfo k;
+    uint64_t s, size, cn;
+    uint32_t lo_bits = 0;
+    DevBuf tw_lo, tw_hi;
+    StageTables<T>* st = nullptr;
+  };
+
+  explicit Pow2Engine(size_t n) : n_(n) {
+    if (!is_pow2(n)) throw EngineError(::fourier::c::FOURIER_HIP_INVALID_ARGUMENT, "Pow2Engine: size not a power of two");
+    const int k = ilog2(n);
+    std::vector<int> lens;
+    if (k <= 3) {
+      tiny_ = true;
+    } else if (k <= 11) {
+      lens = {k};
+    } else if (k <= 22) {
+      lens = {(k + 1) / 2, k / 2};
+    } else if (k <= 30) {
+      const int k1 = (k + 2) / 3, k2 = (k - k1 + 1) / 2, k3 = k - k1 - k2;
+      lens = {k1, k2, k3};
+    } else {
+      throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "power-of-two sizes above 2^30 are not supported");
+    }
+    uint64_t s = 1, size = n;
+    for (size_t p = 0; p < lens.size(); ++p) {
+      auto pass = std::unique_ptr<Pass>(new Pass());
+      const int L = 1 << lens[p];
+      pass->mode = lens.size() == 1 ? MODE_ROWS : (p == 0 ? MODE_FIRST : (p + 1 == lens.size() ? MODE_LAST : MODE_MID));
+      pass->k = get_kernel<T>(L, pass->mode);
+      pass->s = s; pass->size = size; pass->cn = n / L;
+      if (pass->mode != MODE_ROWS) {
+        const uint64_t extent = (pass->mode == MODE_FIRST) ? pass->cn : s;
+        if (extent % (uint64_t)pass->k.COLS != 0)
+          throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "tile does not divide pass extent");
+      }
+      auto it = stage_.find(L);
+      if (it == stage_.end()) {
+        auto st = std::unique_ptr<StageTables<T>>(new StageTables<T>());
+        make_stage_tables<T>(L, *st);
+        it = stage_.emplace(L, std::move(st)).first;
+      }
+      pass->st = it->second.get();
+      if (pass->mode == MODE_FIRST || pass->mode == MODE_MID) {
+        // two-level table of W_size^{e}: e = (e >> lo_bits) << lo_bits | (e & mask)
+        const int lb = (ilog2(size) + 1) / 2;
+        pass->lo_bits = (uint32_t)lb;
+        std::vector<cpx<T>> lo((size_t)1 << lb), hi((size_t)(size >> lb));
+        for (size_t e = 0; e < lo.size(); ++e) { double re, im; unit_root(e, size, re, im); lo[e] = {(T)re, (T)im}; }
+        for (size_t h = 0; h < hi.size(); ++h) { double re, im; unit_root((uint64_t)h << lb, size, re, im); hi[h] = {(T)re, (T)im}; }
+        pass->tw_lo.upload(lo);
+        pass->tw_hi.upload(hi);
+      }
+#ifndef FOURIER_EMU
+      if (pass->k.smem > 48 * 1024)
+        HIP_CHECK(hipFuncSetAttribute((const void*)pass->k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass->k.smem));
+#endif
+      passes_.push_back(std::move(pass));
+      s *= (uint64_t)L;
+      size /= (uint64_t)L;
+    }
+  }
+
+  size_t size() const { return n_; }
+  size_t num_passes() const { return tiny_ ? 1 : passes_.size(); }
+  bool needs_scratch(bool in_place) const { return passes_.size() == 3 || (passes_.size() == 2 && in_place); }
+  std::string describe() const {
+    if (tiny_) return "tiny(" + std::to_string(n_) + ")";
+    std::string d;
+    for (size_t p = 0; p < passes_.size(); ++p) d += (p ? "x" : "") + std::to_string(passes_[p]->k.L);
+    return d;
+  }
+
+  // Transform `batch` contiguous transforms.  in == out is allowed; scratch must hold batch*n
+  // elements when needs_scratch(in == out) (or when force_scratch is set).
+  void run(const cpx<T>* in, cpx<T>* out, cpx<T>* scratch, size_t batch, bool inverse, double scale, const cpx<T>* mul,
+           bool force_scratch, hipStream_t stream) const {
+    if (batch == 0) return;
+    if (tiny_) {
+      TinyArgs a{in, out, mul, (uint64_t)batch, (int)n_, inverse, inverse, scale};
+      FOURIER_LAUNCH(&tiny_dft_kernel<T>, (batch + 255) / 256, 256, 0, stream, a);
+      return;
+    }
+    const size_t np = passes_.size();
+    const bool in_place = ((const void*)in == (const void*)out);
+    const cpx<T>* src[3] = {in, nullptr, nullptr};
+    cpx<T>* dst[3] = {out, nullptr, nullptr};
+    if (np == 2) {
+      cpx<T>* X = (in_place || force_scratch) ? scratch : out;
+      dst[0] = X; src[1] = X; dst[1] = out;
+    } else if (np == 3) {
+      if (in_place) { dst[0] = scratch; src[1] = scratch; dst[1] = out; src[2] = out; dst[2] = out; }
+      else { dst[0] = out; src[1] = out; dst[1] = scratch; src[2] = scratch; dst[2] = out; }
+    }
+    for (size_t p = 0; p < np; ++p) {
+      const Pass& ps = *passes_[p];
+      PassArgs a;
+      std::memset(&a, 0, sizeof(a));
+      a.in = src[p]; a.out = dst[p];
+      a.tw1 = ps.st->tw1.p; a.tw2 = ps.st->tw2.p;
+      a.tw_lo = ps.tw_lo.p; a.tw_hi = ps.tw_hi.p;
+      a.mul = (p + 1 == np) ? mul : nullptr;
+      a.n = n_; a.cn = ps.cn; a.s = ps.s;
+      a.lo_bits = ps.lo_bits;
+      a.swap_in = (p == 0) && inverse;
+      a.swap_out = (p + 1 == np) && inverse;
+      a.scale = (p + 1 == np) ? scale : 1.0;
+      uint64_t grid;
+      if (ps.mode == MODE_ROWS) {
+        a.total_cols = batch;
+        a.tiles = 1;
+        grid = (batch + ps.k.COLS - 1) / ps.k.COLS;
+      } else {
+        a.tiles = ps.cn / ps.k.COLS;
+        grid = (uint64_t)batch * a.tiles;
+      }
+      if (grid > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");
+      FOURIER_LAUNCH(ps.k.fn, grid, ps.k.NT, ps.k.smem, stream, a);
+    }
+  }
+
+ private:
+  size_t n_;
+  bool tiny_ = false;
+  std::vector<std::unique_ptr<Pass>> passes_;
+  std::map<int, std::unique_ptr<StageTables<T>>> stage_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// host f64 radix-2 FFT, used only at plan time for the Bluestein w table (bluesteins.rs:46-47)
+static void host_fft(std::vector<double>& re, std::vector<double>& im) {
+  const size_t m = re.size();
+  for (size_t i = 1, j = 0; i < m; ++i) {
+    size_t bit = m >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+  }
+  std::vector<double> wr(m / 2 ? m / 2 : 1), wi(m / 2 ? m / 2 : 1);
+  for (size_t k = 0; k < m / 2; ++k) unit_root(k, m, wr[k], wi[k]);
+  for (size_t len = 2; len <= m; len <<= 1) {
+    const size_t half = len / 2, step = m / len;
+    for (size_t i = 0; i < m; i += len)
+      for (size_t k = 0; k < half; ++k) {
+        const double ur = wr[k * step], ui = wi[k * step];
+        const double xr = re[i + k + half] * ur - im[i + k + half] * ui;
+        const double xi = re[i + k + half] * ui + im[i + k + half] * ur;
+        re[i + k + half] = re[i + k] - xr; im[i + k + half] = im[i + k] - xi;
+        re[i + k] += xr; im[i + k] += xi;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T> class Plan {
+ public:
+  static constexpr size_t ELEM = sizeof(cpx<T>);
+
+  Plan(size_t n, int device) : n_(n) {
+    if (n == 0) throw EngineError(::fourier::c::FOURIER_HIP_INVALID_ARGUMENT, "size 0 is invalid");
+    int count = 0;
+    HIP_CHECK(hipGetDeviceCount(&count));
+    if (count <= 0) throw EngineError(::fourier::c::FOURIER_HIP_RUNTIME_ERROR, "no HIP device");
+    if (device < 0) HIP_CHECK(hipGetDevice(&device));
+    if (device >= count) throw EngineError(::fourier::c::FOURIER_HIP_INVALID_ARGUMENT, "bad device index");
+    device_ = device;
+    DeviceGuard g(device_);
+    if (is_pow2(n)) {
+      eng_.reset(new Pow2Engine<T>(n));
+      desc_ = "stockham " + eng_->describe();
+    } else {
+      init_bluestein();
+      desc_ = "bluestein M=" + std::to_string(m_) + " inner " + eng_->describe();
+    }
+    desc_ += sizeof(T) == 4 ? " f32" : " f64";
+  }
+
+  size_t size() const { return n_; }
+  const char* describe() const { return desc_.c_str(); }
+  int last_status() const { return status_; }
+  void set_status(int s) const { status_ = s; }
+
+  double model_bytes() const {
+    if (!blu_) return 2.0 * n_ * ELEM * eng_->num_passes();
+    // pre (n read + table + m write) + 2 inner FFTs + w table + post (m.. n read, table, n write)
+    return (double)ELEM * ((2.0 * n_ + m_) + 2.0 * 2.0 * m_ * eng_->num_passes() + m_ + 3.0 * n_);
+  }
+
+  int set_option(const std::string& key, long long v) {
+    if (key == "chunk_bytes" && v >= 0) { chunk_bytes_ = (size_t)v; return 0; }
+    if (key == "scratch" && (v == 0 || v == 1)) { force_scratch_ = (v == 1); return 0; }
+    return ::fourier::c::FOURIER_HIP_INVALID_ARGUMENT;
+  }
+
+  // Batched transform on device memory (the operator behind Fft::transform / transform_in_place).
+  void exec(const void* d_in, void* d_out, size_t batch, int code, hipStream_t stream) const {
+    if (!d_in || !d_out) throw EngineError(::fourier::c::FOURIER_HIP_INVALID_ARGUMENT, "null buffer");
+    if (code < 0 || code > 4) throw EngineError(::fourier::c::FOURIER_HIP_INVALID_ARGUMENT, "unknown transform code");
+    if (batch == 0) return;
+    DeviceGuard g(device_);
+    // fft.rs:20-25 is_forward; autosort/mod.rs:381-385 scale computed in T
+    const bool inverse = !(code == ::fourier::c::FOURIER_TRANSFORM_FFT || code == ::fourier::c::FOURIER_TRANSFORM_SQRT_SCALED_FFT);
+    double scale = 1.0;
+    if (code == ::fourier::c::FOURIER_TRANSFORM_IFFT) scale = (double)((T)1 / (T)n_);
+    else if (code == ::fourier::c::FOURIER_TRANSFORM_SQRT_SCALED_FFT || code == ::fourier::c::FOURIER_TRANSFORM_SQRT_SCALED_IFFT)
+      scale = (double)((T)1 / std::sqrt((T)n_));
+    const cpx<T>* in = (const cpx<T>*)d_in;
+    cpx<T>* out = (cpx<T>*)d_out;
+    const bool in_place = (d_in == d_out);
+    const size_t per = (blu_ ? m_ : n_) * ELEM;
+    size_t chunk = batch;
+    if (chunk_bytes_) chunk = std::max<size_t>(1, std::min<size_t>(batch, chunk_bytes_ / per));
+    // keep every launch's grid below 2^31 blocks
+    while (chunk > 1 && (double)chunk * (double)(blu_ ? m_ : n_) / 16.0 > 2.0e9) chunk = (chunk + 1) / 2;
+
+    if (!blu_) {
+      const bool need = eng_->needs_scratch(in_place) || (force_scratch_ && eng_->num_passes() >= 2);
+      if (need) scratch_.ensure(chunk * n_ * ELEM);
+      for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+        const size_t nb = std::min(chunk, batch - b0);
+        eng_->run(in + b0 * n_, out + b0 * n_, (cpx<T>*)scratch_.p, nb, inverse, scale, nullptr, force_scratch_, stream);
+      }
+      return;
+    }
+    // Bluestein (bluesteins.rs:215-259): work = x.in (zero padded) ; FFT_M ; .w ; IFFT_M ; out = work.x.scale
+    work_.ensure(chunk * m_ * ELEM);
+    if (eng_->needs_scratch(true)) scratch_.ensure(chunk * m_ * ELEM);
+    cpx<T>* work = (cpx<T>*)work_.p;
+    for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+      const size_t nb = std::min(chunk, batch - b0);
+      BluArgs pre{in + b0 * n_, work, xtab_.p, (uint64_t)n_, (uint64_t)m_, (uint64_t)nb, inverse, 1.0};
+      FOURIER_LAUNCH(&blu_pre_kernel<T>, elementwise_grid(nb * m_), 256, 0, stream, pre);
+      eng_->run(work, work, (cpx<T>*)scratch_.p, nb, false, 1.0, (const cpx<T>*)wtab_.p, false, stream);
+      eng_->run(work, work, (cpx<T>*)scratch_.p, nb, true, 1.0, nullptr, false, stream);
+      BluArgs post{work, out + b0 * n_, xtab_.p, (uint64_t)n_, (uint64_t)m_, (uint64_t)nb, inverse, scale};
+      FOURIER_LAUNCH(&blu_post_kernel<T>, elementwise_grid(nb * n_), 256, 0, stream, post);
+    }
+  }
+
+  // Legacy host-buffer path (fourier-ffi/src/lib.rs:31-59): H2D, one transform, D2H, synchronous.
+  void exec_host(const void* h_in, void* h_out, int code) const {
+    if (!h_in || !h_out) throw EngineError(::fourier::c::FOURIER_HIP_INVALID_ARGUMENT, "null buffer");
+    if (code < 0 || code > 4) return;  // unknown code: silent no-op (lib.rs:10)
+    DeviceGuard g(device_);
+    hostio_.ensure(n_ * ELEM);
+    HIP_CHECK(hipMemcpy(hostio_.p, h_in, n_ * ELEM, hipMemcpyHostToDevice));
+    exec(hostio_.p, hostio_.p, 1, code, (hipStream_t)0);
+    HIP_CHECK(hipStreamSynchronize((hipStream_t)0));
+    HIP_CHECK(hipMemcpy(h_out, hostio_.p, n_ * ELEM, hipMemcpyDeviceToHost));
+  }
+
+ private:
+  struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+      if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+      if (prev != dev) (void)hipSetDevice(dev);
+      else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  };
+  static unsigned elementwise_grid(size_t elems) {
+    const size_t blocks = (elems + 255) / 256;
+    return (unsigned)std::min<size_t>(std::max<size_t>(blocks, 1), 256 * 32);
+  }
+
+  void init_bluestein() {
+    blu_ = true;
+    if (n_ > ((size_t)1 << 26)) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "Bluestein sizes above 2^26 are not supported");
+    m_ = 1;
+    while (m_ < 2 * n_ - 1) m_ <<= 1;  // bluesteins.rs:110
+    eng_.reset(new Pow2Engine<T>(m_));
+    // chirp exp(-i*pi*k^2/n), angle reduced exactly with k^2 mod 2n (the reference leaves it
+    // unreduced, bluesteins.rs:10,31,57; the reduction only removes f64 argument error)
+    std::vector<double> cr(n_), ci(n_);
+    const uint64_t two_n = 2 * (uint64_t)n_;
+    for (size_t k = 0; k < n_; ++k) {
+      const uint64_t r = (uint64_t)(((unsigned __int128)k * k) % two_n);
+      const double ang = M_PI * (double)r / (double)n_;
+      cr[k] = std::cos(ang); ci[k] = -std::sin(ang);
+    }
+    std::vector<cpx<T>> x(n_);
+    for (size_t k = 0; k < n_; ++k) x[k] = {(T)cr[k], (T)ci[k]};  // x_fwd, bluesteins.rs:51-61
+    xtab_.upload(x);
+    // w = FFT_M(conj chirp, mirrored) (bluesteins.rs:18-48), evaluated in f64 on the host, with the
+    // inner IFFT's 1/M (bluesteins.rs:239 -> mod.rs:383) folded in.
+    std::vector<double> wr(m_, 0.0), wi(m_, 0.0);
+    for (size_t k = 0; k < n_; ++k) {
+      wr[k] = cr[k]; wi[k] = -ci[k];
+      if (k) { wr[m_ - k] = cr[k]; wi[m_ - k] = -ci[k]; }
+    }
+    host_fft(wr, wi);
+    std::vector<cpx<T>> w(m_);
+    const double inv_m = 1.0 / (double)m_;
+    for (size_t k = 0; k < m_; ++k) w[k] = {(T)(wr[k] * inv_m), (T)(wi[k] * inv_m)};
+    wtab_.upload(w);
+  }
+
+  size_t n_, m_ = 0;
+  int device_ = 0;
+  bool blu_ = false;
+  std::unique_ptr<Pow2Engine<T>> eng_;
+  DevBuf xtab_, wtab_;
+  mutable DevBuf scratch_, work_, hostio_;
+  size_t chunk_bytes_ = 0;
+  bool force_scratch_ = false;
+  mutable int status_ = 0;
+  std::string desc_;
+};
+
+template <typename T> static Plan<T>* create_plan(size_t n, int device) {
+  try {
+    return new Plan<T>(n, device);
+  } catch (...) {
+    return nullptr;  // never unwind into C (fourier-ffi/src/lib.rs:18-19)
+  }
+}
+
+template <typename T, typename F> static int guarded(const Plan<T>* p, F&& f) {
+  if (!p) return ::fourier::c::FOURIER_HIP_INVALID_ARGUMENT;
+  try {
+    f();
+    return ::fourier::c::FOURIER_HIP_OK;
+  } catch (const EngineError& e) {
+    p->set_status(e.status);
+    if (getenv("FOURIER_HIP_VERBOSE")) fprintf(stderr, "libfourier: %s\n", e.what());
+    return e.status;
+  } catch (const std::bad_alloc&) {
+    p->set_status(::fourier::c::FOURIER_HIP_OUT_OF_MEMORY);
+    return ::fourier::c::FOURIER_HIP_OUT_OF_MEMORY;
+  } catch (...) {
+    p->set_status(::fourier::c::FOURIER_HIP_RUNTIME_ERROR);
+    return ::fourier::c::FOURIER_HIP_RUNTIME_ERROR;
+  }
+}
+
+}  // namespace fourier_hip
+
+// ---------------------------------------------------------------------------------------------
+// C ABI (declared in include/fourier.h)
+using namespace fourier_hip;
+namespace fc = ::fourier::c;
+
+#define FOURIER_DEFINE_ABI(T, SUFFIX)                                                                            \
+  extern "C" fc::fourier_fft_##SUFFIX* fourier_create_##SUFFIX(size_t size) {                                    \
+    return (fc::fourier_fft_##SUFFIX*)create_plan<T>(size, -1);                                                  \
+  }                                                                                                              \
+  extern "C" fc::fourier_fft_##SUFFIX* fourier_hip_create_##SUFFIX(size_t size, int device) {                    \
+    return (fc::fourier_fft_##SUFFIX*)create_plan<T>(size, device);                                              \
+  }                                                                                                              \
+  extern "C" void fourier_destroy_##SUFFIX(fc::fourier_fft_##SUFFIX* h) {                                        \
+    try { delete (Plan<T>*)h; } catch (...) {}                                                                   \
+  }                                                                                                              \
+  extern "C" void fourier_transform_in_place_##SUFFIX(const fc::fourier_fft_##SUFFIX* h, std::complex<T>* x, int code) { \
+    const Plan<T>* p = (const Plan<T>*)h;                                                                        \
+    (void)guarded<T>(p, [&] { p->exec_host(x, x, code); });                                                      \
+  }                                                                                                              \
+  extern "C" void fourier_transform_##SUFFIX(const fc::fourier_fft_##SUFFIX* h, const std::complex<T>* in,       \
+                                             std::complex<T>* out, int code) {                                   \
+    const Plan<T>* p = (const Plan<T>*)h;                                                                        \
+    (void)guarded<T>(p, [&] { p->exec_host(in, out, code); });                                                   \
+  }                                                                                                              \
+  extern "C" size_t fourier_hip_size_##SUFFIX(const fc::fourier_fft_##SUFFIX* h) {                               \
+    return h ? ((const Plan<T>*)h)->size() : 0;                                                                  \
+  }                                                                                                              \
+  extern "C" int fourier_hip_transform_batch_##SUFFIX(const fc::fourier_fft_##SUFFIX* h, const void* d_in,       \
+                                                      void* d_out, size_t batch, int code, void* stream) {       \
+    const Plan<T>* p = (const Plan<T>*)h;                                                                        \
+    return guarded<T>(p, [&] { p->exec(d_in, d_out, batch, code, (hipStream_t)stream); });                       \
+  }                                                                                                              \
+  extern "C" int fourier_hip_last_status_##SUFFIX(const fc::fourier_fft_##SUFFIX* h) {                           \
+    return h ? ((const Plan<T>*)h)->last_status() : fc::FOURIER_HIP_INVALID_ARGUMENT;                            \
+  }                                                                                                              \
+  extern "C" int fourier_hip_set_option_##SUFFIX(fc::fourier_fft_##SUFFIX* h, const char* key, long long v) {    \
+    if (!h || !key) return fc::FOURIER_HIP_INVALID_ARGUMENT;                                                     \
+    try { return ((Plan<T>*)h)->set_option(key, v); } catch (...) { return fc::FOURIER_HIP_INVALID_ARGUMENT; }   \
+  }                                                                                                              \
+  extern "C" const char* fourier_hip_describe_##SUFFIX(const fc::fourier_fft_##SUFFIX* h) {                      \
+    return h ? ((const Plan<T>*)h)->describe() : "";                                                             \
+  }                                                                                                              \
+  extern "C" double fourier_hip_model_bytes_##SUFFIX(const fc::fourier_fft_##SUFFIX* h) {                        \
+    return h ? ((const Plan<T>*)h)->model_bytes() : 0.0;                                                         \
+  }
+
+FOURIER_DEFINE_ABI(float, float)
+FOURIER_DEFINE_ABI(double, double)
+
+extern "C" const char* fourier_hip_status_string(int status) {
+  switch (status) {
+    case fc::FOURIER_HIP_OK: return "ok";
+    case fc::FOURIER_HIP_INVALID_ARGUMENT: return "invalid argument";
+    case fc::FOURIER_HIP_OUT_OF_MEMORY: return "out of device memory";
+    case fc::FOURIER_HIP_RUNTIME_ERROR: return "HIP runtime error";
+    case fc::FOURIER_HIP_UNSUPPORTED: return "unsupported size";
+    default: return "unknown status";
+  }
+}
+
+#ifdef FOURIER_EMU
+// test-only: LDS bank-conflict statistics gathered by the emulator
+extern "C" void fourier_emu_lds_stats(uint64_t* instr, uint64_t* cycles, uint64_t* ideal, int reset) {
+  auto& s = hipemu::lds_stats();
+  *instr = s.instr; *cycles = s.cycles; *ideal = s.ideal;
+  if (reset) { s.instr = 0; s.cycles = 0; s.ideal = 0; }
+}
+#endif

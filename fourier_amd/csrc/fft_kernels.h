@@ -1,0 +1,496 @@
+// fft_kernels.h -- gfx950 device code of the batched 1D c2c FFT engine.
+//
+// What it computes (reference: fourier-algorithms/src/autosort/mod.rs:203-284, one Stockham
+// autosort pass `out[j + R*s*i + s*k] = W_size^{i*k} * DFT_R(in[j + s*i + s*m*k'])_k`) -- but with
+// a *big* radix R = L in {16..2048} per HBM round trip instead of the reference's 2/3/4/8, so that
+// N = 2^20 needs 2 sweeps of HBM instead of the reference's 7 (+2 copies).  Inside a pass the
+// L-point DFT of every column is itself a Stockham autosort of radix 16 x R2 x R3 (mod.rs:20-21
+// radix schedule idea, re-derived for a 64-wide wavefront): each thread keeps 16 points of VEC
+// adjacent columns in registers, does the radix-16/8/4/2 butterflies there
+// (autosort/butterfly.rs:3-65 equivalents), and exchanges through LDS between stages.
+//
+// Data layout: interleaved complex (re,im), AoS, exactly the reference's Complex<T>
+// (fourier-ffi/include/fourier.h:10-11,23-24).  A "unit" is 16 bytes = VEC complex numbers of
+// adjacent columns (VEC=2 for f32, 1 for f64): every global access of the column-tile modes is one
+// 16-byte unit per lane, 128-byte segments per tile row.
+//
+// Inverse transforms use IDFT(x) = swap(DFT(swap(x))) with swap = exchange re<->im, applied at the
+// first load / last store, so all twiddle tables are forward-only.
+#pragma once
+#include <stdint.h>
+
+#ifdef FOURIER_EMU
+#define FOURIER_DYN_SMEM(name) unsigned char* name = hipemu::smem()
+#define LDS_NOTE(p, bytes, w, site) hipemu::lds_note((p), (bytes), (w), (site))
+#else
+#include <hip/hip_runtime.h>
+#define FOURIER_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#define LDS_NOTE(p, bytes, w, site)
+#endif
+
+namespace fourier_hip {
+
+template <typename T> struct cpx { T re, im; };
+template <typename T> struct alignas(16) Unit16 { T a[16 / sizeof(T)]; };  // VEC interleaved complex
+template <typename T> struct alignas(8) Unit8 { T a[8 / sizeof(T)]; };     // one plane of VEC columns
+
+enum { MODE_FIRST = 0, MODE_MID = 1, MODE_LAST = 2, MODE_ROWS = 3 };
+
+// Kernel argument block (passed by value).
+struct PassArgs {
+  const void* in;
+  void* out;
+  const void* tw1;    // [Q][16]  W_L^{th*k}            (stage-1 twiddles)
+  const void* tw2;    // [R3][16] W_Q^{i*k}             (stage-2 twiddles, only when R3 > 1)
+  const void* tw_lo;  // W_size^{e},          e < 2^lo_bits     } two-level table of the
+  const void* tw_hi;  // W_size^{h<<lo_bits}, h < size>>lo_bits } inter-pass twiddle W_size^{i*k}
+  const void* mul;    // optional pointwise multiplier applied on store, indexed by output index
+  uint64_t n;         // elements per transform (batch stride)
+  uint64_t cn;        // columns of this pass = n / L
+  uint64_t s;         // Stockham stride = product of the previous passes' lengths
+  uint64_t tiles;     // column tiles per transform = cn / COLS
+  uint64_t total_cols;  // ROWS mode: number of transforms in this launch
+  uint32_t lo_bits;
+  int swap_in, swap_out;
+  double scale;       // applied on the final store (LAST / ROWS)
+};
+
+template <typename T> __device__ __forceinline__ cpx<T> cmul(cpx<T> a, cpx<T> b) {
+  return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+}
+template <typename T> __device__ __forceinline__ void bf2(cpx<T>& a, cpx<T>& b) {
+  const cpx<T> t = a;
+  a = {t.re + b.re, t.im + b.im};
+  b = {t.re - b.re, t.im - b.im};
+}
+template <typename T> __device__ __forceinline__ cpx<T> mul_neg_i(cpx<T> z) { return {z.im, -z.re}; }
+
+// ---- small forward DFTs, natural order in and out (W = exp(-2*pi*i/R)) ----
+template <typename T> __device__ __forceinline__ void dft2(cpx<T>* x) { bf2(x[0], x[1]); }
+
+template <typename T> __device__ __forceinline__ void dft4(cpx<T>& x0, cpx<T>& x1, cpx<T>& x2, cpx<T>& x3) {
+  bf2(x0, x2);
+  bf2(x1, x3);
+  x3 = mul_neg_i(x3);
+  bf2(x0, x1);  // x0 = X0, x1 = X2
+  bf2(x2, x3);  // x2 = X1, x3 = X3
+  const cpx<T> t = x1; x1 = x2; x2 = t;
+}
+template <typename T> __device__ __forceinline__ void dft4(cpx<T>* x) { dft4(x[0], x[1], x[2], x[3]); }
+
+template <typename T> __device__ __forceinline__ void dft8(cpx<T>* x) {
+  const T c = (T)0.70710678118654752440;
+  dft4(x[0], x[2], x[4], x[6]);  // E0..E3 in x0,x2,x4,x6
+  dft4(x[1], x[3], x[5], x[7]);  // O0..O3 in x1,x3,x5,x7
+  x[3] = {c * (x[3].re + x[3].im), c * (x[3].im - x[3].re)};   // * W8^1
+  x[5] = mul_neg_i(x[5]);                                       // * W8^2
+  x[7] = {c * (x[7].im - x[7].re), -c * (x[7].re + x[7].im)};  // * W8^3
+  bf2(x[0], x[1]);  // X0, X4
+  bf2(x[2], x[3]);  // X1, X5
+  bf2(x[4], x[5]);  // X2, X6
+  bf2(x[6], x[7]);  // X3, X7
+  const cpx<T> y1 = x[2], y2 = x[4], y3 = x[6], y4 = x[1], y5 = x[3], y6 = x[5];
+  x[1] = y1; x[2] = y2; x[3] = y3; x[4] = y4; x[5] = y5; x[6] = y6;
+}
+
+template <typename T> __device__ __forceinline__ void dft16(cpx<T>* x) {
+  const T c1 = (T)0.92387953251128675613;  // cos(pi/8)
+  const T s1 = (T)0.38268343236508977173;  // sin(pi/8)
+  const T c2 = (T)0.70710678118654752440;
+  // n = a + 4b : DFT over b for each a; result kb stored at slot a + 4*kb
+#pragma unroll
+  for (int a = 0; a < 4; ++a) dft4(x[a], x[a + 4], x[a + 8], x[a + 12]);
+  // twiddle W16^{a*kb}
+  x[5] = cmul(x[5], cpx<T>{c1, -s1});                                   // a=1,kb=1: W^1
+  x[9] = {c2 * (x[9].re + x[9].im), c2 * (x[9].im - x[9].re)};         // a=1,kb=2: W^2
+  x[13] = cmul(x[13], cpx<T>{s1, -c1});                                 // a=1,kb=3: W^3
+  x[6] = {c2 * (x[6].re + x[6].im), c2 * (x[6].im - x[6].re)};         // a=2,kb=1: W^2
+  x[10] = mul_neg_i(x[10]);                                            // a=2,kb=2: W^4
+  x[14] = {c2 * (x[14].im - x[14].re), -c2 * (x[14].re + x[14].im)};   // a=2,kb=3: W^6
+  x[7] = cmul(x[7], cpx<T>{s1, -c1});                                   // a=3,kb=1: W^3
+  x[11] = {c2 * (x[11].im - x[11].re), -c2 * (x[11].re + x[11].im)};   // a=3,kb=2: W^6
+  x[15] = cmul(x[15], cpx<T>{-c1, s1});                                 // a=3,kb=3: W^9
+  // DFT over a for each kb; result ka at slot ka + 4*kb holds X[kb + 4*ka]
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) dft4(x[4 * kb], x[4 * kb + 1], x[4 * kb + 2], x[4 * kb + 3]);
+  // transpose 4x4 to natural order
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = a + 1; b < 4; ++b) {
+      const cpx<T> t = x[a + 4 * b]; x[a + 4 * b] = x[b + 4 * a]; x[b + 4 * a] = t;
+    }
+}
+
+template <typename T, int R> __device__ __forceinline__ void dft_r(cpx<T>* x) {
+  if constexpr (R == 2) dft2(x);
+  else if constexpr (R == 4) dft4(x);
+  else if constexpr (R == 8) dft8(x);
+  else if constexpr (R == 16) dft16(x);
+}
+
+// ---- tile configuration ----
+template <typename T, int L, int CG> struct TileCfg {
+  static constexpr int VEC = 16 / (2 * (int)sizeof(T));  // complex numbers per 16-byte unit
+  static constexpr int COLS = CG * VEC;                  // columns per tile
+  static constexpr int Q = L / 16;                       // threads per column
+  static constexpr int NT = Q * CG;                      // threads per workgroup
+  static constexpr int R2 = Q >= 16 ? 16 : Q;            // second-stage radix (1 = none)
+  static constexpr int R3 = Q / R2;                      // third-stage radix (1 = none)
+  // LDS exchange buffer: units indexed [pos][cg] plus a skew so that lanes walking `pos` at fixed
+  // cg (the row-contiguous mapping) hit distinct banks.
+  static constexpr int PADU = (Q == 1) ? 0 : ((CG >= 32) ? L : (L * CG) / 32);
+  static constexpr int UNITS = (Q == 1) ? 0 : L * CG + PADU;
+  static constexpr bool SPLIT = (size_t)UNITS * 16 > 80 * 1024;  // exchange re and im planes separately
+  static constexpr size_t EXCH_BYTES = SPLIT ? (size_t)UNITS * 8 : (size_t)UNITS * 16;
+  static constexpr size_t TABU_OFF = (EXCH_BYTES + 15) & ~(size_t)15;
+  static constexpr size_t TABU_BYTES = (size_t)COLS * 16 * sizeof(cpx<T>);
+  static constexpr size_t SMEM_FIRST = TABU_OFF + TABU_BYTES;
+  static constexpr size_t SMEM_MID = TABU_OFF + 16 * sizeof(cpx<T>);
+  static constexpr size_t SMEM_PLAIN = EXCH_BYTES;
+  static __host__ __device__ constexpr size_t smem_bytes(int mode) {
+    return mode == MODE_FIRST ? SMEM_FIRST : (mode == MODE_MID ? SMEM_MID : SMEM_PLAIN);
+  }
+  static __device__ __forceinline__ int unit_index(int pos, int cg) {
+    return pos * CG + cg + ((CG >= 32) ? pos : ((pos * CG) >> 5));
+  }
+};
+
+// Exchange through LDS: register r of this thread goes to position wpos(r) of column group cg_w;
+// afterwards register r holds position th_r + Q*r of column group cg_r.
+template <typename T, int L, int CG> using RegTile = cpx<T>[TileCfg<T, L, CG>::VEC][16];
+
+template <typename T, int L, int CG, typename WPos>
+__device__ __forceinline__ void lds_exchange(RegTile<T, L, CG>& x, unsigned char* smem, int cg_w, WPos wpos, int th_r,
+                                             int cg_r, unsigned site) {
+  using C = TileCfg<T, L, CG>;
+  constexpr int VEC = C::VEC, Q = C::Q;
+  if constexpr (C::SPLIT) {
+    Unit8<T>* lds = (Unit8<T>*)smem;
+#pragma unroll
+    for (int plane = 0; plane < 2; ++plane) {
+      if (plane == 1) __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        Unit8<T> u;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) u.a[v] = plane ? x[v][r].im : x[v][r].re;
+        Unit8<T>* p = lds + C::unit_index(wpos(r), cg_w);
+        LDS_NOTE(p, 8, true, site + plane);
+        *p = u;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const Unit8<T>* p = lds + C::unit_index(th_r + Q * r, cg_r);
+        LDS_NOTE(p, 8, false, site + 2 + plane);
+        const Unit8<T> u = *p;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          if (plane) x[v][r].im = u.a[v]; else x[v][r].re = u.a[v];
+        }
+      }
+    }
+  } else {
+    Unit16<T>* lds = (Unit16<T>*)smem;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      Unit16<T> u;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) { u.a[2 * v] = x[v][r].re; u.a[2 * v + 1] = x[v][r].im; }
+      Unit16<T>* p = lds + C::unit_index(wpos(r), cg_w);
+      LDS_NOTE(p, 16, true, site);
+      *p = u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const Unit16<T>* p = lds + C::unit_index(th_r + Q * r, cg_r);
+      LDS_NOTE(p, 16, false, site + 2);
+      const Unit16<T> u = *p;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
+    }
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ cpx<T> two_level_twiddle(const PassArgs& a, uint64_t e) {
+  const cpx<T>* lo = (const cpx<T>*)a.tw_lo;
+  const cpx<T>* hi = (const cpx<T>*)a.tw_hi;
+  const uint64_t el = e & ((1ull << a.lo_bits) - 1), eh = e >> a.lo_bits;
+  return cmul(lo[el], hi[eh]);
+}
+
+// One big-radix Stockham pass over a tile of COLS columns (or COLS whole transforms in ROWS mode).
+//   MODE_FIRST: s == 1. column-tile load, transposed (row-contiguous) store, twiddle W_size^{i*k}.
+//   MODE_MID  : s >= COLS. column-tile load/store, twiddle W_size^{i*k} with i uniform per tile.
+//   MODE_LAST : size == L. column-tile load/store, no twiddle; mul / swap_out / scale on store.
+//   MODE_ROWS : whole transforms of length L, contiguous rows; mul / swap_out / scale on store.
+template <typename T, int L, int CG, int MODE>
+__global__ void __launch_bounds__((L / 16) * CG) fft_pass_kernel(PassArgs a) {
+  using C = TileCfg<T, L, CG>;
+  constexpr int VEC = C::VEC, Q = C::Q, R2 = C::R2, R3 = C::R3, COLS = C::COLS;
+  constexpr bool IN_ROWS = (MODE == MODE_ROWS);
+  constexpr bool OUT_ROWS = (MODE == MODE_FIRST || MODE == MODE_ROWS);
+  constexpr bool TWIDDLED = (MODE == MODE_FIRST || MODE == MODE_MID);
+  constexpr bool FINAL = (MODE == MODE_LAST || MODE == MODE_ROWS);
+  FOURIER_DYN_SMEM(smem);
+
+  const int tid = (int)threadIdx.x;
+  // cg-fastest mapping ("A") for column-tile I/O, th-fastest ("B") for row-contiguous I/O
+  int th = IN_ROWS ? tid % Q : tid / CG;
+  int cg = IN_ROWS ? tid / Q : tid % CG;
+  const int thB = tid % Q, cgB = tid / Q;
+
+  const uint64_t blk = blockIdx.x;
+  const cpx<T>* __restrict__ in = (const cpx<T>*)a.in;
+  cpx<T>* __restrict__ out = (cpx<T>*)a.out;
+  uint64_t b = 0, c0 = 0, g0 = 0;
+  if constexpr (IN_ROWS) {
+    g0 = blk * COLS;
+  } else {
+    b = blk / a.tiles;
+    c0 = (blk % a.tiles) * COLS;
+    g0 = b * a.cn + c0;
+  }
+
+  // ---- inter-pass twiddle table for this tile: tabU[col][r] = W_size^{i_col * Q * r}
+  if constexpr (TWIDDLED) {
+    cpx<T>* tabU = (cpx<T>*)(smem + C::TABU_OFF);
+    if constexpr (MODE == MODE_FIRST) {
+      for (int idx = tid; idx < COLS * 16; idx += C::NT) {
+        const uint64_t i = c0 + (uint64_t)(idx >> 4);
+        tabU[idx] = two_level_twiddle<T>(a, i * (uint64_t)(Q * (idx & 15)));
+      }
+    } else {
+      if (tid < 16) tabU[tid] = two_level_twiddle<T>(a, (c0 / a.s) * (uint64_t)(Q * tid));
+    }
+  }
+
+  // ---- load: register r <- row th + Q*r
+  cpx<T> x[VEC][16];
+  if constexpr (IN_ROWS) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const uint64_t g = g0 + (uint64_t)(cg * VEC + v);
+      const bool valid = g < a.total_cols;
+      const cpx<T>* p = in + g * L + th;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[v][r] = valid ? p[Q * r] : cpx<T>{0, 0};
+    }
+  } else {
+    const cpx<T>* p = in + b * a.n + (uint64_t)th * a.cn + c0 + (uint64_t)(cg * VEC);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const Unit16<T> u = *(const Unit16<T>*)(p + (uint64_t)(Q * r) * a.cn);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
+    }
+  }
+  if (a.swap_in) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[v][r] = {x[v][r].im, x[v][r].re};
+  }
+
+  // ---- stage 1: radix 16 over rows th + Q*k'  ->  positions 16*th + k, twiddle W_L^{th*k}
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) dft16(x[v]);
+
+  if constexpr (Q > 1) {
+    {
+      const cpx<T>* t1 = (const cpx<T>*)a.tw1 + th * 16;
+#pragma unroll
+      for (int k = 1; k < 16; ++k) {
+        const cpx<T> w = t1[k];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) x[v][k] = cmul(x[v][k], w);
+      }
+    }
+    {
+      const bool remap = (MODE == MODE_FIRST) && (R3 == 1);
+      const int th_r = remap ? thB : th, cg_r = remap ? cgB : cg;
+      const int th_w = th;
+      lds_exchange<T, L, CG>(x, smem, cg, [=](int r) { return 16 * th_w + r; }, th_r, cg_r, 0);
+      th = th_r; cg = cg_r;
+    }
+
+    // ---- stage 2: radix R2 on butterflies q = th + Q*u (register sets {u + NB2*k'})
+    constexpr int NB2 = 16 / R2;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+#pragma unroll
+      for (int u = 0; u < NB2; ++u) {
+        cpx<T> t[R2];
+#pragma unroll
+        for (int k = 0; k < R2; ++k) t[k] = x[v][u + NB2 * k];
+        dft_r<T, R2>(t);
+#pragma unroll
+        for (int k = 0; k < R2; ++k) x[v][u + NB2 * k] = t[k];
+      }
+
+    if constexpr (R3 > 1) {
+      // here R2 == 16, one butterfly per thread: q = th, j = th & 15, i = th >> 4
+      {
+        const cpx<T>* t2 = (const cpx<T>*)a.tw2 + (th >> 4) * 16;
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+          const cpx<T> w = t2[k];
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) x[v][k] = cmul(x[v][k], w);
+        }
+      }
+      {
+        const bool remap = (MODE == MODE_FIRST);
+        const int th_r = remap ? thB : th, cg_r = remap ? cgB : cg;
+        const int jw = th & 15, iw = th >> 4;
+        __syncthreads();  // all reads of exchange 1 are done before the buffer is rewritten
+        lds_exchange<T, L, CG>(x, smem, cg, [=](int r) { return jw + 16 * (16 * iw + r); }, th_r, cg_r, 4);
+        th = th_r; cg = cg_r;
+      }
+      // ---- stage 3: radix R3 on register sets {u + NB3*k'}
+      constexpr int NB3 = 16 / R3;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v)
+#pragma unroll
+        for (int u = 0; u < NB3; ++u) {
+          cpx<T> t[R3];
+#pragma unroll
+          for (int k = 0; k < R3; ++k) t[k] = x[v][u + NB3 * k];
+          dft_r<T, R3>(t);
+#pragma unroll
+          for (int k = 0; k < R3; ++k) x[v][u + NB3 * k] = t[k];
+        }
+    }
+  }
+  // now register r holds output index k = th + Q*r of columns (cg*VEC + v)
+
+  // ---- inter-pass twiddle W_size^{i*k} = W^{i*th} * tabU[col][r]
+  if constexpr (TWIDDLED) {
+    if constexpr (Q == 1) __syncthreads();  // tabU visibility when there was no exchange barrier
+    const cpx<T>* tabU = (const cpx<T>*)(smem + C::TABU_OFF);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const uint64_t i = (MODE == MODE_FIRST) ? c0 + (uint64_t)(cg * VEC + v) : c0 / a.s;
+      const cpx<T> base = two_level_twiddle<T>(a, i * (uint64_t)th);
+      const cpx<T>* tu = (MODE == MODE_FIRST) ? tabU + (cg * VEC + v) * 16 : tabU;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[v][r] = cmul(x[v][r], cmul(base, tu[r]));
+    }
+  }
+
+  // ---- store
+  const T scale = (T)a.scale;
+  const cpx<T>* __restrict__ mul = (const cpx<T>*)a.mul;
+  if constexpr (OUT_ROWS) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const uint64_t g = g0 + (uint64_t)(cg * VEC + v);
+      if (MODE == MODE_ROWS && g >= a.total_cols) continue;
+      cpx<T>* p = out + g * L + th;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        cpx<T> y = x[v][r];
+        if constexpr (FINAL) {
+          if (mul) y = cmul(y, mul[th + Q * r]);
+          if (a.swap_out) y = {y.im, y.re};
+          y = {y.re * scale, y.im * scale};
+        }
+        p[Q * r] = y;
+      }
+    }
+  } else {
+    const uint64_t i = c0 / a.s, j0 = c0 % a.s;
+    const uint64_t off = j0 + (uint64_t)(cg * VEC) + a.s * ((uint64_t)L * i + (uint64_t)th);
+    cpx<T>* p = out + b * a.n + off;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      Unit16<T> u;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        cpx<T> y = x[v][r];
+        if constexpr (FINAL) {
+          if (mul) y = cmul(y, mul[off + a.s * (uint64_t)(Q * r) + v]);
+          if (a.swap_out) y = {y.im, y.re};
+          y = {y.re * scale, y.im * scale};
+        }
+        u.a[2 * v] = y.re; u.a[2 * v + 1] = y.im;
+      }
+      *(Unit16<T>*)(p + a.s * (uint64_t)(Q * r)) = u;
+    }
+  }
+}
+
+// ---- transforms of length 1, 2, 4, 8: one thread per transform ----
+struct TinyArgs {
+  const void* in; void* out; const void* mul;
+  uint64_t batch; int n; int swap_in, swap_out; double scale;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) tiny_dft_kernel(TinyArgs a) {
+  const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= a.batch) return;
+  const cpx<T>* in = (const cpx<T>*)a.in + b * a.n;
+  cpx<T>* out = (cpx<T>*)a.out + b * a.n;
+  const cpx<T>* mul = (const cpx<T>*)a.mul;
+  cpx<T> x[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    x[i] = (i < a.n) ? in[i] : cpx<T>{0, 0};
+    if (a.swap_in) x[i] = {x[i].im, x[i].re};
+  }
+  if (a.n == 2) dft2(x); else if (a.n == 4) dft4(x); else if (a.n == 8) dft8(x);
+  const T scale = (T)a.scale;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i < a.n) {
+      cpx<T> y = x[i];
+      if (mul) y = cmul(y, mul[i]);
+      if (a.swap_out) y = {y.im, y.re};
+      out[i] = {y.re * scale, y.im * scale};
+    }
+  }
+}
+
+// ---- Bluestein chirp-z pointwise steps (reference: fourier-algorithms/src/bluesteins.rs:229-258) ----
+struct BluArgs {
+  const void* in; void* out; const void* xtab;
+  uint64_t n, m, batch; int swap; double scale;
+};
+// work[b][i] = x[i] * in[b][i] for i < n, 0 for n <= i < m      (bluesteins.rs:229-234)
+template <typename T>
+__global__ void __launch_bounds__(256) blu_pre_kernel(BluArgs a) {
+  const cpx<T>* in = (const cpx<T>*)a.in;
+  cpx<T>* work = (cpx<T>*)a.out;
+  const cpx<T>* xt = (const cpx<T>*)a.xtab;
+  const uint64_t total = a.batch * a.m;
+  for (uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * 256) {
+    const uint64_t b = idx / a.m, i = idx - b * a.m;
+    cpx<T> y{0, 0};
+    if (i < a.n) {
+      cpx<T> v = in[b * a.n + i];
+      if (a.swap) v = {v.im, v.re};
+      y = cmul(xt[i], v);
+    }
+    work[idx] = y;
+  }
+}
+// out[b][i] = work[b][i] * x[i] * scale for i < n                (bluesteins.rs:240-258)
+template <typename T>
+__global__ void __launch_bounds__(256) blu_post_kernel(BluArgs a) {
+  const cpx<T>* work = (const cpx<T>*)a.in;
+  cpx<T>* out = (cpx<T>*)a.out;
+  const cpx<T>* xt = (const cpx<T>*)a.xtab;
+  const T scale = (T)a.scale;
+  const uint64_t total = a.batch * a.n;
+  for (uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * 256) {
+    const uint64_t b = idx / a.n, i = idx - b * a.n;
+    cpx<T> y = cmul(work[b * a.m + i], xt[i]);
+    if (a.swap) y = {y.im, y.re};
+    out[idx] = {y.re * scale, y.im * scale};
+  }
+}
+
+}  // namespace fourier_hip

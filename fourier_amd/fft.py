@@ -1,0 +1,152 @@
+"""Host-side mirror of the reference's operator interface for the FFT path.
+
+Same names, argument meaning and error behaviour as the reference:
+  * `Transform`                  -- fourier-algorithms/src/fft.rs:4-37
+  * `Fft` (size / transform_in_place / transform / fft / ifft ...) -- fft.rs:40-82
+  * `create_fft_f32`, `create_fft_f64` -- fourier/src/lib.rs:31-60
+plus the batched, device-resident entry point the GPU path is measured on (the reference has no
+batch API: fft.rs:48-61 takes one slice per call).
+
+Buffers: numpy complex64/complex128 arrays go through the legacy host ABI (H2D + D2H inside the
+library); torch CUDA tensors go through the device-resident batched ABI on the current stream.
+All compute happens in libfourier.so (HIP); there is no CPU fallback.
+"""
+import enum
+
+import numpy as np
+
+from . import _lib
+
+
+class Transform(enum.IntEnum):
+    """fourier-algorithms/src/fft.rs:4-16; integer values = the C codes (fourier-ffi/src/lib.rs:3-12)."""
+
+    Fft = 0
+    Ifft = 1
+    UnscaledIfft = 2
+    SqrtScaledFft = 3
+    SqrtScaledIfft = 4
+
+    def is_forward(self):  # fft.rs:20-25
+        return self in (Transform.Fft, Transform.SqrtScaledFft)
+
+    def inverse(self):  # fft.rs:28-36
+        return {Transform.Fft: Transform.Ifft, Transform.Ifft: Transform.Fft,
+                Transform.SqrtScaledFft: Transform.SqrtScaledIfft,
+                Transform.SqrtScaledIfft: Transform.SqrtScaledFft}.get(self)
+
+
+class FourierError(RuntimeError):
+    pass
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class Fft:
+    """The `Fft` trait (fft.rs:40-82) over a libfourier.so plan handle."""
+
+    def __init__(self, size, real, device=-1):
+        self._suffix = {"f32": "float", "f64": "double"}[real]
+        self.real = real
+        self.np_dtype = np.dtype(np.complex64 if real == "f32" else np.complex128)
+        self._L = _lib.lib()
+        self._h = getattr(self._L, f"fourier_hip_create_{self._suffix}")(int(size), int(device))
+        if not self._h:
+            # the reference's create panics -> NULL through the FFI (fourier-ffi/src/lib.rs:18-19)
+            raise FourierError(f"cannot create FFT plan of size {size}")
+        self._n = int(size)
+
+    # -- trait surface ---------------------------------------------------------------------
+    def size(self):
+        return self._n
+
+    def transform_in_place(self, input, transform):
+        """fft.rs:48: in-place transform of exactly `size` elements (or batch*size, see below)."""
+        self._dispatch(input, input, transform)
+
+    def transform(self, input, output, transform):
+        """fft.rs:51-61: out-of-place; asserts both lengths equal size()."""
+        self._dispatch(input, output, transform)
+
+    def fft_in_place(self, input):  # fft.rs:64-66
+        self.transform_in_place(input, Transform.Fft)
+
+    def ifft_in_place(self, input):  # fft.rs:69-71
+        self.transform_in_place(input, Transform.Ifft)
+
+    def fft(self, input, output):  # fft.rs:74-76
+        self.transform(input, output, Transform.Fft)
+
+    def ifft(self, input, output):  # fft.rs:79-81
+        self.transform(input, output, Transform.Ifft)
+
+    # -- batched device-resident extension -------------------------------------------------
+    def transform_batch_ptr(self, d_in, d_out, batch, transform, stream=0):
+        """Raw-pointer form: `batch` contiguous transforms on device memory, enqueued on `stream`."""
+        st = getattr(self._L, f"fourier_hip_transform_batch_{self._suffix}")(
+            self._h, d_in, d_out, int(batch), int(transform), stream)
+        if st != 0:
+            raise FourierError(self._L.fourier_hip_status_string(st).decode())
+
+    def set_option(self, key, value):
+        st = getattr(self._L, f"fourier_hip_set_option_{self._suffix}")(self._h, key.encode(), int(value))
+        if st != 0:
+            raise FourierError(f"bad option {key}={value}")
+
+    def describe(self):
+        return getattr(self._L, f"fourier_hip_describe_{self._suffix}")(self._h).decode()
+
+    def model_bytes(self):
+        return getattr(self._L, f"fourier_hip_model_bytes_{self._suffix}")(self._h)
+
+    # -- plumbing --------------------------------------------------------------------------
+    def _dispatch(self, input, output, transform):
+        code = int(transform)
+        if _is_torch(input) or _is_torch(output):
+            import torch
+
+            want = torch.complex64 if self.real == "f32" else torch.complex128
+            for t in (input, output):
+                if not (_is_torch(t) and t.is_cuda and t.dtype == want and t.is_contiguous()):
+                    raise TypeError(f"expected contiguous CUDA {want} tensors")
+            # the reference asserts input.len() == output.len() == size (fft.rs:57-58); the batched
+            # extension accepts any whole number of transforms
+            if input.numel() != output.numel() or input.numel() % self._n != 0 or input.numel() == 0:
+                raise ValueError(f"buffer of {input.numel()} elements is not a multiple of size {self._n}")
+            stream = torch.cuda.current_stream(input.device).cuda_stream
+            self.transform_batch_ptr(input.data_ptr(), output.data_ptr(), input.numel() // self._n, code, stream)
+            return
+        for a in (input, output):
+            if not (isinstance(a, np.ndarray) and a.dtype == self.np_dtype and a.flags.c_contiguous):
+                raise TypeError(f"expected C-contiguous numpy {self.np_dtype} arrays")
+        if input.size != self._n or output.size != self._n:
+            raise ValueError(f"buffer length {input.size}/{output.size} != size {self._n}")  # fft.rs:57-58
+        if not output.flags.writeable:
+            raise ValueError("output is read-only")
+        if input is output or input.ctypes.data == output.ctypes.data:
+            getattr(self._L, f"fourier_transform_in_place_{self._suffix}")(self._h, output.ctypes.data, code)
+        else:
+            getattr(self._L, f"fourier_transform_{self._suffix}")(self._h, input.ctypes.data, output.ctypes.data, code)
+        st = getattr(self._L, f"fourier_hip_last_status_{self._suffix}")(self._h)
+        if st != 0:
+            raise FourierError(self._L.fourier_hip_status_string(st).decode())
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                getattr(self._L, f"fourier_destroy_{self._suffix}")(h)
+            except Exception:
+                pass
+
+
+def create_fft_f32(size, device=-1):
+    """fourier/src/lib.rs:31-43."""
+    return Fft(size, "f32", device)
+
+
+def create_fft_f64(size, device=-1):
+    """fourier/src/lib.rs:49-60."""
+    return Fft(size, "f64", device)

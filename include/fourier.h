@@ -1,0 +1,181 @@
+/* fourier.h -- C ABI of the MI355X-native FFT engine (libfourier.so).
+ *
+ * Part 1 is byte-compatible with the reference's C header, calebzulawski/fourier
+ * `fourier-ffi/include/fourier.h:30-58` (implementation `fourier-ffi/src/lib.rs:14-106`): same
+ * symbol names, argument meaning, transform codes and error behaviour, so existing C/C++ users and
+ * the reference's own `Fft` trait (fourier-algorithms/src/fft.rs:40-82, through the Rust shim shown
+ * in INTEGRATION.md) relink against this library unchanged.  The 8 legacy entry points take HOST
+ * buffers of exactly `size` elements (no length argument, as in the reference) and are synchronous.
+ *
+ * Part 2 is the new surface the reversed boundary needs: batched execution
+ * on device-resident interleaved buffers, stream-ordered, plus status queries.  The reference has
+ * no batch API (fft.rs:48-61 is one slice per call); batching is what the GPU path is measured on.
+ *
+ * Handles are Send, not Sync -- like the reference's plans (RefCell scratch,
+ * fourier-algorithms/src/autosort/mod.rs:54): one thread / one stream at a time per handle.
+ */
+#ifndef FOURIER_H_
+#define FOURIER_H_
+
+#ifdef __cplusplus
+#include <complex>
+#include <cstddef>
+#include <memory>
+#define FOURIER_COMPLEX_FLOAT_TYPE ::std::complex<float>
+#define FOURIER_COMPLEX_DOUBLE_TYPE ::std::complex<double>
+#define FOURIER_SIZE_TYPE ::std::size_t
+#define FOURIER_STRUCT
+namespace fourier {
+namespace c {
+extern "C" {
+#else
+#include <stddef.h>
+#define FOURIER_COMPLEX_FLOAT_TYPE float _Complex
+#define FOURIER_COMPLEX_DOUBLE_TYPE double _Complex
+#define FOURIER_SIZE_TYPE size_t
+#define FOURIER_STRUCT struct
+#endif
+
+/* ---------------- Part 1: legacy ABI (replaces fourier-ffi/include/fourier.h:30-58) ---------- */
+
+/* Transform codes: fourier.h:30-36, fourier-ffi/src/lib.rs:3-12, fourier-algorithms/src/fft.rs:4-16 */
+enum {
+  FOURIER_TRANSFORM_FFT = 0,              /* forward, unscaled                */
+  FOURIER_TRANSFORM_IFFT = 1,             /* inverse, scaled by 1/N           */
+  FOURIER_TRANSFORM_UNSCALED_IFFT = 2,    /* inverse, unscaled                */
+  FOURIER_TRANSFORM_SQRT_SCALED_FFT = 3,  /* forward, scaled by 1/sqrt(N)     */
+  FOURIER_TRANSFORM_SQRT_SCALED_IFFT = 4, /* inverse, scaled by 1/sqrt(N)     */
+};
+
+struct fourier_fft_float;
+struct fourier_fft_double;
+
+/* replaces fourier.h:41-42 / lib.rs:15-20,62-67.  NULL on failure (the reference returns NULL when
+ * plan creation panics, lib.rs:18-19).  size == 0 returns NULL (the reference hangs). */
+struct fourier_fft_float *fourier_create_float(FOURIER_SIZE_TYPE);
+struct fourier_fft_double *fourier_create_double(FOURIER_SIZE_TYPE);
+
+/* replaces fourier.h:44-45 / lib.rs:22-29,69-76.  NULL is a no-op. */
+void fourier_destroy_float(FOURIER_STRUCT fourier_fft_float *);
+void fourier_destroy_double(FOURIER_STRUCT fourier_fft_double *);
+
+/* replaces fourier.h:47-51 / lib.rs:31-43,78-90.  Host buffer of `size` elements, in place.
+ * Unknown transform code: silent no-op, buffer untouched (lib.rs:10). */
+void fourier_transform_in_place_float(const FOURIER_STRUCT fourier_fft_float *,
+                                      FOURIER_COMPLEX_FLOAT_TYPE *, int);
+void fourier_transform_in_place_double(
+    const FOURIER_STRUCT fourier_fft_double *, FOURIER_COMPLEX_DOUBLE_TYPE *,
+    int);
+
+/* replaces fourier.h:53-58 / lib.rs:45-59,92-106.  Host buffers, out of place (in == out allowed). */
+void fourier_transform_float(const FOURIER_STRUCT fourier_fft_float *,
+                             const FOURIER_COMPLEX_FLOAT_TYPE *,
+                             FOURIER_COMPLEX_FLOAT_TYPE *, int);
+void fourier_transform_double(const FOURIER_STRUCT fourier_fft_double *,
+                              const FOURIER_COMPLEX_DOUBLE_TYPE *,
+                              FOURIER_COMPLEX_DOUBLE_TYPE *, int);
+
+/* ---------------- Part 2: device-resident batched extension (new surface) -------------------- */
+
+/* Status codes returned by the fourier_hip_* calls and by fourier_hip_last_status_*. */
+enum {
+  FOURIER_HIP_OK = 0,
+  FOURIER_HIP_INVALID_ARGUMENT = 1, /* NULL handle/pointer, unknown transform code, bad option   */
+  FOURIER_HIP_OUT_OF_MEMORY = 2,    /* device allocation failed                                  */
+  FOURIER_HIP_RUNTIME_ERROR = 3,    /* a HIP call or kernel launch failed                        */
+  FOURIER_HIP_UNSUPPORTED = 4,      /* size outside the engine's range                           */
+};
+
+/* Create a plan on a specific device (-1 = current device).  Same plan factory as
+ * `create_fft_f32/f64` (fourier/src/lib.rs:31-60): Stockham for power-of-two sizes, Bluestein
+ * chirp-z (fourier-algorithms/src/bluesteins.rs) for every other size.  NULL on failure. */
+struct fourier_fft_float *fourier_hip_create_float(FOURIER_SIZE_TYPE size, int device);
+struct fourier_fft_double *fourier_hip_create_double(FOURIER_SIZE_TYPE size, int device);
+
+/* `Fft::size()` (fft.rs:45). 0 for a NULL handle. */
+FOURIER_SIZE_TYPE fourier_hip_size_float(const FOURIER_STRUCT fourier_fft_float *);
+FOURIER_SIZE_TYPE fourier_hip_size_double(const FOURIER_STRUCT fourier_fft_double *);
+
+/* Batched `Fft::transform` on DEVICE memory: `batch` contiguous transforms, transform b at element
+ * offset b*size, interleaved complex.  d_in == d_out selects in-place (`transform_in_place`).
+ * Enqueued on `stream` (a hipStream_t, NULL = default stream); returns without synchronising.
+ * Partial overlap of d_in and d_out is not allowed. */
+int fourier_hip_transform_batch_float(const FOURIER_STRUCT fourier_fft_float *, const void *d_in,
+                                      void *d_out, FOURIER_SIZE_TYPE batch, int transform,
+                                      void *stream);
+int fourier_hip_transform_batch_double(const FOURIER_STRUCT fourier_fft_double *, const void *d_in,
+                                       void *d_out, FOURIER_SIZE_TYPE batch, int transform,
+                                       void *stream);
+
+/* Sticky status of the last failing call on this handle (FOURIER_HIP_OK if none) and its text. */
+int fourier_hip_last_status_float(const FOURIER_STRUCT fourier_fft_float *);
+int fourier_hip_last_status_double(const FOURIER_STRUCT fourier_fft_double *);
+const char *fourier_hip_status_string(int status);
+
+/* Tunables (return FOURIER_HIP_OK or FOURIER_HIP_INVALID_ARGUMENT):
+ *   "chunk_bytes"  bytes of one batch chunk pushed through all passes before the next chunk starts
+ *                  (keeps the inter-pass intermediate inside the 256 MiB Infinity Cache); 0 = whole batch
+ *   "scratch"      1 = always route the intermediate through the plan's reused scratch buffer,
+ *                  0 = use the output buffer as intermediate when out of place (default) */
+int fourier_hip_set_option_float(FOURIER_STRUCT fourier_fft_float *, const char *key, long long value);
+int fourier_hip_set_option_double(FOURIER_STRUCT fourier_fft_double *, const char *key, long long value);
+
+/* Human-readable plan description ("stockham 1024x1024 ..."), valid until the handle is destroyed. */
+const char *fourier_hip_describe_float(const FOURIER_STRUCT fourier_fft_float *);
+const char *fourier_hip_describe_double(const FOURIER_STRUCT fourier_fft_double *);
+
+/* HBM bytes this plan reads+writes per transform across all its kernels (design traffic model). */
+double fourier_hip_model_bytes_float(const FOURIER_STRUCT fourier_fft_float *);
+double fourier_hip_model_bytes_double(const FOURIER_STRUCT fourier_fft_double *);
+
+#ifdef __cplusplus
+} /* extern "C" */
+} /* namespace c */
+
+/* Header-only C++ RAII wrapper, same shape as the reference's (fourier.h:64-128). */
+enum class transform {
+  fft = ::fourier::c::FOURIER_TRANSFORM_FFT,
+  ifft = ::fourier::c::FOURIER_TRANSFORM_IFFT,
+  unscaled_ifft = ::fourier::c::FOURIER_TRANSFORM_UNSCALED_IFFT,
+  sqrt_scaled_fft = ::fourier::c::FOURIER_TRANSFORM_SQRT_SCALED_FFT,
+  sqrt_scaled_ifft = ::fourier::c::FOURIER_TRANSFORM_SQRT_SCALED_IFFT,
+};
+
+template <typename T> struct fft;
+
+#define FOURIER_DEFINE_CXX_WRAPPER(T, SUFFIX)                                                      \
+  template <> struct fft<T> {                                                                      \
+    explicit fft(std::size_t size)                                                                 \
+        : impl(::fourier::c::fourier_create_##SUFFIX(size), ::fourier::c::fourier_destroy_##SUFFIX) {} \
+    fft() = delete;                                                                                \
+    fft(const fft &) = delete;                                                                     \
+    fft(fft &&) = default;                                                                         \
+    fft &operator=(const fft &) = delete;                                                          \
+    fft &operator=(fft &&) = default;                                                              \
+    ~fft() = default;                                                                              \
+    void transform_in_place(::std::complex<T> *x, transform t) const {                             \
+      ::fourier::c::fourier_transform_in_place_##SUFFIX(impl.get(), x, static_cast<int>(t));       \
+    }                                                                                              \
+    void transform(const ::std::complex<T> *in, ::std::complex<T> *out, transform t) const {       \
+      ::fourier::c::fourier_transform_##SUFFIX(impl.get(), in, out, static_cast<int>(t));          \
+    }                                                                                              \
+    /* device-resident batched execution (extension) */                                           \
+    int transform_batch_device(const void *d_in, void *d_out, std::size_t batch,               \
+                               ::fourier::transform t,                                            \
+                               void *stream = nullptr) const {                                     \
+      return ::fourier::c::fourier_hip_transform_batch_##SUFFIX(impl.get(), d_in, d_out, batch,    \
+                                                                static_cast<int>(t), stream);      \
+    }                                                                                              \
+    explicit operator bool() const { return static_cast<bool>(impl); }                             \
+                                                                                                   \
+  private:                                                                                         \
+    ::std::unique_ptr<::fourier::c::fourier_fft_##SUFFIX, void (*)(::fourier::c::fourier_fft_##SUFFIX *)> impl; \
+  };
+FOURIER_DEFINE_CXX_WRAPPER(float, float)
+FOURIER_DEFINE_CXX_WRAPPER(double, double)
+#undef FOURIER_DEFINE_CXX_WRAPPER
+
+} /* namespace fourier */
+#endif
+
+#endif /* FOURIER_H_ */

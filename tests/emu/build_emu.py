@@ -1,0 +1,29 @@
+"""TEST-ONLY: builds the engine sources against tests/emu/hipemu.h (CPU fibers) so kernel logic,
+plan logic and the C ABI can be exercised without a GPU.  Not a product path."""
+import ctypes
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+SRC = os.path.join(ROOT, "fourier_amd", "csrc", "engine.cpp")
+DEPS = [SRC, os.path.join(ROOT, "fourier_amd", "csrc", "fft_kernels.h"), os.path.join(HERE, "hipemu.h"),
+        os.path.join(ROOT, "include", "fourier.h")]
+OUT = os.path.join(HERE, "libfourier_emu.so")
+
+
+def build():
+    if os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
+        return OUT
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFOURIER_EMU", "-include", os.path.join(HERE, "hipemu.h"),
+                           "-shared", "-fPIC", "-pthread", "-o", OUT, SRC])
+    return OUT
+
+
+def load():
+    from fourier_amd import _lib
+
+    cdll = _lib.bind(ctypes.CDLL(build()))
+    cdll.fourier_emu_lds_stats.restype = None
+    cdll.fourier_emu_lds_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)] * 3 + [ctypes.c_int]
+    return cdll
