@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the batched 1D c2c FFT hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched under
+torch.distributed.run, one rank per GPU.  A "step" is one pass of the hot path over one batch of
+synthetic input: BASELINE.json configs[1], batched 1D c2c f32, N=2^20, batch=4096 per GPU,
+forward `Transform::Fft`, out of place, inputs resident in HBM before the timed region.
+Rank 0 prints ONE JSON line.  metric = nominal 5*N*log2(N) GFLOP/s, whole job (all ranks).
+
+Extra objects in the JSON line:
+  roofline     -- dominant kernel, algorithmic bytes per launch / HIP-event duration (events on the
+                  launch stream, inside this process), peak 8 TB/s; `traffic` from the committed
+                  rocprofv3 PMC pass (profiles/traffic_latest.json) or null.
+  cpu_baseline -- the oracle (CPU restatement of the reference, kind "port") timed on this box's host
+                  cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--log2n", type=int, default=20)
+    p.add_argument("--batch", type=int, default=4096, help="transforms per GPU per step")
+    p.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    p.add_argument("--chunk-bytes", type=int, default=None, help="override the plan's chunk_bytes option")
+    p.add_argument("--scratch", type=int, default=None, help="override the plan's scratch option (0/1)")
+    p.add_argument("--inplace", action="store_true")
+    p.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    p.add_argument("--cpu-sample", type=int, default=0, help="transforms in the CPU sample (0 = auto)")
+    return p.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the hot path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import fourier_amd
+    from fourier_amd import Transform
+
+    n = 1 << args.log2n
+    batch = args.batch
+    cdt = torch.complex64 if args.dtype == "f32" else torch.complex128
+    esz = 8 if args.dtype == "f32" else 16
+    plan = (fourier_amd.create_fft_f32 if args.dtype == "f32" else fourier_amd.create_fft_f64)(n, local_rank)
+    if args.chunk_bytes is not None:
+        plan.set_option("chunk_bytes", args.chunk_bytes)
+    if args.scratch is not None:
+        plan.set_option("scratch", args.scratch)
+
+    # synthetic input: re, im i.i.d. uniform [0,1) (the reference bench recipe, fft_bench.rs:18-23)
+    torch.manual_seed(0x5EED0001 + rank)
+    x = torch.empty((batch, n), dtype=cdt, device=dev)
+    torch.view_as_real(x).uniform_(0.0, 1.0)
+    y = x if args.inplace else torch.empty_like(x)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        plan.transform_batch_ptr(x.data_ptr(), y.data_ptr(), batch, int(Transform.Fft), stream)
+
+    # host copy of the parity / CPU-baseline sample, taken before anything can overwrite the input
+    hx = None
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if rank == 0 and world == 1 and not args.no_cpu:
+        sample = min(batch, args.cpu_sample or max(8, min(256, 2 * cores)))
+        hx = x[:sample].cpu().numpy()
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    flops_per = 5.0 * n * math.log2(n)
+    alg_bytes_per = 2.0 * n * esz  # each point read once + written once
+    total_units = world * batch * args.steps
+    gflops = total_units * flops_per / elapsed / 1e9
+    alg_gbps = total_units * alg_bytes_per / elapsed / 1e9
+    ms_per_step = elapsed / args.steps * 1e3
+
+    out = {
+        "metric": "batched 1D c2c FFT GFLOP/s (5N*log2N), f32 N=2^20" if (args.dtype == "f32" and args.log2n == 20)
+        else f"batched 1D c2c FFT GFLOP/s (5N*log2N), {args.dtype} N=2^{args.log2n}",
+        "value": round(gflops, 1),
+        "unit": "GFLOP/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {
+            "workload": f"batched 1D c2c {args.dtype} N=2^{args.log2n} batch={batch}/GPU forward "
+                        f"{'in-place' if args.inplace else 'out-of-place'} (BASELINE configs[1])",
+            "n": n, "batch_per_gpu": batch, "global_batch": world * batch, "parallelism": f"batch-shard x{world}",
+            "plan": plan.describe(),
+        },
+        "hbm_gbps_algorithmic": round(alg_gbps, 1),
+        "hbm_frac_algorithmic": round(alg_gbps / (HBM_PEAK_GBPS * world), 4),
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: HIP events on the launch stream, live
+        reps = 3
+        acc = {}
+        for _ in range(reps):
+            for name, ms, cnt in plan.profile_batch_ptr(x.data_ptr(), y.data_ptr(), batch, int(Transform.Fft), stream):
+                a = acc.setdefault(name, [0.0, 0])
+                a[0] += ms
+                a[1] += cnt
+        kernels = {k: {"ms_per_step": v[0] / reps, "launches_per_step": v[1] // reps} for k, v in acc.items()}
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+        dom_ms = kernels[dom]["ms_per_step"]
+        achieved = batch * alg_bytes_per / (dom_ms * 1e-3) / 1e9  # all launches of that kernel in a step cover the batch
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as f:
+                    tj = json.load(f)
+                traffic = tj.get("per_launch_bytes", {}).get(dom)
+            except Exception:
+                traffic = None
+        out["roofline"] = {
+            "bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": batch * alg_bytes_per / max(kernels[dom]["launches_per_step"], 1),
+            "kernels": {k: {"ms_per_step": round(v["ms_per_step"], 4), "launches_per_step": v["launches_per_step"]}
+                        for k, v in kernels.items()},
+            "whole_path_frac": round(alg_gbps / world / HBM_PEAK_GBPS, 4),
+        }
+
+        # ---- parity sample + cpu_baseline: the oracle on this box's host cores (bounded sample)
+        if hx is not None:
+            import numpy as np
+            from oracle import oracle as O
+
+            O.build()
+            sample = hx.shape[0]
+            xs = torch.from_numpy(hx).to(dev)
+            ys = torch.empty_like(xs)
+            plan.transform_batch_ptr(xs.data_ptr(), ys.data_ptr(), sample, int(Transform.Fft), stream)
+            torch.cuda.synchronize(dev)
+            got = ys.cpu().numpy()
+            ob = O.OracleBatch(n, hx.dtype, nthreads=cores)
+            ref = np.empty_like(hx)
+            ob.run(hx[: min(sample, cores)], O.FFT, out=ref[: min(sample, cores)])  # warm-up (page faults)
+            t0 = time.perf_counter()
+            ob.run(hx, O.FFT, out=ref)
+            cpu_s = time.perf_counter() - t0
+            err = float(np.linalg.norm(got.astype(np.complex128) - ref) / np.linalg.norm(ref))
+            out["parity"] = {"sample_transforms": sample, "rel_l2_vs_oracle": err,
+                             "tolerance": 1e-6 if args.dtype == "f32" else 5e-14}
+            out["cpu_baseline"] = {
+                "value": round(sample * flops_per / cpu_s / 1e9, 2), "unit": "GFLOP/s", "cores": cores,
+                "kind": "port",
+                "sample": f"{sample} of the same transforms ({args.dtype} N=2^{args.log2n}, out-of-place), "
+                          f"one oracle plan per thread, {cpu_s:.2f} s wall",
+                "ms_per_transform_aggregate": round(cpu_s / sample * 1e3, 3),
+            }
+        print(json.dumps(out), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,7 +15,8 @@ SUFFIXES = ("float", "double")
 # every symbol include/fourier.h declares
 LEGACY_SYMBOLS = [f"fourier_{op}_{s}" for s in SUFFIXES for op in ("create", "destroy", "transform_in_place", "transform")]
 EXT_SYMBOLS = [f"fourier_hip_{op}_{s}" for s in SUFFIXES
-               for op in ("create", "size", "transform_batch", "last_status", "set_option", "describe", "model_bytes")] + [
+               for op in ("create", "size", "transform_batch", "last_status", "set_option", "describe", "model_bytes",
+                          "profile", "slot_names")] + [
     "fourier_hip_status_string"]
 ALL_SYMBOLS = LEGACY_SYMBOLS + EXT_SYMBOLS
 
@@ -35,6 +36,9 @@ def bind(cdll):
         f = getattr(cdll, f"fourier_hip_set_option_{s}"); f.restype = ci; f.argtypes = [vp, cp, ll]
         f = getattr(cdll, f"fourier_hip_describe_{s}"); f.restype = cp; f.argtypes = [vp]
         f = getattr(cdll, f"fourier_hip_model_bytes_{s}"); f.restype = ctypes.c_double; f.argtypes = [vp]
+        f = getattr(cdll, f"fourier_hip_profile_{s}"); f.restype = ci
+        f.argtypes = [vp, vp, vp, sz, ci, vp, ci, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ci)]
+        f = getattr(cdll, f"fourier_hip_slot_names_{s}"); f.restype = cp; f.argtypes = [vp]
     cdll.fourier_hip_status_string.restype = cp
     cdll.fourier_hip_status_string.argtypes = [ci]
     return cdll

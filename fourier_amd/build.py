@@ -10,7 +10,10 @@ OUT = os.path.join(HERE, "lib", "libfourier.so")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
-         "-Wl,-soname,libfourier.so.0", "-Wno-unused-result"]
+         "-Wl,-soname,libfourier.so.0", "-Wno-unused-result",
+         # SLP-packing f32 math into v_pk_* ops doubles the live register set of the butterflies (222 vs 104
+         # VGPRs on the 1024-point pass) and costs a workgroup per CU; keep scalar f32 VALU ops
+         "-fno-slp-vectorize"]
 
 
 def build(force=False, extra=()):

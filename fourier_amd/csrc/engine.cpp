@@ -79,6 +79,35 @@ struct DevBuf {
 };
 
 // ---------------------------------------------------------------------------------------------
+// optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg)
+struct Profiler {
+  hipStream_t stream;
+  struct Span { int slot; hipEvent_t a, b; };
+  std::vector<Span> spans;
+  explicit Profiler(hipStream_t s) : stream(s) {}
+  ~Profiler() { for (auto& sp : spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); } }
+  void begin(int slot) {
+    Span sp{slot, nullptr, nullptr};
+    HIP_CHECK(hipEventCreate(&sp.a));
+    HIP_CHECK(hipEventCreate(&sp.b));
+    HIP_CHECK(hipEventRecord(sp.a, stream));
+    spans.push_back(sp);
+  }
+  void end() { HIP_CHECK(hipEventRecord(spans.back().b, stream)); }
+  void collect(int nslots, float* ms_sum, int* launches) {
+    for (int i = 0; i < nslots; ++i) { ms_sum[i] = 0; launches[i] = 0; }
+    for (auto& sp : spans) {
+      HIP_CHECK(hipEventSynchronize(sp.b));
+      float ms = 0;
+      HIP_CHECK(hipEventElapsedTime(&ms, sp.a, sp.b));
+      if (sp.slot >= 0 && sp.slot < nslots) { ms_sum[sp.slot] += ms; launches[sp.slot] += 1; }
+    }
+  }
+};
+#define PROF_BEGIN(prof, slot) do { if (prof) (prof)->begin(slot); } while (0)
+#define PROF_END(prof) do { if (prof) (prof)->end(); } while (0)
+
+// ---------------------------------------------------------------------------------------------
 // kernel registry: one tile shape (CG) per pass length L
 typedef void (*PassKernel)(PassArgs);
 struct KernelInfo {
@@ -247,11 +276,13 @@ template <typename T> class Pow2Engine {
   // Transform `batch` contiguous transforms.  in == out is allowed; scratch must hold batch*n
   // elements when needs_scratch(in == out) (or when force_scratch is set).
   void run(const cpx<T>* in, cpx<T>* out, cpx<T>* scratch, size_t batch, bool inverse, double scale, const cpx<T>* mul,
-           bool force_scratch, hipStream_t stream) const {
+           bool force_scratch, hipStream_t stream, Profiler* prof = nullptr, int slot0 = 0) const {
     if (batch == 0) return;
     if (tiny_) {
       TinyArgs a{in, out, mul, (uint64_t)batch, (int)n_, inverse, inverse, scale};
+      PROF_BEGIN(prof, slot0);
       FOURIER_LAUNCH(&tiny_dft_kernel<T>, (batch + 255) / 256, 256, 0, stream, a);
+      PROF_END(prof);
       return;
     }
     const size_t np = passes_.size();
@@ -288,7 +319,9 @@ template <typename T> class Pow2Engine {
         grid = (uint64_t)batch * a.tiles;
       }
       if (grid > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");
+      PROF_BEGIN(prof, slot0 + (int)p);
       FOURIER_LAUNCH(ps.k.fn, grid, ps.k.NT, ps.k.smem, stream, a);
+      PROF_END(prof);
     }
   }
 
@@ -353,6 +386,17 @@ template <typename T> class Plan {
   int last_status() const { return status_; }
   void set_status(int s) const { status_ = s; }
 
+  // kernel "slots" in launch order, as reported by profile(): names for bench.py / rocprof matching
+  std::string slot_names() const {
+    std::string d;
+    auto passes = [&](const char* tag) {
+      for (size_t p = 0; p < eng_->num_passes(); ++p) d += std::string(d.empty() ? "" : ",") + tag + std::to_string(p);
+    };
+    if (!blu_) { passes("pass"); return d; }
+    d = "blu_pre"; passes("fwd_pass"); passes("inv_pass"); d += ",blu_post";
+    return d;
+  }
+
   double model_bytes() const {
     if (!blu_) return 2.0 * n_ * ELEM * eng_->num_passes();
     // pre (n read + table + m write) + 2 inner FFTs + w table + post (m.. n read, table, n write)
@@ -366,7 +410,7 @@ template <typename T> class Plan {
   }
 
   // Batched transform on device memory (the operator behind Fft::transform / transform_in_place).
-  void exec(const void* d_in, void* d_out, size_t batch, int code, hipStream_t stream) const {
+  void exec(const void* d_in, void* d_out, size_t batch, int code, hipStream_t stream, Profiler* prof = nullptr) const {
     if (!d_in || !d_out) throw EngineError(::fourier::c::FOURIER_HIP_INVALID_ARGUMENT, "null buffer");
     if (code < 0 || code > 4) throw EngineError(::fourier::c::FOURIER_HIP_INVALID_ARGUMENT, "unknown transform code");
     if (batch == 0) return;
@@ -391,7 +435,7 @@ template <typename T> class Plan {
       if (need) scratch_.ensure(chunk * n_ * ELEM);
       for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const size_t nb = std::min(chunk, batch - b0);
-        eng_->run(in + b0 * n_, out + b0 * n_, (cpx<T>*)scratch_.p, nb, inverse, scale, nullptr, force_scratch_, stream);
+        eng_->run(in + b0 * n_, out + b0 * n_, (cpx<T>*)scratch_.p, nb, inverse, scale, nullptr, force_scratch_, stream, prof, 0);
       }
       return;
     }
@@ -402,11 +446,16 @@ template <typename T> class Plan {
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
       const size_t nb = std::min(chunk, batch - b0);
       BluArgs pre{in + b0 * n_, work, xtab_.p, (uint64_t)n_, (uint64_t)m_, (uint64_t)nb, inverse, 1.0};
+      const int np = (int)eng_->num_passes();
+      PROF_BEGIN(prof, 0);
       FOURIER_LAUNCH(&blu_pre_kernel<T>, elementwise_grid(nb * m_), 256, 0, stream, pre);
-      eng_->run(work, work, (cpx<T>*)scratch_.p, nb, false, 1.0, (const cpx<T>*)wtab_.p, false, stream);
-      eng_->run(work, work, (cpx<T>*)scratch_.p, nb, true, 1.0, nullptr, false, stream);
+      PROF_END(prof);
+      eng_->run(work, work, (cpx<T>*)scratch_.p, nb, false, 1.0, (const cpx<T>*)wtab_.p, false, stream, prof, 1);
+      eng_->run(work, work, (cpx<T>*)scratch_.p, nb, true, 1.0, nullptr, false, stream, prof, 1 + np);
       BluArgs post{work, out + b0 * n_, xtab_.p, (uint64_t)n_, (uint64_t)m_, (uint64_t)nb, inverse, scale};
+      PROF_BEGIN(prof, 1 + 2 * np);
       FOURIER_LAUNCH(&blu_post_kernel<T>, elementwise_grid(nb * n_), 256, 0, stream, post);
+      PROF_END(prof);
     }
   }
 
@@ -540,6 +589,22 @@ namespace fc = ::fourier::c;
                                                       void* d_out, size_t batch, int code, void* stream) {       \
     const Plan<T>* p = (const Plan<T>*)h;                                                                        \
     return guarded<T>(p, [&] { p->exec(d_in, d_out, batch, code, (hipStream_t)stream); });                       \
+  }                                                                                                              \
+  extern "C" int fourier_hip_profile_##SUFFIX(const fc::fourier_fft_##SUFFIX* h, const void* d_in, void* d_out,  \
+                                              size_t batch, int code, void* stream, int nslots, float* ms_sum,   \
+                                              int* launches) {                                                   \
+    const Plan<T>* p = (const Plan<T>*)h;                                                                        \
+    if (!ms_sum || !launches || nslots <= 0) return fc::FOURIER_HIP_INVALID_ARGUMENT;                            \
+    return guarded<T>(p, [&] {                                                                                   \
+      Profiler prof((hipStream_t)stream);                                                                        \
+      p->exec(d_in, d_out, batch, code, (hipStream_t)stream, &prof);                                             \
+      prof.collect(nslots, ms_sum, launches);                                                                    \
+    });                                                                                                          \
+  }                                                                                                              \
+  extern "C" const char* fourier_hip_slot_names_##SUFFIX(const fc::fourier_fft_##SUFFIX* h) {                    \
+    static thread_local std::string s;                                                                           \
+    s = h ? ((const Plan<T>*)h)->slot_names() : "";                                                              \
+    return s.c_str();                                                                                            \
   }                                                                                                              \
   extern "C" int fourier_hip_last_status_##SUFFIX(const fc::fourier_fft_##SUFFIX* h) {                           \
     return h ? ((const Plan<T>*)h)->last_status() : fc::FOURIER_HIP_INVALID_ARGUMENT;                            \

@@ -28,6 +28,12 @@
 #define LDS_NOTE(p, bytes, w, site)
 #endif
 
+// second __launch_bounds__ argument = min waves per SIMD: ask for two workgroups per CU
+// (2*NT/64 waves over 4 SIMDs), which caps the kernel at 128 VGPRs for NT = 512.
+#ifndef FOURIER_MIN_WAVES
+#define FOURIER_MIN_WAVES(NT) ((NT) >= 256 ? (NT) / 128 : 1)
+#endif
+
 namespace fourier_hip {
 
 template <typename T> struct cpx { T re, im; };
@@ -151,8 +157,13 @@ template <typename T, int L, int CG> struct TileCfg {
   static __host__ __device__ constexpr size_t smem_bytes(int mode) {
     return mode == MODE_FIRST ? SMEM_FIRST : (mode == MODE_MID ? SMEM_MID : SMEM_PLAIN);
   }
-  static __device__ __forceinline__ int unit_index(int pos, int cg) {
-    return pos * CG + cg + ((CG >= 32) ? pos : ((pos * CG) >> 5));
+  // LAYOUT 0 ("skew"): conflict-free for lanes walking pos at fixed cg (row-contiguous mapping).
+  // LAYOUT 1 ("xor"):  for the stage-1 exchange of the split-plane tiles, where a 16-lane ds_write_b64
+  //   group holds 16/CG threads whose positions differ by 16: flip the unit index by the 16-block
+  //   parity so those threads land in different bank quarters; reads (cg-fastest) stay contiguous.
+  template <int LAYOUT> static __device__ __forceinline__ int unit_index(int pos, int cg) {
+    if constexpr (LAYOUT == 1 && CG <= 8) return (pos * CG + cg) ^ (((pos >> 4) & (16 / CG - 1)) * CG);
+    else return pos * CG + cg + ((CG >= 32) ? pos : ((pos * CG) >> 5));
   }
 };
 
@@ -160,7 +171,7 @@ template <typename T, int L, int CG> struct TileCfg {
 // afterwards register r holds position th_r + Q*r of column group cg_r.
 template <typename T, int L, int CG> using RegTile = cpx<T>[TileCfg<T, L, CG>::VEC][16];
 
-template <typename T, int L, int CG, typename WPos>
+template <typename T, int L, int CG, int LAYOUT, typename WPos>
 __device__ __forceinline__ void lds_exchange(RegTile<T, L, CG>& x, unsigned char* smem, int cg_w, WPos wpos, int th_r,
                                              int cg_r, unsigned site) {
   using C = TileCfg<T, L, CG>;
@@ -175,14 +186,14 @@ __device__ __forceinline__ void lds_exchange(RegTile<T, L, CG>& x, unsigned char
         Unit8<T> u;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) u.a[v] = plane ? x[v][r].im : x[v][r].re;
-        Unit8<T>* p = lds + C::unit_index(wpos(r), cg_w);
+        Unit8<T>* p = lds + C::template unit_index<LAYOUT>(wpos(r), cg_w);
         LDS_NOTE(p, 8, true, site + plane);
         *p = u;
       }
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const Unit8<T>* p = lds + C::unit_index(th_r + Q * r, cg_r);
+        const Unit8<T>* p = lds + C::template unit_index<LAYOUT>(th_r + Q * r, cg_r);
         LDS_NOTE(p, 8, false, site + 2 + plane);
         const Unit8<T> u = *p;
 #pragma unroll
@@ -198,14 +209,14 @@ __device__ __forceinline__ void lds_exchange(RegTile<T, L, CG>& x, unsigned char
       Unit16<T> u;
 #pragma unroll
       for (int v = 0; v < VEC; ++v) { u.a[2 * v] = x[v][r].re; u.a[2 * v + 1] = x[v][r].im; }
-      Unit16<T>* p = lds + C::unit_index(wpos(r), cg_w);
+      Unit16<T>* p = lds + C::template unit_index<LAYOUT>(wpos(r), cg_w);
       LDS_NOTE(p, 16, true, site);
       *p = u;
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const Unit16<T>* p = lds + C::unit_index(th_r + Q * r, cg_r);
+      const Unit16<T>* p = lds + C::template unit_index<LAYOUT>(th_r + Q * r, cg_r);
       LDS_NOTE(p, 16, false, site + 2);
       const Unit16<T> u = *p;
 #pragma unroll
@@ -228,7 +239,7 @@ __device__ __forceinline__ cpx<T> two_level_twiddle(const PassArgs& a, uint64_t 
 //   MODE_LAST : size == L. column-tile load/store, no twiddle; mul / swap_out / scale on store.
 //   MODE_ROWS : whole transforms of length L, contiguous rows; mul / swap_out / scale on store.
 template <typename T, int L, int CG, int MODE>
-__global__ void __launch_bounds__((L / 16) * CG) fft_pass_kernel(PassArgs a) {
+__global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG)) fft_pass_kernel(PassArgs a) {
   using C = TileCfg<T, L, CG>;
   constexpr int VEC = C::VEC, Q = C::Q, R2 = C::R2, R3 = C::R3, COLS = C::COLS;
   constexpr bool IN_ROWS = (MODE == MODE_ROWS);
@@ -313,7 +324,9 @@ __global__ void __launch_bounds__((L / 16) * CG) fft_pass_kernel(PassArgs a) {
       const bool remap = (MODE == MODE_FIRST) && (R3 == 1);
       const int th_r = remap ? thB : th, cg_r = remap ? cgB : cg;
       const int th_w = th;
-      lds_exchange<T, L, CG>(x, smem, cg, [=](int r) { return 16 * th_w + r; }, th_r, cg_r, 0);
+      // both sides cg-fastest and split planes -> xor layout; anything row-contiguous -> skew layout
+      constexpr int LAY1 = (C::SPLIT && !IN_ROWS && !(MODE == MODE_FIRST && R3 == 1)) ? 1 : 0;
+      lds_exchange<T, L, CG, LAY1>(x, smem, cg, [=](int r) { return 16 * th_w + r; }, th_r, cg_r, 0);
       th = th_r; cg = cg_r;
     }
 
@@ -347,7 +360,7 @@ __global__ void __launch_bounds__((L / 16) * CG) fft_pass_kernel(PassArgs a) {
         const int th_r = remap ? thB : th, cg_r = remap ? cgB : cg;
         const int jw = th & 15, iw = th >> 4;
         __syncthreads();  // all reads of exchange 1 are done before the buffer is rewritten
-        lds_exchange<T, L, CG>(x, smem, cg, [=](int r) { return jw + 16 * (16 * iw + r); }, th_r, cg_r, 4);
+        lds_exchange<T, L, CG, 0>(x, smem, cg, [=](int r) { return jw + 16 * (16 * iw + r); }, th_r, cg_r, 4);
         th = th_r; cg = cg_r;
       }
       // ---- stage 3: radix R3 on register sets {u + NB3*k'}

@@ -90,6 +90,20 @@ class Fft:
         if st != 0:
             raise FourierError(self._L.fourier_hip_status_string(st).decode())
 
+    def profile_batch_ptr(self, d_in, d_out, batch, transform, stream=0, nslots=16):
+        """One batched transform with a HIP event pair around every kernel launch.
+        Returns [(slot_name, total_ms, launches), ...] in launch order."""
+        import ctypes
+
+        ms = (ctypes.c_float * nslots)()
+        cnt = (ctypes.c_int * nslots)()
+        st = getattr(self._L, f"fourier_hip_profile_{self._suffix}")(
+            self._h, d_in, d_out, int(batch), int(transform), stream, nslots, ms, cnt)
+        if st != 0:
+            raise FourierError(self._L.fourier_hip_status_string(st).decode())
+        names = getattr(self._L, f"fourier_hip_slot_names_{self._suffix}")(self._h).decode().split(",")
+        return [(nm, float(ms[i]), int(cnt[i])) for i, nm in enumerate(names) if i < nslots]
+
     def set_option(self, key, value):
         st = getattr(self._L, f"fourier_hip_set_option_{self._suffix}")(self._h, key.encode(), int(value))
         if st != 0:

@@ -128,6 +128,19 @@ const char *fourier_hip_describe_double(const FOURIER_STRUCT fourier_fft_double 
 double fourier_hip_model_bytes_float(const FOURIER_STRUCT fourier_fft_float *);
 double fourier_hip_model_bytes_double(const FOURIER_STRUCT fourier_fft_double *);
 
+/* Measurement hook: runs ONE batched transform exactly like fourier_hip_transform_batch_*, with a
+ * HIP event pair around every kernel launch on `stream`, waits for it, and returns per kernel slot
+ * (launch order; names from fourier_hip_slot_names_*) the summed duration in ms and launch count. */
+int fourier_hip_profile_float(const FOURIER_STRUCT fourier_fft_float *, const void *d_in, void *d_out,
+                              FOURIER_SIZE_TYPE batch, int transform, void *stream, int nslots,
+                              float *ms_sum, int *launches);
+int fourier_hip_profile_double(const FOURIER_STRUCT fourier_fft_double *, const void *d_in, void *d_out,
+                               FOURIER_SIZE_TYPE batch, int transform, void *stream, int nslots,
+                               float *ms_sum, int *launches);
+/* Comma-separated kernel slot names ("pass0,pass1" / "blu_pre,fwd_pass0,...,blu_post"). */
+const char *fourier_hip_slot_names_float(const FOURIER_STRUCT fourier_fft_float *);
+const char *fourier_hip_slot_names_double(const FOURIER_STRUCT fourier_fft_double *);
+
 #ifdef __cplusplus
 } /* extern "C" */
 } /* namespace c */

@@ -1,0 +1,70 @@
+"""The C-ABI library builds for gfx950 and exports every symbol include/fourier.h declares
+(no compute calls: this runs without a GPU)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    from fourier_amd import build
+
+    return build.build()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "fourier.h")).read()
+    text = text[: text.index("Header-only C++ RAII wrapper")]
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fourier_(?:hip_)?[a-z_]+_(?:float|double)|fourier_hip_status_string)\s*\(", text)))
+
+
+def test_header_declares_the_reference_abi():
+    syms = declared_symbols()
+    # the 8 entry points of the reference header, fourier-ffi/include/fourier.h:41-58
+    for s in ("float", "double"):
+        for op in ("create", "destroy", "transform_in_place", "transform"):
+            assert f"fourier_{op}_{s}" in syms
+
+
+def test_library_exports_every_declared_symbol(libpath):
+    out = subprocess.run(["nm", "-D", "--defined-only", libpath], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    missing = [s for s in declared_symbols() if s not in exported]
+    assert not missing, missing
+
+
+def test_python_binding_lists_the_same_symbols():
+    from fourier_amd import _lib
+
+    assert sorted(_lib.ALL_SYMBOLS) == declared_symbols()
+
+
+def test_library_is_gfx950_only(libpath):
+    # the fat binary embeds one code object per offload target: only gfx950 may be present
+    blob = open(libpath, "rb").read()
+    targets = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", blob))
+    assert targets == {b"gfx950"}, targets
+
+
+def test_soname_matches_reference_packaging(libpath):
+    # fourier-ffi/CMakeLists.txt:55 / config.toml:13-14: SONAME libfourier.so.0
+    out = subprocess.run(["objdump", "-p", libpath], capture_output=True, text=True, check=True).stdout
+    assert "libfourier.so.0" in out
+
+
+def test_transform_enum_matches_reference():
+    from fourier_amd import Transform
+
+    # fourier-ffi/src/lib.rs:3-12
+    assert [int(t) for t in (Transform.Fft, Transform.Ifft, Transform.UnscaledIfft, Transform.SqrtScaledFft,
+                             Transform.SqrtScaledIfft)] == [0, 1, 2, 3, 4]
+    # fft.rs:20-36
+    assert Transform.Fft.is_forward() and Transform.SqrtScaledFft.is_forward()
+    assert not Transform.Ifft.is_forward() and not Transform.UnscaledIfft.is_forward()
+    assert Transform.Fft.inverse() is Transform.Ifft and Transform.UnscaledIfft.inverse() is None
+    assert Transform.SqrtScaledIfft.inverse() is Transform.SqrtScaledFft

@@ -1,0 +1,231 @@
+"""Host logic + kernel logic of the engine, exercised WITHOUT a GPU.
+
+The engine sources (fourier_amd/csrc) are compiled against tests/emu/hipemu.h, a test-only fiber
+emulation of the HIP subset they use, and driven through the same C ABI / Python operator layer as
+the product.  This validates plan construction, pass scheduling, kernel index arithmetic, LDS layouts,
+the legacy host ABI and error behaviour before any GPU minute is spent; the `-m gpu` tests repeat the
+parity checks on the real library.  The emulation is never used by the product path.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, hash_normal, load_ref10, naive_dft, near, rel_l2, max_rel
+
+F32_EPS, F64_EPS = 1e-4, 1e-11  # fourier/tests/integrity.rs:92,120
+
+
+@pytest.fixture(scope="module")
+def fa():
+    from emu import build_emu
+    from fourier_amd import _lib
+
+    prev = _lib._lib
+    _lib.use_library(build_emu.load())
+    import fourier_amd
+
+    yield fourier_amd
+    _lib.use_library(prev)
+
+
+def make(fa, n, dtype):
+    return fa.create_fft_f32(n) if np.dtype(dtype) == np.complex64 else fa.create_fft_f64(n)
+
+
+def run_batch(plan, x, code, inplace=False):
+    x = np.ascontiguousarray(x)
+    y = x.copy() if inplace else np.empty_like(x)
+    src = y if inplace else x
+    plan.transform_batch_ptr(src.ctypes.data, y.ctypes.data, x.shape[0], int(code))
+    return y
+
+
+@pytest.mark.parametrize("dtype,eps", [(np.complex64, F32_EPS), (np.complex128, F64_EPS)])
+@pytest.mark.parametrize("forward", [True, False])
+def test_sweep_1_255_like_reference(fa, oracle, dtype, eps, forward):
+    """integrity.rs:145-192 procedure through the engine: every size 1..255 (tiny, row kernels,
+    Bluestein), vs the naive DFT at the reference tolerance, vs numpy-f64 and vs the oracle."""
+    g = np.load(os.path.join(GOLDEN, "sweep_1_255.npz"))
+    x = (g["x_fwd"] if forward else g["x_inv"]).astype(dtype)
+    y64 = g["y_fwd"] if forward else g["y_inv"]
+    code = fa.Transform.Fft if forward else fa.Transform.Ifft
+    off = 0
+    for n in range(1, 256):
+        plan = make(fa, n, dtype)
+        got = np.empty(n, dtype)
+        plan.transform(np.ascontiguousarray(x[:n]), got, code)  # legacy host ABI, out of place
+        ok, worst = near(naive_dft(x[:n], inverse=not forward), got, eps)
+        assert ok, (n, worst)
+        want = y64[off:off + n]
+        off += n
+        scale = max(np.abs(want).max(), 1.0)
+        tol = (3e-6 if dtype == np.complex64 else 1e-12) * scale
+        assert np.abs(got - want).max() <= tol, (n, float(np.abs(got - want).max()))
+        orc = oracle.OracleFft(n, dtype).transform(x[:n], int(code))
+        assert np.abs(got - orc).max() <= 2 * tol, n
+
+
+@pytest.mark.parametrize("dtype,eps", [(np.complex64, F32_EPS), (np.complex128, F64_EPS)])
+def test_reference_golden_vector_through_engine(fa, dtype, eps):
+    x, y = load_ref10()  # integrity.rs:48-72; N=10 -> Bluestein, M=32
+    plan = make(fa, 10, dtype)
+    got = np.empty(10, dtype)
+    plan.fft(x.astype(dtype), got)
+    ok, worst = near(got, y, eps)
+    assert ok, worst
+    plan.ifft(y.astype(dtype), got)
+    ok, worst = near(got, x, eps)
+    assert ok, worst
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_ffi_impulse_roundtrip(fa, dtype):
+    # fourier-ffi/test.c:7-39 through the legacy C ABI
+    plan = make(fa, 4, dtype)
+    x = np.array([1, 0, 0, 0], dtype=dtype)
+    out = np.empty_like(x)
+    plan.transform(x, out, fa.Transform.Fft)
+    assert np.allclose(out, 1)
+    plan.transform_in_place(out, fa.Transform.Ifft)
+    assert np.abs(out - x).max() <= 1e-10
+
+
+@pytest.mark.parametrize("n", [16, 64, 512, 2048, 4096, 8192, 1 << 16])
+@pytest.mark.parametrize("dtype,tl2,tmax", [(np.complex64, 1e-6, 2e-6), (np.complex128, 5e-14, 1e-13)])
+def test_pow2_sizes_all_codes_vs_oracle(fa, oracle, n, dtype, tl2, tmax):
+    plan = make(fa, n, dtype)
+    x = np.stack([hash_normal(900 + b, n) for b in range(3)]).astype(dtype)
+    for code in range(5):
+        ref = oracle.transform_batch(x, code)
+        for inplace in (False, True):
+            got = run_batch(plan, x, code, inplace)
+            assert rel_l2(got, ref) <= tl2 and max_rel(got, ref) <= tmax, (n, code, inplace, rel_l2(got, ref))
+
+
+def test_n4096_against_committed_spectrum(fa):
+    g = np.load(os.path.join(GOLDEN, "n4096.npz"))
+    x = hash_normal(int(g["seed"]), 4096)
+    for dtype, tl2 in ((np.complex64, 1e-6), (np.complex128, 5e-14)):
+        got = run_batch(make(fa, 4096, dtype), x.astype(dtype)[None, :], 0)[0]
+        assert rel_l2(got, g["y"]) <= tl2
+
+
+@pytest.mark.parametrize("n", [7, 96, 100, 1000, 1025, 2500])
+def test_bluestein_and_mixed_radix_sizes(fa, oracle, n):
+    x = np.stack([hash_normal(40 + b, n) for b in range(2)])
+    for dtype, tl2 in ((np.complex64, 2e-6), (np.complex128, 2e-12)):
+        plan = make(fa, n, dtype)
+        for code in range(5):
+            ref = oracle.transform_batch(x.astype(dtype), code)
+            assert rel_l2(run_batch(plan, x.astype(dtype), code), ref) <= tl2, (n, code)
+            assert rel_l2(run_batch(plan, x.astype(dtype), code, inplace=True), ref) <= tl2, (n, code)
+
+
+def test_three_pass_plan(fa):
+    # 2^23 = 256 x 256 x 128: exercises the middle (uniform-twiddle) pass
+    n = 1 << 23
+    plan = make(fa, n, np.complex64)
+    assert "256x256x128" in plan.describe()
+    rng = np.random.default_rng(7)
+    x = (rng.standard_normal(n, np.float32) + 1j * rng.standard_normal(n, np.float32)).astype(np.complex64)[None, :]
+    ref = np.fft.fft(x[0].astype(np.complex128))
+    assert rel_l2(run_batch(plan, x, 0)[0], ref) <= 1e-6
+    assert rel_l2(run_batch(plan, x, 0, inplace=True)[0], ref) <= 1e-6
+
+
+def test_chunking_and_scratch_options_do_not_change_results(fa):
+    n, batch = 4096, 7
+    x = np.stack([hash_normal(300 + b, n) for b in range(batch)]).astype(np.complex64)
+    base = run_batch(make(fa, n, np.complex64), x, 0)
+    for chunk_bytes, scratch in ((n * 8, 0), (3 * n * 8, 1), (0, 1)):
+        plan = make(fa, n, np.complex64)
+        plan.set_option("chunk_bytes", chunk_bytes)
+        plan.set_option("scratch", scratch)
+        assert np.array_equal(run_batch(plan, x, 0), base)
+        assert np.array_equal(run_batch(plan, x, 0, inplace=True), base)
+    with pytest.raises(fa.FourierError):
+        make(fa, n, np.complex64).set_option("no_such_option", 1)
+
+
+def test_linearity_and_roundtrip_properties(fa):
+    n = 1 << 14
+    plan = make(fa, n, np.complex64)
+    a = hash_normal(1, n).astype(np.complex64)[None, :]
+    b = hash_normal(2, n).astype(np.complex64)[None, :]
+    fa_, fb, fab = run_batch(plan, a, 0), run_batch(plan, b, 0), run_batch(plan, a + 2 * b, 0)
+    assert rel_l2(fab, fa_ + 2 * fb) <= 1e-6
+    assert rel_l2(run_batch(plan, fa_, 1), a) <= 1e-6  # Ifft(Fft(x)) == x
+    assert rel_l2(run_batch(plan, run_batch(plan, a, 3), 4), a) <= 1e-6  # unitary pair
+    # Parseval
+    assert abs(np.linalg.norm(fa_) ** 2 / n - np.linalg.norm(a) ** 2) <= 1e-5 * np.linalg.norm(a) ** 2
+
+
+def test_error_behaviour_matches_reference_ffi(fa):
+    from fourier_amd import _lib
+
+    L = _lib.lib()
+    assert not L.fourier_create_float(0)  # reference hangs; we return NULL
+    assert not L.fourier_create_double(0)
+    L.fourier_destroy_float(None)  # no-op
+    x = hash_normal(3, 8).astype(np.complex64)
+    buf = x.copy()
+    L.fourier_transform_in_place_float(None, buf.ctypes.data, 0)  # NULL handle: no-op
+    assert np.array_equal(buf, x)
+    h = L.fourier_create_float(8)
+    L.fourier_transform_in_place_float(h, buf.ctypes.data, 9)  # unknown code: silent no-op (lib.rs:10)
+    assert np.array_equal(buf, x)
+    assert L.fourier_hip_transform_batch_float(h, buf.ctypes.data, buf.ctypes.data, 1, 9, None) == 1
+    assert L.fourier_hip_last_status_float(h) == 1
+    assert L.fourier_hip_status_string(1) == b"invalid argument"
+    assert L.fourier_hip_size_float(h) == 8 and L.fourier_hip_size_float(None) == 0
+    L.fourier_destroy_float(h)
+    with pytest.raises(fa.FourierError):
+        fa.create_fft_f32(0)
+    with pytest.raises(fa.FourierError):
+        fa.create_fft_f32(1 << 31)  # beyond the engine's range
+    plan = fa.create_fft_f32(8)
+    with pytest.raises(ValueError):  # fft.rs:57-58 length asserts
+        plan.transform(np.zeros(8, np.complex64), np.zeros(9, np.complex64), fa.Transform.Fft)
+    with pytest.raises(TypeError):
+        plan.fft_in_place(np.zeros(8, np.complex128))
+
+
+def test_profile_hook_reports_every_kernel(fa):
+    plan = make(fa, 4096, np.complex64)
+    x = hash_normal(1, 4096).astype(np.complex64)[None, :]
+    y = np.empty_like(x)
+    prof = plan.profile_batch_ptr(x.ctypes.data, y.ctypes.data, 1, 0)
+    assert [p[0] for p in prof] == ["pass0", "pass1"] and all(p[2] == 1 for p in prof)
+    assert rel_l2(y[0], np.fft.fft(x[0].astype(np.complex128))) <= 1e-6
+    planb = make(fa, 1000, np.complex64)
+    xb = hash_normal(1, 1000).astype(np.complex64)[None, :]
+    names = [p[0] for p in planb.profile_batch_ptr(xb.ctypes.data, np.empty_like(xb).ctypes.data, 1, 0)]
+    assert names == ["blu_pre", "fwd_pass0", "inv_pass0", "blu_post"]
+
+
+def test_lds_layouts_are_bank_conflict_light(fa):
+    """Bank-conflict model of MI355X_MICROARCH.md (LDS table) applied to the headline tile
+    (1024-point f32 pass, split planes): total LDS-array cycles within 1.1x of conflict-free."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, ctypes; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from emu import build_emu\n"
+        "from fourier_amd import _lib\n"
+        "c = build_emu.load(); _lib.use_library(c)\n"
+        "import fourier_amd as fa\n"
+        "n = 1 << 20\n"
+        "p = fa.create_fft_f32(n); x = np.ones((1, n), np.complex64); y = np.empty_like(x)\n"
+        "p.transform_batch_ptr(x.ctypes.data, y.ctypes.data, 1, 0)\n"
+        "a, b, d = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()\n"
+        "c.fourier_emu_lds_stats(ctypes.byref(a), ctypes.byref(b), ctypes.byref(d), 1)\n"
+        "print(b.value / d.value)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HIPEMU_LDS_TRACE="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert float(out.stdout.strip().splitlines()[-1]) <= 1.1
