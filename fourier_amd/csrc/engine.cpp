@@ -125,6 +125,17 @@ template <typename T, int L, int CG, int MODE> static KernelInfo make_info() {
   return k;
 }
 
+// tile widths (column groups of 16 bytes) per pass length; overridable for A/B builds
+#ifndef FOURIER_CG_512
+#define FOURIER_CG_512 8
+#endif
+#ifndef FOURIER_CG_1024
+#define FOURIER_CG_1024 8
+#endif
+#ifndef FOURIER_CG_2048
+#define FOURIER_CG_2048 4
+#endif
+
 template <typename T> static KernelInfo get_kernel(int L, int mode) {
 #define FK(LL, CGG)                                                         \
   case LL:                                                                  \
@@ -142,9 +153,9 @@ template <typename T> static KernelInfo get_kernel(int L, int mode) {
     FK(64, 16)
     FK(128, 16)
     FK(256, 16)
-    FK(512, 8)
-    FK(1024, 8)
-    FK(2048, 4)
+    FK(512, FOURIER_CG_512)
+    FK(1024, FOURIER_CG_1024)
+    FK(2048, FOURIER_CG_2048)
     default: break;
   }
 #undef FK

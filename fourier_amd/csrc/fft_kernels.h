@@ -31,7 +31,7 @@
 // second __launch_bounds__ argument = min waves per SIMD: ask for two workgroups per CU
 // (2*NT/64 waves over 4 SIMDs), which caps the kernel at 128 VGPRs for NT = 512.
 #ifndef FOURIER_MIN_WAVES
-#define FOURIER_MIN_WAVES(NT) ((NT) >= 256 ? (NT) / 128 : 1)
+#define FOURIER_MIN_WAVES(NT) ((NT) >= 1024 ? 4 : ((NT) >= 256 ? (NT) / 128 : 1))
 #endif
 
 namespace fourier_hip {
@@ -41,6 +41,42 @@ template <typename T> struct alignas(16) Unit16 { T a[16 / sizeof(T)]; };  // VE
 template <typename T> struct alignas(8) Unit8 { T a[8 / sizeof(T)]; };     // one plane of VEC columns
 
 enum { MODE_FIRST = 0, MODE_MID = 1, MODE_LAST = 2, MODE_ROWS = 3 };
+
+// Build-time knobs (tools/build_variants.py A/B-tests them on the GPU):
+//   FOURIER_NT_LOAD  = 1: first-pass input loads are non-temporal (streamed once, keep them out of L2/MALL)
+//   FOURIER_NT_STORE = 1: final-pass output stores are non-temporal
+#ifndef FOURIER_NT_LOAD
+#define FOURIER_NT_LOAD 0
+#endif
+#ifndef FOURIER_NT_STORE
+#define FOURIER_NT_STORE 0
+#endif
+
+// 16-byte global accesses (global_load_dwordx4 / global_store_dwordx4)
+template <typename T, bool NT> __device__ __forceinline__ Unit16<T> load_unit(const void* p) {
+#ifndef FOURIER_EMU
+  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+  v4u v;
+  if constexpr (NT) v = __builtin_nontemporal_load((const v4u*)p);
+  else v = *(const v4u*)p;
+  Unit16<T> u;
+  __builtin_memcpy(&u, &v, 16);
+  return u;
+#else
+  return *(const Unit16<T>*)p;
+#endif
+}
+template <typename T, bool NT> __device__ __forceinline__ void store_unit(void* p, const Unit16<T>& u) {
+#ifndef FOURIER_EMU
+  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+  v4u v;
+  __builtin_memcpy(&v, &u, 16);
+  if constexpr (NT) __builtin_nontemporal_store(v, (v4u*)p);
+  else *(v4u*)p = v;
+#else
+  *(Unit16<T>*)p = u;
+#endif
+}
 
 // Kernel argument block (passed by value).
 struct PassArgs {
@@ -294,7 +330,7 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
     const cpx<T>* p = in + b * a.n + (uint64_t)th * a.cn + c0 + (uint64_t)(cg * VEC);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const Unit16<T> u = *(const Unit16<T>*)(p + (uint64_t)(Q * r) * a.cn);
+      const Unit16<T> u = load_unit<T, (MODE == MODE_FIRST) && FOURIER_NT_LOAD>(p + (uint64_t)(Q * r) * a.cn);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
     }
@@ -431,7 +467,7 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
         }
         u.a[2 * v] = y.re; u.a[2 * v + 1] = y.im;
       }
-      *(Unit16<T>*)(p + a.s * (uint64_t)(Q * r)) = u;
+      store_unit<T, FINAL && FOURIER_NT_STORE>(p + a.s * (uint64_t)(Q * r), u);
     }
   }
 }

@@ -1,0 +1,277 @@
+"""Parity tests proper (-m gpu): the HIP engine, called through the C ABI of include/fourier.h,
+against the oracle (oracle/fourier_oracle.cpp), the committed golden fixtures, and -- at BASELINE.json's
+full sizes -- size-independent properties (round trip, Parseval, linearity) plus sampled transforms.
+
+Tolerances (SURVEY.md section 8c / BASELINE.md section 3):
+  small-N sweep: the reference's own 1e-4 | 8 ulp (f32), 1e-11 | 8 ulp (f64)  (integrity.rs:89-143)
+  f32 pow2 (N=4096, 2^20, 2^22): rel-L2 <= 1e-6, max <= 2e-6*max|X| ; f64 N=2^20: 5e-14 / 1e-13
+  Bluestein f32 N=999983: rel-L2 <= 2e-6, max <= 4e-6*max|X|
+"""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, hash_normal, hash_uniform, load_ref10, naive_dft, near, rel_l2, max_rel, sample_bins
+
+pytestmark = pytest.mark.gpu
+
+F32_EPS, F64_EPS = 1e-4, 1e-11
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("these tests need a GPU: the product path has no CPU fallback")
+    return torch
+
+
+@pytest.fixture(scope="module")
+def fa(torch):
+    import fourier_amd
+    from fourier_amd import _lib
+
+    _lib.lib()  # raises if the HIP library is missing: never fall back silently
+    maps = open("/proc/self/maps").read()
+    assert "fourier_amd/lib/libfourier.so" in maps, "the in-tree HIP library must be the one that is loaded"
+    return fourier_amd
+
+
+def make(fa, n, dtype):
+    return fa.create_fft_f32(n) if np.dtype(dtype) == np.complex64 else fa.create_fft_f64(n)
+
+
+def gpu_batch(torch, fa, plan, x, code, inplace=False):
+    """x: numpy (batch, n) -> device-resident batched transform -> numpy."""
+    d = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    o = d if inplace else torch.empty_like(d)
+    plan.transform(d, o, fa.Transform(code))
+    torch.cuda.synchronize()
+    return o.cpu().numpy()
+
+
+@pytest.mark.parametrize("dtype,eps", [(np.complex64, F32_EPS), (np.complex128, F64_EPS)])
+@pytest.mark.parametrize("forward", [True, False])
+def test_sweep_1_255_like_reference(fa, oracle, dtype, eps, forward):
+    """integrity.rs:145-192 through the legacy host ABI (H2D, transform, D2H inside the library)."""
+    g = np.load(os.path.join(GOLDEN, "sweep_1_255.npz"))
+    x = (g["x_fwd"] if forward else g["x_inv"]).astype(dtype)
+    y64 = g["y_fwd"] if forward else g["y_inv"]
+    code = fa.Transform.Fft if forward else fa.Transform.Ifft
+    off = 0
+    for n in range(1, 256):
+        plan = make(fa, n, dtype)
+        got = np.empty(n, dtype)
+        plan.transform(np.ascontiguousarray(x[:n]), got, code)
+        ok, worst = near(naive_dft(x[:n], inverse=not forward), got, eps)
+        assert ok, (n, worst)
+        want = y64[off:off + n]
+        off += n
+        scale = max(np.abs(want).max(), 1.0)
+        tol = (3e-6 if dtype == np.complex64 else 1e-12) * scale
+        assert np.abs(got - want).max() <= tol, (n, float(np.abs(got - want).max()))
+        orc = oracle.OracleFft(n, dtype).transform(x[:n], int(code))
+        assert np.abs(got - orc).max() <= 2 * tol, n
+
+
+@pytest.mark.parametrize("dtype,eps", [(np.complex64, F32_EPS), (np.complex128, F64_EPS)])
+def test_reference_golden_vector(fa, dtype, eps):
+    x, y = load_ref10()
+    plan = make(fa, 10, dtype)
+    got = np.empty(10, dtype)
+    plan.fft(x.astype(dtype), got)
+    assert near(got, y, eps)[0]
+    plan.ifft(y.astype(dtype), got)
+    assert near(got, x, eps)[0]
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_ffi_impulse_roundtrip(fa, dtype):
+    plan = make(fa, 4, dtype)
+    x = np.array([1, 0, 0, 0], dtype=dtype)
+    out = np.empty_like(x)
+    plan.transform(x, out, fa.Transform.Fft)
+    assert np.allclose(out, 1)
+    plan.transform_in_place(out, fa.Transform.Ifft)
+    assert np.abs(out - x).max() <= 1e-10
+
+
+@pytest.mark.parametrize("n", [1, 2, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 1 << 14, 1 << 16, 1 << 18])
+@pytest.mark.parametrize("dtype,tl2,tmax", [(np.complex64, 1e-6, 2e-6), (np.complex128, 5e-14, 1e-13)])
+def test_pow2_all_codes_vs_oracle(torch, fa, oracle, n, dtype, tl2, tmax):
+    plan = make(fa, n, dtype)
+    batch = 5 if n <= 4096 else 3
+    x = np.stack([hash_normal(900 + b, n) for b in range(batch)]).astype(dtype)
+    for code in range(5):
+        ref = oracle.transform_batch(x, code)
+        for inplace in (False, True):
+            got = gpu_batch(torch, fa, plan, x, code, inplace)
+            assert rel_l2(got, ref) <= tl2 and max_rel(got, ref) <= tmax, (n, code, inplace, rel_l2(got, ref))
+
+
+@pytest.mark.parametrize("n", [3, 7, 12, 73, 96, 100, 255, 1000, 1025, 2500, 10007, 65537])
+def test_bluestein_and_mixed_radix_vs_oracle(torch, fa, oracle, n):
+    x = np.stack([hash_normal(40 + b, n) for b in range(3)])
+    for dtype, tl2 in ((np.complex64, 2e-6), (np.complex128, 5e-11)):
+        plan = make(fa, n, dtype)
+        for code in range(5):
+            ref = oracle.transform_batch(x.astype(dtype), code)
+            assert rel_l2(gpu_batch(torch, fa, plan, x.astype(dtype), code), ref) <= tl2, (n, code)
+            assert rel_l2(gpu_batch(torch, fa, plan, x.astype(dtype), code, True), ref) <= tl2, (n, code)
+        if dtype == np.complex128:  # against f64 truth the engine is tighter than the oracle's chirp
+            assert rel_l2(gpu_batch(torch, fa, plan, x.astype(dtype), 0), np.fft.fft(x, axis=1)) <= 1e-13
+
+
+def test_config_c1_n4096_spectrum(torch, fa):
+    g = np.load(os.path.join(GOLDEN, "n4096.npz"))
+    x = hash_normal(int(g["seed"]), 4096)
+    for dtype, tl2, tmax in ((np.complex64, 1e-6, 2e-6), (np.complex128, 5e-14, 1e-13)):
+        got = gpu_batch(torch, fa, make(fa, 4096, dtype), x.astype(dtype)[None, :], 0)[0]
+        assert rel_l2(got, g["y"]) <= tl2 and max_rel(got, g["y"]) <= tmax
+
+
+@pytest.mark.parametrize("n,dtype,tl2,tmax", [
+    (1 << 20, np.complex64, 1e-6, 2e-6),    # C2
+    (1 << 20, np.complex128, 5e-14, 1e-13),  # C3
+    (999983, np.complex64, 2e-6, 4e-6),     # C4
+    (1 << 22, np.complex64, 1e-6, 2e-6),    # C5
+])
+def test_baseline_sizes_vs_oracle_and_golden(torch, fa, oracle, n, dtype, tl2, tmax):
+    g = np.load(os.path.join(GOLDEN, "big_samples.npz"))
+    x0 = hash_uniform(int(g[f"seed_{n}"]), n).astype(dtype)
+    x = np.stack([x0, hash_uniform(11, n).astype(dtype), hash_uniform(12, n).astype(dtype)])
+    plan = make(fa, n, dtype)
+    got = gpu_batch(torch, fa, plan, x, 0)
+    ref = oracle.transform_batch(x, oracle.FFT, nthreads=3)
+    for b in range(3):
+        assert rel_l2(got[b], ref[b]) <= tl2 and max_rel(got[b], ref[b]) <= tmax, (n, b, rel_l2(got[b], ref[b]))
+    bins = g[f"bins_{n}"]
+    assert np.abs(got[0][bins] - g[f"y_{n}"]).max() <= tmax * float(g[f"maxabs_{n}"])
+    # inverse, in place, every scaling, on the first transform
+    for code in (1, 2, 3, 4):
+        gi = gpu_batch(torch, fa, plan, x[:1], code, inplace=True)
+        ri = oracle.transform_batch(x[:1], code)
+        assert rel_l2(gi, ri) <= tl2, (n, code)
+
+
+def test_three_pass_size(torch, fa):
+    n = 1 << 23
+    plan = make(fa, n, np.complex64)
+    rng = np.random.default_rng(7)
+    x = (rng.standard_normal(n, np.float32) + 1j * rng.standard_normal(n, np.float32)).astype(np.complex64)[None, :]
+    ref = np.fft.fft(x[0].astype(np.complex128))
+    assert rel_l2(gpu_batch(torch, fa, plan, x, 0)[0], ref) <= 1e-6
+    assert rel_l2(gpu_batch(torch, fa, plan, x, 0, inplace=True)[0], ref) <= 1e-6
+
+
+def _full_size_properties(torch, fa, oracle, n, batch, dtype, tl2, chunk_bytes=None):
+    """BASELINE full sizes: round trip, Parseval, linearity, plus sampled transforms vs the oracle."""
+    cdt = torch.complex64 if dtype == np.complex64 else torch.complex128
+    plan = make(fa, n, dtype)
+    if chunk_bytes is not None:
+        plan.set_option("chunk_bytes", chunk_bytes)
+    gen = torch.Generator(device="cuda").manual_seed(1234)
+    x = torch.empty((batch, n), dtype=cdt, device="cuda")
+    torch.view_as_real(x).normal_(0.0, 1.0, generator=gen)
+    y = torch.empty_like(x)
+    plan.transform(x, y, fa.Transform.Fft)
+    torch.cuda.synchronize()
+    # sampled transforms vs the oracle (first, middle, last -> batch indexing / chunking)
+    idx = [0, batch // 2, batch - 1]
+    hx = np.stack([x[i].cpu().numpy() for i in idx])
+    ref = oracle.transform_batch(hx, oracle.FFT, nthreads=3)
+    for k, i in enumerate(idx):
+        assert rel_l2(y[i].cpu().numpy(), ref[k]) <= tl2, (n, i)
+    # Parseval on every transform: sum|Y|^2 = N * sum|X|^2
+    ex = torch.view_as_real(x).double().pow(2).sum(dim=(1, 2)) if batch * n <= (1 << 28) else None
+    if ex is None:
+        worst = 0.0
+        for b0 in range(0, batch, 256):
+            ex_ = torch.view_as_real(x[b0:b0 + 256]).double().pow(2).sum(dim=(1, 2))
+            ey_ = torch.view_as_real(y[b0:b0 + 256]).double().pow(2).sum(dim=(1, 2))
+            worst = max(worst, float(((ey_ / n - ex_).abs() / ex_).max()))
+    else:
+        ey = torch.view_as_real(y).double().pow(2).sum(dim=(1, 2))
+        worst = float(((ey / n - ex).abs() / ex).max())
+    assert worst <= 10 * tl2, worst
+    # round trip in place: Ifft(Fft(x)) == x on the whole batch
+    plan.transform_in_place(y, fa.Transform.Ifft)
+    torch.cuda.synchronize()
+    worst = 0.0
+    for b0 in range(0, batch, 256):
+        d = torch.view_as_real(y[b0:b0 + 256] - x[b0:b0 + 256]).double().pow(2).sum(dim=(1, 2)).sqrt()
+        r = torch.view_as_real(x[b0:b0 + 256]).double().pow(2).sum(dim=(1, 2)).sqrt()
+        worst = max(worst, float((d / r).max()))
+    assert worst <= 2 * tl2, worst
+    del x, y
+    torch.cuda.empty_cache()
+
+
+def test_full_size_c2_f32_2p20_batch4096(torch, fa, oracle):
+    _full_size_properties(torch, fa, oracle, 1 << 20, 4096, np.complex64, 1e-6)
+
+
+def test_full_size_c2_chunked(torch, fa, oracle):
+    _full_size_properties(torch, fa, oracle, 1 << 20, 512, np.complex64, 1e-6, chunk_bytes=64 << 20)
+
+
+def test_full_size_c3_f64_2p20_batch4096(torch, fa, oracle):
+    _full_size_properties(torch, fa, oracle, 1 << 20, 4096, np.complex128, 5e-14)
+
+
+def test_full_size_c4_bluestein_batch512(torch, fa, oracle):
+    _full_size_properties(torch, fa, oracle, 999983, 512, np.complex64, 2e-6)
+
+
+def test_c5_chunk_of_2p22(torch, fa, oracle):
+    # C5 is 65536 transforms = 2 TiB: executed as fixed chunks; one 256-transform chunk here
+    _full_size_properties(torch, fa, oracle, 1 << 22, 256, np.complex64, 1e-6)
+
+
+def test_linearity(torch, fa):
+    n = 1 << 20
+    plan = make(fa, n, np.complex64)
+    a = hash_uniform(1, n).astype(np.complex64)[None, :]
+    b = hash_uniform(2, n).astype(np.complex64)[None, :]
+    fa_, fb = gpu_batch(torch, fa, plan, a, 0), gpu_batch(torch, fa, plan, b, 0)
+    fab = gpu_batch(torch, fa, plan, a + 2 * b, 0)
+    assert rel_l2(fab, fa_.astype(np.complex128) + 2 * fb.astype(np.complex128)) <= 1e-6
+
+
+def test_runs_on_a_side_stream(torch, fa, oracle):
+    n = 1 << 16
+    plan = make(fa, n, np.complex64)
+    x = np.stack([hash_normal(5 + b, n) for b in range(4)]).astype(np.complex64)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        d = torch.from_numpy(x).cuda()
+        o = torch.empty_like(d)
+        plan.transform(d, o, fa.Transform.Fft)
+    s.synchronize()
+    assert rel_l2(o.cpu().numpy(), oracle.transform_batch(x, 0)) <= 1e-6
+
+
+def test_error_behaviour(torch, fa):
+    from fourier_amd import _lib
+
+    L = _lib.lib()
+    assert not L.fourier_create_float(0)
+    L.fourier_destroy_float(None)
+    x = hash_normal(3, 8).astype(np.complex64)
+    buf = x.copy()
+    h = L.fourier_create_float(8)
+    L.fourier_transform_in_place_float(h, buf.ctypes.data, 9)  # unknown code: silent no-op
+    assert np.array_equal(buf, x)
+    L.fourier_transform_in_place_float(None, buf.ctypes.data, 0)  # NULL handle: no-op
+    assert np.array_equal(buf, x)
+    L.fourier_destroy_float(h)
+    with pytest.raises(fa.FourierError):
+        fa.create_fft_f32(0)
+    plan = fa.create_fft_f32(8)
+    with pytest.raises(ValueError):
+        plan.transform(torch.zeros(12, dtype=torch.complex64, device="cuda"),
+                       torch.zeros(12, dtype=torch.complex64, device="cuda"), fa.Transform.Fft)
+    with pytest.raises(TypeError):
+        plan.fft_in_place(torch.zeros(8, dtype=torch.complex128, device="cuda"))

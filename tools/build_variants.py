@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Builds A/B variants of libfourier.so (different compile-time knobs) into fourier_amd/lib/variants/
+so one GPU session can time them side by side (tools/gpu_sweep.py).  Development tool only."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fourier_amd import build as B  # noqa: E402
+
+VARIANTS = {
+    "base": [],
+    "slp": ["-fslp-vectorize"],
+    "waves1": ["-DFOURIER_MIN_WAVES(NT)=1"],
+    "nt_load": ["-DFOURIER_NT_LOAD=1"],
+    "nt_store": ["-DFOURIER_NT_STORE=1"],
+    "nt_both": ["-DFOURIER_NT_LOAD=1", "-DFOURIER_NT_STORE=1"],
+    "cg4": ["-DFOURIER_CG_1024=4"],
+    "cg16": ["-DFOURIER_CG_1024=16"],
+}
+
+
+def main(names):
+    outdir = os.path.join(ROOT, "fourier_amd", "lib", "variants")
+    os.makedirs(outdir, exist_ok=True)
+    procs = []
+    for name in names:
+        flags = [f for f in B.FLAGS if not (name == "slp" and f == "-fno-slp-vectorize")] + VARIANTS[name]
+        out = os.path.join(outdir, f"libfourier_{name}.so")
+        procs.append((name, subprocess.Popen([B.HIPCC] + flags + [B.SRC, "-o", out])))
+    for name, p in procs:
+        rc = p.wait()
+        print(name, "ok" if rc == 0 else f"FAILED rc={rc}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:] or list(VARIANTS))
