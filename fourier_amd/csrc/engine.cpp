@@ -287,7 +287,7 @@ template <typename T> class Pow2Engine {
   // Transform `batch` contiguous transforms.  in == out is allowed; scratch must hold batch*n
   // elements when needs_scratch(in == out) (or when force_scratch is set).
   void run(const cpx<T>* in, cpx<T>* out, cpx<T>* scratch, size_t batch, bool inverse, double scale, const cpx<T>* mul,
-           bool force_scratch, hipStream_t stream, Profiler* prof = nullptr, int slot0 = 0) const {
+           bool force_scratch, hipStream_t stream, Profiler* prof = nullptr, int slot0 = 0, unsigned nxcd = 8) const {
     if (batch == 0) return;
     if (tiny_) {
       TinyArgs a{in, out, mul, (uint64_t)batch, (int)n_, inverse, inverse, scale};
@@ -317,6 +317,7 @@ template <typename T> class Pow2Engine {
       a.mul = (p + 1 == np) ? mul : nullptr;
       a.n = n_; a.cn = ps.cn; a.s = ps.s;
       a.lo_bits = ps.lo_bits;
+      a.nxcd = nxcd;
       a.swap_in = (p == 0) && inverse;
       a.swap_out = (p + 1 == np) && inverse;
       a.scale = (p + 1 == np) ? scale : 1.0;
@@ -417,6 +418,7 @@ template <typename T> class Plan {
   int set_option(const std::string& key, long long v) {
     if (key == "chunk_bytes" && v >= 0) { chunk_bytes_ = (size_t)v; return 0; }
     if (key == "scratch" && (v == 0 || v == 1)) { force_scratch_ = (v == 1); return 0; }
+    if (key == "xcd_swizzle" && (v == 0 || v == 1)) { nxcd_ = v ? 8 : 1; return 0; }
     return ::fourier::c::FOURIER_HIP_INVALID_ARGUMENT;
   }
 
@@ -446,7 +448,7 @@ template <typename T> class Plan {
       if (need) scratch_.ensure(chunk * n_ * ELEM);
       for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const size_t nb = std::min(chunk, batch - b0);
-        eng_->run(in + b0 * n_, out + b0 * n_, (cpx<T>*)scratch_.p, nb, inverse, scale, nullptr, force_scratch_, stream, prof, 0);
+        eng_->run(in + b0 * n_, out + b0 * n_, (cpx<T>*)scratch_.p, nb, inverse, scale, nullptr, force_scratch_, stream, prof, 0, nxcd_);
       }
       return;
     }
@@ -461,8 +463,8 @@ template <typename T> class Plan {
       PROF_BEGIN(prof, 0);
       FOURIER_LAUNCH(&blu_pre_kernel<T>, elementwise_grid(nb * m_), 256, 0, stream, pre);
       PROF_END(prof);
-      eng_->run(work, work, (cpx<T>*)scratch_.p, nb, false, 1.0, (const cpx<T>*)wtab_.p, false, stream, prof, 1);
-      eng_->run(work, work, (cpx<T>*)scratch_.p, nb, true, 1.0, nullptr, false, stream, prof, 1 + np);
+      eng_->run(work, work, (cpx<T>*)scratch_.p, nb, false, 1.0, (const cpx<T>*)wtab_.p, false, stream, prof, 1, nxcd_);
+      eng_->run(work, work, (cpx<T>*)scratch_.p, nb, true, 1.0, nullptr, false, stream, prof, 1 + np, nxcd_);
       BluArgs post{work, out + b0 * n_, xtab_.p, (uint64_t)n_, (uint64_t)m_, (uint64_t)nb, inverse, scale};
       PROF_BEGIN(prof, 1 + 2 * np);
       FOURIER_LAUNCH(&blu_post_kernel<T>, elementwise_grid(nb * n_), 256, 0, stream, post);
@@ -537,6 +539,7 @@ template <typename T> class Plan {
   mutable DevBuf scratch_, work_, hostio_;
   size_t chunk_bytes_ = 0;
   bool force_scratch_ = false;
+  unsigned nxcd_ = 8;
   mutable int status_ = 0;
   std::string desc_;
 };

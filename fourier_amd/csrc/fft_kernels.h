@@ -43,13 +43,18 @@ template <typename T> struct alignas(8) Unit8 { T a[8 / sizeof(T)]; };     // on
 enum { MODE_FIRST = 0, MODE_MID = 1, MODE_LAST = 2, MODE_ROWS = 3 };
 
 // Build-time knobs (tools/build_variants.py A/B-tests them on the GPU):
-//   FOURIER_NT_LOAD  = 1: first-pass input loads are non-temporal (streamed once, keep them out of L2/MALL)
-//   FOURIER_NT_STORE = 1: final-pass output stores are non-temporal
+//   FOURIER_NT_LOAD  = 1 (default): first-pass input loads are non-temporal (streamed once)
+//   FOURIER_NT_STORE = 1 (default): final-pass output stores are non-temporal (+1% measured, r01 sweep)
+//   FOURIER_ABLATE (timing experiments only, results are wrong): 1 = no butterflies / twiddles,
+//   2 = additionally no LDS exchange (pure load -> store), 3 = no inter-pass twiddle only
+#ifndef FOURIER_ABLATE
+#define FOURIER_ABLATE 0
+#endif
 #ifndef FOURIER_NT_LOAD
-#define FOURIER_NT_LOAD 0
+#define FOURIER_NT_LOAD 1
 #endif
 #ifndef FOURIER_NT_STORE
-#define FOURIER_NT_STORE 0
+#define FOURIER_NT_STORE 1
 #endif
 
 // 16-byte global accesses (global_load_dwordx4 / global_store_dwordx4)
@@ -93,6 +98,7 @@ struct PassArgs {
   uint64_t tiles;     // column tiles per transform = cn / COLS
   uint64_t total_cols;  // ROWS mode: number of transforms in this launch
   uint32_t lo_bits;
+  uint32_t nxcd;      // >1: remap blockIdx so that each XCD (blockIdx % nxcd) walks a contiguous tile range
   int swap_in, swap_out;
   double scale;       // applied on the final store (LAST / ROWS)
 };
@@ -290,7 +296,15 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
   int cg = IN_ROWS ? tid / Q : tid % CG;
   const int thB = tid % Q, cgB = tid / Q;
 
-  const uint64_t blk = blockIdx.x;
+  // Workgroup b is dispatched to XCD b % 8 (observed, MI355X_MICROARCH.md).  Give every XCD its own
+  // contiguous range of tiles (= whole transforms): each 2 MiB page and each DRAM row is then
+  // touched by one XCD's L2/TLB instead of all eight (+11..16% on the strided tile pattern, measured
+  // with tools/membench.py --xcd).  Bijective for any grid size; affects speed only.
+  uint64_t blk = blockIdx.x;
+  if (a.nxcd > 1) {
+    const uint64_t nwg = gridDim.x, nx = a.nxcd, xcd = blk % nx, q = nwg / nx, r = nwg % nx;
+    blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + blk / nx;
+  }
   const cpx<T>* __restrict__ in = (const cpx<T>*)a.in;
   cpx<T>* __restrict__ out = (cpx<T>*)a.out;
   uint64_t b = 0, c0 = 0, g0 = 0;
@@ -343,11 +357,15 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
   }
 
   // ---- stage 1: radix 16 over rows th + Q*k'  ->  positions 16*th + k, twiddle W_L^{th*k}
+  constexpr bool DO_MATH = (FOURIER_ABLATE != 1 && FOURIER_ABLATE != 2);
+  constexpr bool DO_EXCH = (FOURIER_ABLATE != 2);
+  if constexpr (DO_MATH) {
 #pragma unroll
-  for (int v = 0; v < VEC; ++v) dft16(x[v]);
+    for (int v = 0; v < VEC; ++v) dft16(x[v]);
+  }
 
   if constexpr (Q > 1) {
-    {
+    if constexpr (DO_MATH) {
       const cpx<T>* t1 = (const cpx<T>*)a.tw1 + th * 16;
 #pragma unroll
       for (int k = 1; k < 16; ++k) {
@@ -362,12 +380,14 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
       const int th_w = th;
       // both sides cg-fastest and split planes -> xor layout; anything row-contiguous -> skew layout
       constexpr int LAY1 = (C::SPLIT && !IN_ROWS && !(MODE == MODE_FIRST && R3 == 1)) ? 1 : 0;
-      lds_exchange<T, L, CG, LAY1>(x, smem, cg, [=](int r) { return 16 * th_w + r; }, th_r, cg_r, 0);
+      if constexpr (DO_EXCH)
+        lds_exchange<T, L, CG, LAY1>(x, smem, cg, [=](int r) { return 16 * th_w + r; }, th_r, cg_r, 0);
       th = th_r; cg = cg_r;
     }
 
     // ---- stage 2: radix R2 on butterflies q = th + Q*u (register sets {u + NB2*k'})
     constexpr int NB2 = 16 / R2;
+    if constexpr (DO_MATH)
 #pragma unroll
     for (int v = 0; v < VEC; ++v)
 #pragma unroll
@@ -382,7 +402,7 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
 
     if constexpr (R3 > 1) {
       // here R2 == 16, one butterfly per thread: q = th, j = th & 15, i = th >> 4
-      {
+      if constexpr (DO_MATH) {
         const cpx<T>* t2 = (const cpx<T>*)a.tw2 + (th >> 4) * 16;
 #pragma unroll
         for (int k = 1; k < 16; ++k) {
@@ -396,11 +416,13 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
         const int th_r = remap ? thB : th, cg_r = remap ? cgB : cg;
         const int jw = th & 15, iw = th >> 4;
         __syncthreads();  // all reads of exchange 1 are done before the buffer is rewritten
+        if constexpr (DO_EXCH)
         lds_exchange<T, L, CG, 0>(x, smem, cg, [=](int r) { return jw + 16 * (16 * iw + r); }, th_r, cg_r, 4);
         th = th_r; cg = cg_r;
       }
       // ---- stage 3: radix R3 on register sets {u + NB3*k'}
       constexpr int NB3 = 16 / R3;
+      if constexpr (DO_MATH)
 #pragma unroll
       for (int v = 0; v < VEC; ++v)
 #pragma unroll
@@ -417,7 +439,7 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
   // now register r holds output index k = th + Q*r of columns (cg*VEC + v)
 
   // ---- inter-pass twiddle W_size^{i*k} = W^{i*th} * tabU[col][r]
-  if constexpr (TWIDDLED) {
+  if constexpr (TWIDDLED && DO_MATH && FOURIER_ABLATE != 3) {
     if constexpr (Q == 1) __syncthreads();  // tabU visibility when there was no exchange barrier
     const cpx<T>* tabU = (const cpx<T>*)(smem + C::TABU_OFF);
 #pragma unroll

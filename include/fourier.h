@@ -116,7 +116,8 @@ const char *fourier_hip_status_string(int status);
  *   "chunk_bytes"  bytes of one batch chunk pushed through all passes before the next chunk starts
  *                  (keeps the inter-pass intermediate inside the 256 MiB Infinity Cache); 0 = whole batch
  *   "scratch"      1 = always route the intermediate through the plan's reused scratch buffer,
- *                  0 = use the output buffer as intermediate when out of place (default) */
+ *                  0 = use the output buffer as intermediate when out of place (default)
+ *   "xcd_swizzle"  1 (default) = XCD-aware workgroup->tile mapping, 0 = plain blockIdx order */
 int fourier_hip_set_option_float(FOURIER_STRUCT fourier_fft_float *, const char *key, long long value);
 int fourier_hip_set_option_double(FOURIER_STRUCT fourier_fft_double *, const char *key, long long value);
 

@@ -98,6 +98,19 @@ def main():
                 emit(tag="variant:" + name, error=repr(e))
         _lib.use_library(base_lib)
 
+    if "xcd" in what:
+        for xcd in (0, 1):
+            for scratch, chunk in ((0, 0), (1, 0), (1, 1 << 30), (1, 256 << 20)):
+                plan = F.create_fft_f32(n, 0)
+                plan.set_option("xcd_swizzle", xcd)
+                plan.set_option("scratch", scratch)
+                plan.set_option("chunk_bytes", chunk)
+                med, best = time_plan(plan, x, y, batch)
+                prof = plan.profile_batch_ptr(x.data_ptr(), y.data_ptr(), batch, 0, torch.cuda.current_stream().cuda_stream)
+                report(f"xcd={xcd},scratch={scratch},chunk={chunk >> 20}MiB", plan, n, batch, 8, med, best,
+                       {"kernels_ms": {k: round(ms, 3) for k, ms, _ in prof}})
+                del plan
+
     if "options" in what:
         for inplace in (0, 1):
             for scratch in (0, 1):

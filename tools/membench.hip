@@ -1,0 +1,174 @@
+// membench.hip -- development microbenchmarks (not product): achievable HBM / Infinity-Cache
+// bandwidth for the access patterns the FFT passes use.  Built by tools/membench.py with hipcc.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+
+// linear copy: each thread moves U units (16 B) per outer iteration, grid-stride; `iters` repeats
+// the whole copy inside the launch (persistent form: no launch gaps -> cache-resident bandwidth)
+template <int U, int MODE>  // MODE 0 copy, 1 read-only (sum), 2 write-only
+__global__ void __launch_bounds__(256) k_lin(const v4u* __restrict__ src, v4u* __restrict__ dst, uint64_t units, int iters) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  v4u acc = {0, 0, 0, 0};
+  for (int it = 0; it < iters; ++it) {
+    for (uint64_t base = (uint64_t)blockIdx.x * 256 + threadIdx.x; base < units; base += stride * U) {
+      v4u v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t i = base + (uint64_t)u * stride;
+        if (MODE != 2) v[u] = (i < units) ? src[i] : v4u{0, 0, 0, 0};
+        else v[u] = v4u{(unsigned)i, 1, 2, 3};
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t i = base + (uint64_t)u * stride;
+        if (MODE == 1) acc += v[u];
+        else if (i < units) dst[i] = v[u];
+      }
+    }
+  }
+  if (MODE == 1 && acc.x == 0x12345678u) dst[0] = acc;
+}
+
+// block-contiguous copy: block b owns a contiguous slab; mirrors "one tile per workgroup"
+template <int U>
+__global__ void __launch_bounds__(256) k_slab(const v4u* __restrict__ src, v4u* __restrict__ dst, uint64_t units_per_block) {
+  const v4u* s = src + (uint64_t)blockIdx.x * units_per_block;
+  v4u* d = dst + (uint64_t)blockIdx.x * units_per_block;
+  for (uint64_t base = threadIdx.x; base < units_per_block; base += 256 * U) {
+    v4u v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = s[base + u * 256];
+#pragma unroll
+    for (int u = 0; u < U; ++u) d[base + u * 256] = v[u];
+  }
+}
+
+// column-tile copy: the FFT pass pattern without compute.  Matrix rows x rowunits (16-B units);
+// a block of 512 threads moves a tile of `rows` x 8 units: thread (th = tid/8, cg = tid%8) loads 16
+// rows th + 64*r.  transposed=1 writes like the FIRST pass (tile column c -> contiguous row c).
+__global__ void __launch_bounds__(512) k_tile(const v4u* __restrict__ src, v4u* __restrict__ dst, uint64_t rowunits,
+                                              int transposed) {
+  const int tid = threadIdx.x, cg = tid & 7, th = tid >> 3;  // 64 x 8
+  const uint64_t tiles = rowunits / 8;
+  const uint64_t b = blockIdx.x / tiles, t = blockIdx.x % tiles;
+  const uint64_t xform = 1024 * rowunits;
+  const v4u* s = src + b * xform + t * 8 + cg;
+  v4u v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = s[(uint64_t)(th + 64 * r) * rowunits];
+  if (!transposed) {
+    v4u* d = dst + b * xform + t * 8 + cg;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[(uint64_t)(th + 64 * r) * rowunits] = v[r];
+  } else {
+    // tile holds 16 columns (2 per unit); column c of tile t -> output row (t*16 + c), 1024 elements
+    // = 512 units; lane-contiguous 8-byte stores in the real kernel, modelled here as one 16-B unit
+    // per lane pair: thread writes unit (th + 64*r)/2 ... keep it simple: each thread writes 16 units
+    // of row (t*8 + cg) at unit offsets th + 64*r (rows are 1024 units apart here)
+    v4u* d = dst + b * xform + (t * 8 + cg) * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[th + 64 * r] = v[r];
+  }
+}
+
+// Model of a fused two-pass FFT kernel's traffic: per tile, stream 128 KiB in from A (HBM), park
+// 128 KiB in a small reused ring S, read another 128 KiB back from S, stream 128 KiB out to B (HBM).
+// No synchronisation (throughput model only).  ring_tiles*128 KiB = footprint of S.
+__global__ void __launch_bounds__(512) k_fused_model(const v4u* __restrict__ A, v4u* __restrict__ B, v4u* __restrict__ S,
+                                                     uint64_t tiles, uint64_t ring_tiles, int mode) {
+  const int tid = threadIdx.x;
+  for (uint64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const v4u* a = A + t * 8192 + tid;
+    v4u v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = a[r * 512];
+    if (mode >= 1) {
+      v4u* s = S + (t % ring_tiles) * 8192 + tid;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r * 512] = v[r];
+    }
+    if (mode >= 2) {
+      const v4u* s2 = S + ((t + ring_tiles / 2 + 7) % ring_tiles) * 8192 + tid;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = s2[r * 512];
+    }
+    v4u* b = B + t * 8192 + tid;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) b[r * 512] = v[r];
+  }
+}
+// XCD-aware slab copy: block b is observed to run on XCD b % 8.  With swz=1 the slab index is
+// remapped so that every XCD walks its own contiguous 1/8 of the buffer (each 2 MiB page is then
+// touched -- and its translation fetched -- by one XCD instead of all eight).
+template <int U>
+__global__ void __launch_bounds__(256) k_slab_x(const v4u* __restrict__ src, v4u* __restrict__ dst, uint64_t units_per_block, int swz) {
+  uint64_t b = blockIdx.x;
+  if (swz) { const uint64_t cpx = gridDim.x / 8; b = (b % 8) * cpx + b / 8; }
+  const v4u* s = src + b * units_per_block;
+  v4u* d = dst + b * units_per_block;
+  for (uint64_t base = threadIdx.x; base < units_per_block; base += 256 * U) {
+    v4u v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = s[base + u * 256];
+#pragma unroll
+    for (int u = 0; u < U; ++u) d[base + u * 256] = v[u];
+  }
+}
+extern "C" int mb_slab_x(const void* src, void* dst, uint64_t bytes, uint64_t bytes_per_block, int swz, void* stream) {
+  const unsigned blocks = (unsigned)(bytes / bytes_per_block);
+  k_slab_x<8><<<blocks, 256, 0, (hipStream_t)stream>>>((const v4u*)src, (v4u*)dst, bytes_per_block / 16, swz);
+  return (int)hipGetLastError();
+}
+__global__ void __launch_bounds__(512) k_tile_x(const v4u* __restrict__ src, v4u* __restrict__ dst, uint64_t rowunits, int swz) {
+  const int tid = threadIdx.x, cg = tid & 7, th = tid >> 3;
+  const uint64_t tiles = rowunits / 8;
+  uint64_t blk = blockIdx.x;
+  if (swz) { const uint64_t cpx = gridDim.x / 8; blk = (blk % 8) * cpx + blk / 8; }
+  const uint64_t b = blk / tiles, t = blk % tiles;
+  const uint64_t xform = 1024 * rowunits;
+  const v4u* s = src + b * xform + t * 8 + cg;
+  v4u v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = s[(uint64_t)(th + 64 * r) * rowunits];
+  v4u* d = dst + b * xform + t * 8 + cg;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) d[(uint64_t)(th + 64 * r) * rowunits] = v[r];
+}
+extern "C" int mb_tile_x(const void* src, void* dst, uint64_t bytes, int swz, void* stream) {
+  const uint64_t rowunits = 512, xform_bytes = 1024 * rowunits * 16;
+  const unsigned blocks = (unsigned)(bytes / xform_bytes * (rowunits / 8));
+  k_tile_x<<<blocks, 512, 0, (hipStream_t)stream>>>((const v4u*)src, (v4u*)dst, rowunits, swz);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mb_fused_model(const void* A, void* B, void* S, uint64_t bytes, uint64_t ring_bytes, int mode, int blocks, void* stream) {
+  k_fused_model<<<blocks, 512, 0, (hipStream_t)stream>>>((const v4u*)A, (v4u*)B, (v4u*)S, bytes / (128 << 10), ring_bytes / (128 << 10), mode);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mb_lin(int mode, int U, const void* src, void* dst, uint64_t bytes, int blocks, int iters, void* stream) {
+  const uint64_t units = bytes / 16;
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(UU, MM) k_lin<UU, MM><<<blocks, 256, 0, st>>>((const v4u*)src, (v4u*)dst, units, iters)
+#define BYMODE(UU) do { if (mode == 0) LAUNCH(UU, 0); else if (mode == 1) LAUNCH(UU, 1); else LAUNCH(UU, 2); } while (0)
+  if (U == 1) BYMODE(1); else if (U == 2) BYMODE(2); else if (U == 4) BYMODE(4); else if (U == 8) BYMODE(8); else BYMODE(16);
+  return (int)hipGetLastError();
+}
+extern "C" int mb_slab(int U, const void* src, void* dst, uint64_t bytes, uint64_t bytes_per_block, void* stream) {
+  const uint64_t upb = bytes_per_block / 16;
+  const unsigned blocks = (unsigned)(bytes / bytes_per_block);
+  hipStream_t st = (hipStream_t)stream;
+  if (U == 4) k_slab<4><<<blocks, 256, 0, st>>>((const v4u*)src, (v4u*)dst, upb);
+  else if (U == 8) k_slab<8><<<blocks, 256, 0, st>>>((const v4u*)src, (v4u*)dst, upb);
+  else k_slab<16><<<blocks, 256, 0, st>>>((const v4u*)src, (v4u*)dst, upb);
+  return (int)hipGetLastError();
+}
+extern "C" int mb_tile(const void* src, void* dst, uint64_t bytes, int transposed, void* stream) {
+  const uint64_t rowunits = 512;  // 1024 complex64 per row = 8 KiB
+  const uint64_t xform_bytes = 1024 * rowunits * 16;
+  const unsigned blocks = (unsigned)(bytes / xform_bytes * (rowunits / 8));
+  k_tile<<<blocks, 512, 0, (hipStream_t)stream>>>((const v4u*)src, (v4u*)dst, rowunits, transposed);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Development microbenchmarks: HBM / Infinity-Cache bandwidth for the FFT passes' access patterns."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "tools", "libmembench.so")
+
+
+def build():
+    src = os.path.join(ROOT, "tools", "membench.hip")
+    if not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", src, "-o", SO])
+    return SO
+
+
+def main():
+    import torch
+
+    L = ctypes.CDLL(build())
+    vp, u64, ci = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int
+    L.mb_lin.argtypes = [ci, ci, vp, vp, u64, ci, ci, vp]
+    L.mb_slab.argtypes = [ci, vp, vp, u64, u64, vp]
+    L.mb_tile.argtypes = [vp, vp, u64, ci, vp]
+    out = open(os.path.join(ROOT, "gpurun_out", "membench.jsonl"), "a")
+
+    def emit(**kw):
+        s = json.dumps(kw)
+        print(s, flush=True)
+        out.write(s + "\n")
+        out.flush()
+
+    dev = torch.device("cuda", 0)
+    big = 16 << 30
+    a = torch.empty(big, dtype=torch.uint8, device=dev)
+    b = torch.empty(big, dtype=torch.uint8, device=dev)
+    a.view(torch.float32).uniform_(0, 1)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def timeit(fn, reps=5, warm=2):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    L.mb_fused_model.argtypes = [vp, vp, vp, u64, u64, ci, ci, vp]
+    L.mb_slab_x.argtypes = [vp, vp, u64, u64, ci, vp]
+    L.mb_tile_x.argtypes = [vp, vp, u64, ci, vp]
+    if "--xcd" in sys.argv:
+        for swz in (0, 1):
+            for slab in (64 << 10, 128 << 10, 512 << 10, 2 << 20):
+                t = timeit(lambda: L.mb_slab_x(a.data_ptr(), b.data_ptr(), big, slab, swz, st))
+                emit(tag="slab_x", swz=swz, slab_kib=slab >> 10, ms=round(t * 1e3, 3), tbps=round(2 * big / t / 1e12, 3))
+            t = timeit(lambda: L.mb_tile_x(a.data_ptr(), b.data_ptr(), big, swz, st))
+            emit(tag="tile_x", swz=swz, ms=round(t * 1e3, 3), tbps=round(2 * big / t / 1e12, 3))
+            t = timeit(lambda: L.mb_tile_x(a.data_ptr(), a.data_ptr(), big, swz, st))
+            emit(tag="tile_x_inplace", swz=swz, ms=round(t * 1e3, 3), tbps=round(2 * big / t / 1e12, 3))
+        return
+    if "--fused-only" in sys.argv:
+        ring = torch.empty(4 << 30, dtype=torch.uint8, device=dev)
+        for blocks in (256, 512, 1024):
+            for mode, mname in ((0, "copy_only"), (1, "copy+ring_write"), (2, "copy+ring_write+ring_read")):
+                for ring_mib in (16, 32, 64, 128, 192, 256, 1024, 4096):
+                    if mode == 0 and ring_mib != 16:
+                        continue
+                    t = timeit(lambda: L.mb_fused_model(a.data_ptr(), b.data_ptr(), ring.data_ptr(), big, ring_mib << 20, mode, blocks, st), reps=3, warm=1)
+                    emit(tag="fused_model", mode=mname, blocks=blocks, ring_mib=ring_mib, ms=round(t * 1e3, 3),
+                         alg_tbps=round(2 * big / t / 1e12, 3), us_per_8MiB=round(t / (big / (8 << 20)) * 1e6, 3))
+        return
+    # 1. linear streaming, HBM-sized
+    for mode, mname in ((0, "copy"), (1, "read"), (2, "write")):
+        for U in (4, 8, 16):
+            for blocks in (2048, 4096, 8192, 65536):
+                t = timeit(lambda: L.mb_lin(mode, U, a.data_ptr(), b.data_ptr(), big, blocks, 1, st))
+                traffic = big * (2 if mode == 0 else 1)
+                emit(tag=f"lin_{mname}", U=U, blocks=blocks, ms=round(t * 1e3, 3), tbps=round(traffic / t / 1e12, 3))
+    # 2. slab (one contiguous slab per block)
+    for U in (4, 8, 16):
+        for slab in (64 << 10, 128 << 10, 1 << 20):
+            t = timeit(lambda: L.mb_slab(U, a.data_ptr(), b.data_ptr(), big, slab, st))
+            emit(tag="slab_copy", U=U, slab_kib=slab >> 10, ms=round(t * 1e3, 3), tbps=round(2 * big / t / 1e12, 3))
+    # 3. column-tile pattern of the FFT passes (no compute)
+    for tr in (0, 1):
+        t = timeit(lambda: L.mb_tile(a.data_ptr(), b.data_ptr(), big, tr, st))
+        emit(tag="tile_copy", transposed=tr, ms=round(t * 1e3, 3), tbps=round(2 * big / t / 1e12, 3))
+        t = timeit(lambda: L.mb_tile(a.data_ptr(), a.data_ptr(), big, 0, st)) if tr == 0 else None
+        if t:
+            emit(tag="tile_copy_inplace", ms=round(t * 1e3, 3), tbps=round(2 * big / t / 1e12, 3))
+    # 4. footprint sweep: the same copy repeated inside one launch (persistent) -> cache-resident bandwidth
+    for fp_mib in (8, 16, 32, 64, 96, 128, 192, 256, 384, 512, 1024, 4096):
+        fp = fp_mib << 20
+        iters = max(2, min(400, (32 << 30) // fp))
+        for mode, mname in ((0, "copy"), (1, "read"), (2, "write")):
+            half = fp // 2 if mode == 0 else fp
+            t = timeit(lambda: L.mb_lin(mode, 8, a.data_ptr(), b.data_ptr(), half, 2048, iters, st), reps=2, warm=1)
+            traffic = half * iters * (2 if mode == 0 else 1)
+            emit(tag=f"footprint_{mname}", footprint_mib=fp_mib, iters=iters, ms=round(t * 1e3, 3), tbps=round(traffic / t / 1e12, 3))
+    # 5. write-then-read across launches: is freshly written data served from the Infinity Cache?
+    for fp_mib in (16, 32, 64, 128, 192, 256, 512, 2048):
+        fp = fp_mib << 20
+        def wr():
+            L.mb_lin(2, 8, a.data_ptr(), b.data_ptr(), fp, 2048, 1, st)   # write b[0:fp]
+        def rd():
+            L.mb_lin(1, 8, b.data_ptr(), a.data_ptr(), fp, 2048, 1, st)   # read b[0:fp]
+        tw = timeit(wr, reps=20, warm=2)
+        trd = timeit(rd, reps=20, warm=2)
+        both = timeit(lambda: (wr(), rd()), reps=20, warm=2)
+        emit(tag="write_then_read", footprint_mib=fp_mib, write_us=round(tw * 1e6, 1), read_us=round(trd * 1e6, 1),
+             pair_us=round(both * 1e6, 1), pair_tbps=round(2 * fp / both / 1e12, 3))
+
+
+if __name__ == "__main__":
+    main()
