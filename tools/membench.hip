@@ -143,6 +143,181 @@ extern "C" int mb_tile_x(const void* src, void* dst, uint64_t bytes, int swz, vo
   return (int)hipGetLastError();
 }
 
+// ---- fused two-phase model WITH team barriers (what the real fused FFT kernel would do, minus math)
+// grid = 8 XCDs x teams_per_xcd x wgs_per_team persistent workgroups (block b -> XCD b % 8, observed).
+// A team processes transforms t = team, team + nteams, ...: phase A moves the transform's 64 tiles
+// (1024 rows x 128 B, column-tile pattern) from A into the team's 8 MiB scratch (transposed rows),
+// team barrier (release/acquire at agent scope), phase B moves 64 column tiles scratch -> B,
+// second barrier (WAR on the scratch).  Spins are bounded; on timeout a flag is set and everybody bails.
+__device__ __forceinline__ void team_arrive(unsigned* ctr, bool release) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (release) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__device__ __forceinline__ bool team_wait(unsigned* ctr, unsigned target, unsigned* abort_flag, bool acquire) {
+  __shared__ int ok_s;
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    unsigned spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > (1u << 22) || ((spins & 255) == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+    }
+    if (acquire) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      // the L1 invalidate must have COMPLETED before the other waves pass the barrier below
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    ok_s = ok;
+  }
+  __syncthreads();
+  return ok_s != 0;
+}
+__global__ void __launch_bounds__(512, 4) k_fused_sync(const v4u* __restrict__ A, v4u* __restrict__ B, v4u* __restrict__ S,
+                                                       unsigned* ctrs, uint64_t ntransforms, int teams_per_xcd,
+                                                       int wgs_per_team, int variant) {
+  extern __shared__ unsigned char pad_lds[];  // occupy LDS like the real kernel (limits to 2 WG/CU)
+  const int tid = threadIdx.x, cg = tid & 7, th = tid >> 3;
+  const unsigned xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+  const unsigned team_in_xcd = slot / wgs_per_team, w = slot % wgs_per_team;
+  const unsigned nteams = 8 * teams_per_xcd, team = xcd * teams_per_xcd + team_in_xcd;
+  unsigned* ctr1 = ctrs + team * 64;       // arrivals of phase A (data release)
+  unsigned* ctr2 = ctrs + team * 64 + 32;  // arrivals of phase B (scratch free again)
+  unsigned* abort_flag = ctrs + 4096;
+  v4u* Sg = S + (uint64_t)team * (512 * 1024);  // 8 MiB per team
+  const uint64_t rowunits = 512, xform = 1024 * rowunits;
+  unsigned phase = 0;
+  for (uint64_t t = team; t < ntransforms; t += nteams, ++phase) {
+    // ---- phase A: tiles w, w + wgs_per_team, ... of transform t: A -> Sg (transposed rows)
+    for (unsigned tile = w; tile < 64; tile += wgs_per_team) {
+      const v4u* s = A + t * xform + tile * 8 + cg;
+      v4u v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = __builtin_nontemporal_load(s + (uint64_t)(th + 64 * r) * rowunits);
+      if (tile == w && phase > 0) {  // scratch must be free: all phase-B reads of the previous transform done
+        if (!team_wait(ctr2, phase * wgs_per_team, abort_flag, false)) return;
+      }
+      v4u* d = Sg + (uint64_t)(tile * 8 + cg) * 1024;  // column c of the tile -> contiguous row
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d[th + 64 * r] = v[r];
+    }
+    team_arrive(ctr1, true);
+    if (!team_wait(ctr1, (phase + 1) * wgs_per_team, abort_flag, true)) return;
+    // ---- phase B: column tiles of the scratch -> B
+    for (unsigned tile = w; tile < 64; tile += wgs_per_team) {
+      const v4u* s = Sg + tile * 8 + cg;
+      v4u v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = s[(uint64_t)(th + 64 * r) * rowunits];
+      if (tile + wgs_per_team >= 64) team_arrive(ctr2, false);  // last tile's loads have landed (vmcnt(0) inside)
+      v4u* d = B + t * xform + tile * 8 + cg;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(v[r], d + (uint64_t)(th + 64 * r) * rowunits);
+    }
+  }
+  (void)variant; (void)pad_lds;
+}
+// ---- variant 2: software-pipelined (phase A of transform t+1 runs before phase B of t, scratch double
+// buffered) and write-through (sc1) scratch stores instead of an L2 write-back fence.
+__device__ __forceinline__ void store_sc1(v4u* p, v4u v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ v4u load_flavour(const v4u* p, int flavour) {
+  v4u v;
+  if (flavour == 1) asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  else if (flavour == 2) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  else v = *p;
+  return v;
+}
+__global__ void __launch_bounds__(512, 4) k_fused_pipe(const v4u* __restrict__ A, v4u* __restrict__ B, v4u* __restrict__ S,
+                                                       unsigned* ctrs, uint64_t ntransforms, int teams_per_xcd,
+                                                       int wgs_per_team, int use_sc1) {
+  extern __shared__ unsigned char pad_lds[];
+  const int tid = threadIdx.x, cg = tid & 7, th = tid >> 3;
+  const int load_fl = use_sc1 >> 4;
+  use_sc1 &= 15;
+  if (tid == 0) ctrs[4200 + blockIdx.x] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID[3:0]
+  const unsigned xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+  const unsigned team_in_xcd = slot / wgs_per_team, w = slot % wgs_per_team;
+  const unsigned nteams = 8 * teams_per_xcd, team = xcd * teams_per_xcd + team_in_xcd;
+  unsigned* ctr1 = ctrs + team * 64;
+  unsigned* ctr2 = ctrs + team * 64 + 32;
+  unsigned* abort_flag = ctrs + 4096;
+  v4u* S0 = S + (uint64_t)team * (2 * 512 * 1024);  // 2 x 8 MiB per team
+  const uint64_t rowunits = 512, xform = 1024 * rowunits;
+  const uint64_t mine = (ntransforms > team) ? (ntransforms - team + nteams - 1) / nteams : 0;  // transforms of this team
+  // iteration i: phase A of local transform i (if any), then phase B of local transform i-1 (if any)
+  for (uint64_t i = 0; i <= mine; ++i) {
+    if (i < mine) {
+      const uint64_t t = team + i * nteams;
+      v4u* Sg = S0 + (i & 1) * (512 * 1024);
+      for (unsigned tile = w; tile < 64; tile += wgs_per_team) {
+        const v4u* s = A + t * xform + tile * 8 + cg;
+        v4u v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = __builtin_nontemporal_load(s + (uint64_t)(th + 64 * r) * rowunits);
+        if (tile == w && i >= 2) {  // buffer (i&1) was last read by phase B of local transform i-2
+          if (!team_wait(ctr2, (unsigned)(i - 1) * wgs_per_team, abort_flag, false)) return;
+        }
+        v4u* d = Sg + (uint64_t)(tile * 8 + cg) * 1024;
+        if (use_sc1) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) store_sc1(d + th + 64 * r, v[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) d[th + 64 * r] = v[r];
+        }
+      }
+      team_arrive(ctr1, !use_sc1);
+    }
+    if (i >= 1) {
+      const uint64_t t = team + (i - 1) * nteams;
+      const v4u* Sg = S0 + ((i - 1) & 1) * (512 * 1024);
+      if (!team_wait(ctr1, (unsigned)i * wgs_per_team, abort_flag, true)) return;
+      for (unsigned tile = w; tile < 64; tile += wgs_per_team) {
+        const v4u* s = Sg + tile * 8 + cg;
+        v4u v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = load_flavour(s + (uint64_t)(th + 64 * r) * rowunits, load_fl);
+        if (tile + wgs_per_team >= 64) team_arrive(ctr2, false);
+        v4u* d = B + t * xform + tile * 8 + cg;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(v[r], d + (uint64_t)(th + 64 * r) * rowunits);
+      }
+    }
+  }
+  (void)pad_lds;
+}
+extern "C" int mb_fused_pipe(const void* A, void* B, void* S, void* ctrs, uint64_t bytes, int teams_per_xcd, int wgs_per_team,
+                             int lds_bytes, int use_sc1, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  hipMemsetAsync(ctrs, 0, 4097 * 4, st);
+  hipFuncSetAttribute((const void*)k_fused_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  const unsigned blocks = 8 * teams_per_xcd * wgs_per_team;
+  k_fused_pipe<<<blocks, 512, lds_bytes, st>>>((const v4u*)A, (v4u*)B, (v4u*)S, (unsigned*)ctrs, bytes / (8 << 20), teams_per_xcd, wgs_per_team, use_sc1);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mb_fused_sync(const void* A, void* B, void* S, void* ctrs, uint64_t bytes, int teams_per_xcd, int wgs_per_team,
+                             int lds_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  hipMemsetAsync(ctrs, 0, 4097 * 4, st);
+  hipFuncSetAttribute((const void*)k_fused_sync, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  const unsigned blocks = 8 * teams_per_xcd * wgs_per_team;
+  k_fused_sync<<<blocks, 512, lds_bytes, st>>>((const v4u*)A, (v4u*)B, (v4u*)S, (unsigned*)ctrs, bytes / (8 << 20), teams_per_xcd, wgs_per_team, 0);
+  return (int)hipGetLastError();
+}
+
 extern "C" int mb_fused_model(const void* A, void* B, void* S, uint64_t bytes, uint64_t ring_bytes, int mode, int blocks, void* stream) {
   k_fused_model<<<blocks, 512, 0, (hipStream_t)stream>>>((const v4u*)A, (v4u*)B, (v4u*)S, bytes / (128 << 10), ring_bytes / (128 << 10), mode);
   return (int)hipGetLastError();

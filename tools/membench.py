@@ -56,6 +56,49 @@ def main():
     L.mb_fused_model.argtypes = [vp, vp, vp, u64, u64, ci, ci, vp]
     L.mb_slab_x.argtypes = [vp, vp, u64, u64, ci, vp]
     L.mb_tile_x.argtypes = [vp, vp, u64, ci, vp]
+    L.mb_fused_sync.argtypes = [vp, vp, vp, vp, u64, ci, ci, ci, vp]
+    L.mb_fused_pipe.argtypes = [vp, vp, vp, vp, u64, ci, ci, ci, ci, vp]
+    if "--pipe" in sys.argv:
+        S = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        ctrs = torch.zeros(8192, dtype=torch.int32, device=dev)
+        nt = big // (8 << 20)
+        for sc1 in (1, 1, 1 + 16):
+            for tpx, wpt in ((1, 64), (2, 32), (4, 16)):
+                b.zero_()
+                t = timeit(lambda: L.mb_fused_pipe(a.data_ptr(), b.data_ptr(), S.data_ptr(), ctrs.data_ptr(), big, tpx, wpt, 69632, sc1, st), reps=3, warm=1)
+                torch.cuda.synchronize()
+                flag = int(ctrs[4096].item())
+                bad = 0
+                for t0 in range(0, nt, 64):
+                    xa = a[t0 * (8 << 20):(t0 + 64) * (8 << 20)].view(torch.int32).view(64, 1024, 512, 4)
+                    xb = b[t0 * (8 << 20):(t0 + 64) * (8 << 20)].view(torch.int32).view(64, 512, 1024, 4)
+                    bad += int((xb != xa.transpose(1, 2)).any(dim=-1).sum().item())
+                xcc = ctrs[4200:4200 + 8 * tpx * wpt].cpu().numpy()
+                import numpy as _np
+                mism = int((xcc != (_np.arange(len(xcc)) % 8)).sum())
+                emit(tag="fused_pipe", xcc_mismatch=mism, xcc_first16=[int(v) for v in xcc[:16]], sc1=sc1, teams_per_xcd=tpx, wgs_per_team=wpt, scratch_mib=8 * tpx * 16, ms=round(t * 1e3, 3),
+                     alg_tbps=round(2 * big / t / 1e12, 3), us_per_transform=round(t / nt * 1e6, 3), abort_flag=flag, wrong_units=bad)
+        return
+    if "--sync" in sys.argv:
+        S = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+        ctrs = torch.zeros(8192, dtype=torch.int32, device=dev)
+        b.zero_()
+        for tpx, wpt in ((2, 32), (1, 64), (4, 16), (2, 16), (1, 32)):
+            for lds in (69632,):
+                t = timeit(lambda: L.mb_fused_sync(a.data_ptr(), b.data_ptr(), S.data_ptr(), ctrs.data_ptr(), big, tpx, wpt, lds, st), reps=3, warm=1)
+                torch.cuda.synchronize()
+                flag = int(ctrs[4096].item())
+                emit(tag="fused_sync", teams_per_xcd=tpx, wgs_per_team=wpt, ms=round(t * 1e3, 3), alg_tbps=round(2 * big / t / 1e12, 3),
+                     us_per_transform=round(t / (big / (8 << 20)) * 1e6, 3), abort_flag=flag)
+        # data check of the last run (all transforms): B[u*1024 + row] == A[row*512 + u] in 16-byte units
+        nt = big // (8 << 20)
+        bad = 0
+        for t0 in range(0, nt, 64):
+            xa = a[t0 * (8 << 20):(t0 + 64) * (8 << 20)].view(torch.int32).view(64, 1024, 512, 4)
+            xb = b[t0 * (8 << 20):(t0 + 64) * (8 << 20)].view(torch.int32).view(64, 512, 1024, 4)
+            bad += int((xb != xa.transpose(1, 2)).any(dim=-1).sum().item())
+        emit(tag="fused_sync_check", wrong_units=bad, transforms=nt)
+        return
     if "--xcd" in sys.argv:
         for swz in (0, 1):
             for slab in (64 << 10, 128 << 10, 512 << 10, 2 << 20):
