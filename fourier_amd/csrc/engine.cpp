@@ -116,10 +116,10 @@ struct KernelInfo {
   size_t smem = 0;
 };
 
-template <typename T, int L, int CG, int MODE> static KernelInfo make_info() {
+template <typename T, int L, int CG, int MODE, int IO = IO_PLAIN> static KernelInfo make_info() {
   using C = TileCfg<T, L, CG>;
   KernelInfo k;
-  k.fn = &fft_pass_kernel<T, L, CG, MODE>;
+  k.fn = &fft_pass_kernel<T, L, CG, MODE, IO>;
   k.L = L; k.CG = CG; k.NT = C::NT; k.COLS = C::COLS; k.R3 = C::R3;
   k.smem = C::smem_bytes(MODE);
   return k;
@@ -133,17 +133,21 @@ template <typename T, int L, int CG, int MODE> static KernelInfo make_info() {
 #define FOURIER_CG_1024 8
 #endif
 #ifndef FOURIER_CG_2048
-#define FOURIER_CG_2048 4
+#define FOURIER_CG_2048 8
 #endif
 
-template <typename T> static KernelInfo get_kernel(int L, int mode) {
-#define FK(LL, CGG)                                                         \
-  case LL:                                                                  \
-    switch (mode) {                                                         \
-      case MODE_FIRST: return make_info<T, LL, CGG, MODE_FIRST>();          \
-      case MODE_MID: return make_info<T, LL, CGG, MODE_MID>();              \
-      case MODE_LAST: return make_info<T, LL, CGG, MODE_LAST>();            \
-      default: return make_info<T, LL, CGG, MODE_ROWS>();                   \
+template <typename T> static KernelInfo get_kernel(int L, int mode, int io = IO_PLAIN) {
+#define FK(LL, CGG)                                                                              \
+  case LL:                                                                                       \
+    switch (mode) {                                                                              \
+      case MODE_FIRST:                                                                           \
+        return io == IO_BLU_IN ? make_info<T, LL, CGG, MODE_FIRST, IO_BLU_IN>()                  \
+                               : make_info<T, LL, CGG, MODE_FIRST>();                            \
+      case MODE_MID: return make_info<T, LL, CGG, MODE_MID>();                                   \
+      case MODE_LAST:                                                                            \
+        return io == IO_BLU_OUT ? make_info<T, LL, CGG, MODE_LAST, IO_BLU_OUT>()                 \
+                                : make_info<T, LL, CGG, MODE_LAST>();                            \
+      default: return make_info<T, LL, CGG, MODE_ROWS>();                                        \
     }
 #define FK_ROWS_ONLY(LL, CGG) \
   case LL: return make_info<T, LL, CGG, MODE_ROWS>();
@@ -213,6 +217,8 @@ template <typename T> class Pow2Engine {
   struct Pass {
     int mode;
     KernelInfo k;
+    KernelInfo k_blu;  // IO_BLU_IN variant of a FIRST pass / IO_BLU_OUT variant of a LAST pass (lazy)
+    bool has_blu = false;
     uint64_t s, size, cn;
     uint32_t lo_bits = 0;
     DevBuf tw_lo, tw_hi;
@@ -274,6 +280,22 @@ template <typename T> class Pow2Engine {
     }
   }
 
+  // Bluestein fusion is available when the plan has separate first and last passes.
+  bool can_fuse_bluestein() const { return !tiny_ && passes_.size() >= 2; }
+  void enable_bluestein_fusion() {
+    if (!can_fuse_bluestein()) return;
+    Pass& f = *passes_.front();
+    Pass& l = *passes_.back();
+    f.k_blu = get_kernel<T>(f.k.L, MODE_FIRST, IO_BLU_IN);
+    l.k_blu = get_kernel<T>(l.k.L, MODE_LAST, IO_BLU_OUT);
+    f.has_blu = l.has_blu = true;
+#ifndef FOURIER_EMU
+    for (Pass* p : {&f, &l})
+      if (p->k_blu.smem > 48 * 1024)
+        HIP_CHECK(hipFuncSetAttribute((const void*)p->k_blu.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->k_blu.smem));
+#endif
+  }
+
   size_t size() const { return n_; }
   size_t num_passes() const { return tiny_ ? 1 : passes_.size(); }
   bool needs_scratch(bool in_place) const { return passes_.size() == 3 || (passes_.size() == 2 && in_place); }
@@ -286,8 +308,18 @@ template <typename T> class Pow2Engine {
 
   // Transform `batch` contiguous transforms.  in == out is allowed; scratch must hold batch*n
   // elements when needs_scratch(in == out) (or when force_scratch is set).
+  // Optional Bluestein fusion: io == IO_BLU_IN: `in` is the USER array (batch stride blu_n); io == IO_BLU_OUT:
+  // `out` is the USER array.  The other side and the scratch are plan-sized (batch stride n).
+  struct BluIO {
+    int io = IO_PLAIN;
+    const void* xtab = nullptr;
+    uint64_t n = 0;
+    int swap = 0;
+  };
+
   void run(const cpx<T>* in, cpx<T>* out, cpx<T>* scratch, size_t batch, bool inverse, double scale, const cpx<T>* mul,
-           bool force_scratch, hipStream_t stream, Profiler* prof = nullptr, int slot0 = 0, unsigned nxcd = 8) const {
+           bool force_scratch, hipStream_t stream, Profiler* prof = nullptr, int slot0 = 0, unsigned nxcd = 8,
+           BluIO blu = BluIO()) const {
     if (batch == 0) return;
     if (tiny_) {
       TinyArgs a{in, out, mul, (uint64_t)batch, (int)n_, inverse, inverse, scale};
@@ -301,10 +333,12 @@ template <typename T> class Pow2Engine {
     const cpx<T>* src[3] = {in, nullptr, nullptr};
     cpx<T>* dst[3] = {out, nullptr, nullptr};
     if (np == 2) {
-      cpx<T>* X = (in_place || force_scratch) ? scratch : out;
+      cpx<T>* X = (in_place || force_scratch || blu.io == IO_BLU_OUT) ? scratch : out;
       dst[0] = X; src[1] = X; dst[1] = out;
     } else if (np == 3) {
-      if (in_place) { dst[0] = scratch; src[1] = scratch; dst[1] = out; src[2] = out; dst[2] = out; }
+      if (blu.io == IO_BLU_OUT) {  // the user-side output is shorter than n: never use it as an intermediate
+        dst[0] = scratch; src[1] = scratch; dst[1] = (cpx<T>*)in; src[2] = in; dst[2] = out;
+      } else if (in_place) { dst[0] = scratch; src[1] = scratch; dst[1] = out; src[2] = out; dst[2] = out; }
       else { dst[0] = out; src[1] = out; dst[1] = scratch; src[2] = scratch; dst[2] = out; }
     }
     for (size_t p = 0; p < np; ++p) {
@@ -318,6 +352,9 @@ template <typename T> class Pow2Engine {
       a.n = n_; a.cn = ps.cn; a.s = ps.s;
       a.lo_bits = ps.lo_bits;
       a.nxcd = nxcd;
+      const bool blu_here = ps.has_blu && ((blu.io == IO_BLU_IN && p == 0) || (blu.io == IO_BLU_OUT && p + 1 == np));
+      if (blu_here) { a.blu_x = blu.xtab; a.blu_n = blu.n; a.blu_swap = blu.swap; }
+      const KernelInfo& kk = blu_here ? ps.k_blu : ps.k;
       a.swap_in = (p == 0) && inverse;
       a.swap_out = (p + 1 == np) && inverse;
       a.scale = (p + 1 == np) ? scale : 1.0;
@@ -332,7 +369,7 @@ template <typename T> class Pow2Engine {
       }
       if (grid > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");
       PROF_BEGIN(prof, slot0 + (int)p);
-      FOURIER_LAUNCH(ps.k.fn, grid, ps.k.NT, ps.k.smem, stream, a);
+      FOURIER_LAUNCH(kk.fn, grid, kk.NT, kk.smem, stream, a);
       PROF_END(prof);
     }
   }
@@ -405,13 +442,15 @@ template <typename T> class Plan {
       for (size_t p = 0; p < eng_->num_passes(); ++p) d += std::string(d.empty() ? "" : ",") + tag + std::to_string(p);
     };
     if (!blu_) { passes("pass"); return d; }
-    d = "blu_pre"; passes("fwd_pass"); passes("inv_pass"); d += ",blu_post";
+    d = "blu_pre"; passes("fwd_pass"); passes("inv_pass"); d += ",blu_post";  // blu_pre/post stay empty when fused
     return d;
   }
 
   double model_bytes() const {
     if (!blu_) return 2.0 * n_ * ELEM * eng_->num_passes();
-    // pre (n read + table + m write) + 2 inner FFTs + w table + post (m.. n read, table, n write)
+    // unfused: pre (n + table read, m write) + 2 inner FFTs + w table + post (n + table read, n write);
+    // fused: the first / last inner pass read / write the n-point user array instead of an m-point sweep
+    if (fused_) return (double)ELEM * (2.0 * 2.0 * m_ * eng_->num_passes() - 2.0 * (m_ - n_) + m_ + 2.0 * n_);
     return (double)ELEM * ((2.0 * n_ + m_) + 2.0 * 2.0 * m_ * eng_->num_passes() + m_ + 3.0 * n_);
   }
 
@@ -419,6 +458,7 @@ template <typename T> class Plan {
     if (key == "chunk_bytes" && v >= 0) { chunk_bytes_ = (size_t)v; return 0; }
     if (key == "scratch" && (v == 0 || v == 1)) { force_scratch_ = (v == 1); return 0; }
     if (key == "xcd_swizzle" && (v == 0 || v == 1)) { nxcd_ = v ? 8 : 1; return 0; }
+    if (key == "bluestein_fusion" && (v == 0 || v == 1)) { fused_ = (v == 1) && blu_ && eng_->can_fuse_bluestein(); return 0; }
     return ::fourier::c::FOURIER_HIP_INVALID_ARGUMENT;
   }
 
@@ -454,12 +494,23 @@ template <typename T> class Plan {
     }
     // Bluestein (bluesteins.rs:215-259): work = x.in (zero padded) ; FFT_M ; .w ; IFFT_M ; out = work.x.scale
     work_.ensure(chunk * m_ * ELEM);
-    if (eng_->needs_scratch(true)) scratch_.ensure(chunk * m_ * ELEM);
+    if (eng_->needs_scratch(true) || fused_) scratch_.ensure(chunk * m_ * ELEM);
     cpx<T>* work = (cpx<T>*)work_.p;
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
       const size_t nb = std::min(chunk, batch - b0);
       BluArgs pre{in + b0 * n_, work, xtab_.p, (uint64_t)n_, (uint64_t)m_, (uint64_t)nb, inverse, 1.0};
       const int np = (int)eng_->num_passes();
+      if (fused_) {
+        // chirp multiply + zero pad fused into the forward inner FFT's first pass, chirp * scale fused into
+        // the inverse inner FFT's last pass: no separate sweeps over the M-point work array
+        typename Pow2Engine<T>::BluIO bin, bout;
+        bin.io = IO_BLU_IN; bin.xtab = xtab_.p; bin.n = n_; bin.swap = inverse;
+        bout.io = IO_BLU_OUT; bout.xtab = xtab_.p; bout.n = n_; bout.swap = inverse;
+        eng_->run(in + b0 * n_, work, (cpx<T>*)scratch_.p, nb, false, 1.0, (const cpx<T>*)wtab_.p, false, stream, prof, 1,
+                  nxcd_, bin);
+        eng_->run(work, out + b0 * n_, (cpx<T>*)scratch_.p, nb, true, scale, nullptr, false, stream, prof, 1 + np, nxcd_, bout);
+        continue;
+      }
       PROF_BEGIN(prof, 0);
       FOURIER_LAUNCH(&blu_pre_kernel<T>, elementwise_grid(nb * m_), 256, 0, stream, pre);
       PROF_END(prof);
@@ -505,6 +556,8 @@ template <typename T> class Plan {
     m_ = 1;
     while (m_ < 2 * n_ - 1) m_ <<= 1;  // bluesteins.rs:110
     eng_.reset(new Pow2Engine<T>(m_));
+    eng_->enable_bluestein_fusion();
+    fused_ = eng_->can_fuse_bluestein();
     // chirp exp(-i*pi*k^2/n), angle reduced exactly with k^2 mod 2n (the reference leaves it
     // unreduced, bluesteins.rs:10,31,57; the reduction only removes f64 argument error)
     std::vector<double> cr(n_), ci(n_);
@@ -539,6 +592,7 @@ template <typename T> class Plan {
   mutable DevBuf scratch_, work_, hostio_;
   size_t chunk_bytes_ = 0;
   bool force_scratch_ = false;
+  bool fused_ = false;  // Bluestein: chirp steps fused into the inner passes
   unsigned nxcd_ = 8;
   mutable int status_ = 0;
   std::string desc_;

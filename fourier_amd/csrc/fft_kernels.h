@@ -41,6 +41,10 @@ template <typename T> struct alignas(16) Unit16 { T a[16 / sizeof(T)]; };  // VE
 template <typename T> struct alignas(8) Unit8 { T a[8 / sizeof(T)]; };     // one plane of VEC columns
 
 enum { MODE_FIRST = 0, MODE_MID = 1, MODE_LAST = 2, MODE_ROWS = 3 };
+// Bluestein fusion (bluesteins.rs:229-258): IO_BLU_IN = the first pass of the forward inner FFT reads the
+// USER array (length blu_n, zero padded to n) times the chirp x; IO_BLU_OUT = the last pass of the inverse
+// inner FFT writes the first blu_n points times the chirp (and the user scaling) into the USER array.
+enum { IO_PLAIN = 0, IO_BLU_IN = 1, IO_BLU_OUT = 2 };
 
 // Build-time knobs (tools/build_variants.py A/B-tests them on the GPU):
 //   FOURIER_NT_LOAD  = 1 (default): first-pass input loads are non-temporal (streamed once)
@@ -99,6 +103,9 @@ struct PassArgs {
   uint64_t total_cols;  // ROWS mode: number of transforms in this launch
   uint32_t lo_bits;
   uint32_t nxcd;      // >1: remap blockIdx so that each XCD (blockIdx % nxcd) walks a contiguous tile range
+  const void* blu_x;  // Bluestein chirp table x[0..blu_n) (IO_BLU_IN / IO_BLU_OUT)
+  uint64_t blu_n;     // user transform length (batch stride of the user-side buffer)
+  int blu_swap;       // user-level inverse: swap re/im of the user data
   int swap_in, swap_out;
   double scale;       // applied on the final store (LAST / ROWS)
 };
@@ -280,8 +287,10 @@ __device__ __forceinline__ cpx<T> two_level_twiddle(const PassArgs& a, uint64_t 
 //   MODE_MID  : s >= COLS. column-tile load/store, twiddle W_size^{i*k} with i uniform per tile.
 //   MODE_LAST : size == L. column-tile load/store, no twiddle; mul / swap_out / scale on store.
 //   MODE_ROWS : whole transforms of length L, contiguous rows; mul / swap_out / scale on store.
-template <typename T, int L, int CG, int MODE>
+template <typename T, int L, int CG, int MODE, int IO = IO_PLAIN>
 __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG)) fft_pass_kernel(PassArgs a) {
+  static_assert(IO == IO_PLAIN || (IO == IO_BLU_IN && MODE == MODE_FIRST) || (IO == IO_BLU_OUT && MODE == MODE_LAST),
+                "Bluestein fusion: chirp-in on the first pass, chirp-out on the last pass");
   using C = TileCfg<T, L, CG>;
   constexpr int VEC = C::VEC, Q = C::Q, R2 = C::R2, R3 = C::R3, COLS = C::COLS;
   constexpr bool IN_ROWS = (MODE == MODE_ROWS);
@@ -339,6 +348,25 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
       const cpx<T>* p = in + g * L + th;
 #pragma unroll
       for (int r = 0; r < 16; ++r) x[v][r] = valid ? p[Q * r] : cpx<T>{0, 0};
+    }
+  } else if constexpr (IO == IO_BLU_IN) {
+    // work = x (.) in, zero padded (bluesteins.rs:229-234); the user array is only 8-byte aligned
+    const cpx<T>* xt = (const cpx<T>*)a.blu_x;
+    const cpx<T>* p = in + b * a.blu_n;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const uint64_t idx0 = (uint64_t)(th + Q * r) * a.cn + c0 + (uint64_t)(cg * VEC);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const uint64_t idx = idx0 + v;
+        cpx<T> val{0, 0};
+        if (idx < a.blu_n) {
+          val = p[idx];
+          if (a.blu_swap) val = {val.im, val.re};
+          val = cmul(xt[idx], val);
+        }
+        x[v][r] = val;
+      }
     }
   } else {
     const cpx<T>* p = in + b * a.n + (uint64_t)th * a.cn + c0 + (uint64_t)(cg * VEC);
@@ -470,6 +498,26 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
           y = {y.re * scale, y.im * scale};
         }
         p[Q * r] = y;
+      }
+    }
+  } else if constexpr (IO == IO_BLU_OUT) {
+    // out = work (.) x (.) scale, first blu_n points only (bluesteins.rs:240-258)
+    const cpx<T>* xt = (const cpx<T>*)a.blu_x;
+    const uint64_t i = c0 / a.s, j0 = c0 % a.s;
+    const uint64_t off = j0 + (uint64_t)(cg * VEC) + a.s * ((uint64_t)L * i + (uint64_t)th);
+    cpx<T>* p = out + b * a.blu_n;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const uint64_t idx = off + a.s * (uint64_t)(Q * r) + v;
+        if (idx < a.blu_n) {
+          cpx<T> y = x[v][r];
+          if (a.swap_out) y = {y.im, y.re};
+          y = cmul(y, xt[idx]);
+          if (a.blu_swap) y = {y.im, y.re};
+          p[idx] = {y.re * scale, y.im * scale};
+        }
       }
     }
   } else {

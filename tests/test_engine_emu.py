@@ -123,6 +123,19 @@ def test_bluestein_and_mixed_radix_sizes(fa, oracle, n):
             assert rel_l2(run_batch(plan, x.astype(dtype), code, inplace=True), ref) <= tl2, (n, code)
 
 
+def test_bluestein_fusion_matches_unfused(fa):
+    """The chirp steps fused into the inner passes (M >= 4096) give the same values as the separate
+    blu_pre / blu_post sweeps (bluesteins.rs:229-258), for every transform code, in and out of place."""
+    for n in (1025, 3000):
+        x = np.stack([hash_normal(70 + b, n) for b in range(2)]).astype(np.complex64)
+        fused, plain = make(fa, n, np.complex64), make(fa, n, np.complex64)
+        plain.set_option("bluestein_fusion", 0)
+        for code in range(5):
+            a, b = run_batch(fused, x, code), run_batch(plain, x, code)
+            assert np.array_equal(a, b), (n, code)
+            assert np.array_equal(run_batch(fused, x, code, inplace=True), a), (n, code)
+
+
 def test_three_pass_plan(fa):
     # 2^23 = 256 x 256 x 128: exercises the middle (uniform-twiddle) pass
     n = 1 << 23

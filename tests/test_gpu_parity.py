@@ -156,6 +156,17 @@ def test_baseline_sizes_vs_oracle_and_golden(torch, fa, oracle, n, dtype, tl2, t
         assert rel_l2(gi, ri) <= tl2, (n, code)
 
 
+def test_bluestein_fusion_matches_unfused(torch, fa):
+    for n in (1025, 999983):
+        x = np.stack([hash_uniform(70 + b, n) for b in range(2)]).astype(np.complex64)
+        fused, plain = make(fa, n, np.complex64), make(fa, n, np.complex64)
+        plain.set_option("bluestein_fusion", 0)
+        for code in (0, 1, 4):
+            a, b = gpu_batch(torch, fa, fused, x, code), gpu_batch(torch, fa, plain, x, code)
+            assert rel_l2(a, b) <= 1e-7, (n, code, rel_l2(a, b))
+            assert np.array_equal(gpu_batch(torch, fa, fused, x, code, inplace=True), a), (n, code)
+
+
 def test_three_pass_size(torch, fa):
     n = 1 << 23
     plan = make(fa, n, np.complex64)
@@ -251,6 +262,25 @@ def test_runs_on_a_side_stream(torch, fa, oracle):
         plan.transform(d, o, fa.Transform.Fft)
     s.synchronize()
     assert rel_l2(o.cpu().numpy(), oracle.transform_batch(x, 0)) <= 1e-6
+
+
+@pytest.mark.parametrize("src,cc,std", [("consumer.c", "gcc", "-std=c11"), ("consumer.cpp", "g++", "-std=c++14")])
+def test_c_and_cxx_consumers_relink_unchanged(fa, tmp_path, src, cc, std):
+    """existing C / C++ users of fourier.h build against include/fourier.h with
+    -Wall -Wextra -pedantic -Werror (fourier-ffi/CMakeLists.txt:12) and link libfourier.so."""
+    import subprocess
+
+    from fourier_amd import _lib
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "consumer")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call([cc, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c", src), "-o", exe, "-L", libdir, "-l:libfourier.so",
+                           "-lm", f"-Wl,-rpath,{libdir}"])
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0 and "Tests ran successfully." in out.stdout, out.stderr[-2000:]
 
 
 def test_error_behaviour(torch, fa):

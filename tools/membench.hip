@@ -318,6 +318,27 @@ extern "C" int mb_fused_sync(const void* A, void* B, void* S, void* ctrs, uint64
   return (int)hipGetLastError();
 }
 
+// column-tile copy with independent source / destination row strides (in 16-B units): does an 8 KiB row
+// stride (N=2^20: 1024 complex64 per row) cost DRAM bank/channel conflicts that a padded stride avoids?
+__global__ void __launch_bounds__(512) k_tile_s(const v4u* __restrict__ src, v4u* __restrict__ dst, uint64_t src_ru, uint64_t dst_ru,
+                                                int swz) {
+  const int tid = threadIdx.x, cg = tid & 7, th = tid >> 3;
+  uint64_t blk = blockIdx.x;
+  if (swz) { const uint64_t cpx = gridDim.x / 8; blk = (blk % 8) * cpx + blk / 8; }
+  const uint64_t b = blk / 64, t = blk % 64;   // 64 tiles of 8 units per transform, 1024 rows
+  const v4u* s = src + b * 1024 * src_ru + t * 8 + cg;
+  v4u v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = s[(uint64_t)(th + 64 * r) * src_ru];
+  v4u* d = dst + b * 1024 * dst_ru + t * 8 + cg;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) d[(uint64_t)(th + 64 * r) * dst_ru] = v[r];
+}
+extern "C" int mb_tile_s(const void* src, void* dst, uint64_t transforms, uint64_t src_ru, uint64_t dst_ru, int swz, void* stream) {
+  k_tile_s<<<(unsigned)(transforms * 64), 512, 0, (hipStream_t)stream>>>((const v4u*)src, (v4u*)dst, src_ru, dst_ru, swz);
+  return (int)hipGetLastError();
+}
+
 extern "C" int mb_fused_model(const void* A, void* B, void* S, uint64_t bytes, uint64_t ring_bytes, int mode, int blocks, void* stream) {
   k_fused_model<<<blocks, 512, 0, (hipStream_t)stream>>>((const v4u*)A, (v4u*)B, (v4u*)S, bytes / (128 << 10), ring_bytes / (128 << 10), mode);
   return (int)hipGetLastError();

@@ -58,6 +58,13 @@ def main():
     L.mb_tile_x.argtypes = [vp, vp, u64, ci, vp]
     L.mb_fused_sync.argtypes = [vp, vp, vp, vp, u64, ci, ci, ci, vp]
     L.mb_fused_pipe.argtypes = [vp, vp, vp, vp, u64, ci, ci, ci, ci, vp]
+    L.mb_tile_s.argtypes = [vp, vp, u64, u64, u64, ci, vp]
+    if "--stride" in sys.argv:
+        nt = 1024  # transforms of 8 MiB payload
+        for sru, dru in ((512, 512), (520, 512), (512, 520), (520, 520), (528, 528), (576, 576), (1024, 1024), (1032, 1032), (2048, 2048), (640, 640)):
+            t = timeit(lambda: L.mb_tile_s(a.data_ptr(), b.data_ptr(), nt, sru, dru, 1, st))
+            emit(tag="tile_stride", src_row_bytes=sru * 16, dst_row_bytes=dru * 16, ms=round(t * 1e3, 3), payload_tbps=round(2 * nt * (8 << 20) / t / 1e12, 3))
+        return
     if "--pipe" in sys.argv:
         S = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
         ctrs = torch.zeros(8192, dtype=torch.int32, device=dev)
