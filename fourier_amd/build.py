@@ -19,10 +19,19 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x",
 def build(force=False, extra=()):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
+        link_soname()
         return OUT
     cmd = [HIPCC] + FLAGS + list(extra) + [SRC, "-o", OUT]
     subprocess.check_call(cmd)
+    link_soname()
     return OUT
+
+
+def link_soname():
+    """libfourier.so.0 -> libfourier.so, the name consumers' DT_NEEDED carries (fourier-ffi/CMakeLists.txt:55)."""
+    so0 = OUT + ".0"
+    if not os.path.lexists(so0):
+        os.symlink(os.path.basename(OUT), so0)
 
 
 if __name__ == "__main__":
