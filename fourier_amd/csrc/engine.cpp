@@ -382,6 +382,90 @@ template <typename T> class Pow2Engine {
 };
 
 // ---------------------------------------------------------------------------------------------
+// small mixed-radix sizes (2^a * 3^b, b > 0, N <= 4096): the reference's own schedule and tables
+template <typename T> class MixedEngine {
+ public:
+  static constexpr size_t MAX_N = 4096;
+  // autosort/mod.rs:104-116: one radix-4 first when divisible, then greedily 8, 4, 3, 2
+  static bool factor(size_t size, uint32_t counts[5]) {
+    static const size_t radices[5] = {4, 8, 4, 3, 2};
+    size_t cur = size;
+    for (int r = 0; r < 5; ++r) counts[r] = 0;
+    if (cur == 0) return false;
+    if (cur % 4 == 0) { cur /= 4; counts[0] = 1; }
+    for (int r = 1; r < 5; ++r)
+      while (cur % radices[r] == 0) { cur /= radices[r]; counts[r] += 1; }
+    return cur == 1;
+  }
+  static bool handles(size_t n) {
+    uint32_t c[5];
+    return n <= MAX_N && !is_pow2(n) && factor(n, c);
+  }
+  // twiddle.rs:7-19 verbatim: theta = (index*2) as f64 * PI / size as f64; (cos, -sin) cast to T.
+  // cos and sin stay two separate libm calls, as in Rust (a merged sincos() differs in the last bit).
+  __attribute__((noinline)) static double libm_cos(double t) { return std::cos(t); }
+  __attribute__((noinline)) static double libm_sin(double t) { return std::sin(t); }
+  static cpx<T> ref_twiddle(size_t index, size_t size) {
+    const double theta = (double)(index * 2) * M_PI / (double)size;
+    return {(T)libm_cos(theta), (T)(-libm_sin(theta))};
+  }
+
+  explicit MixedEngine(size_t n) : n_(n) {
+    factor(n, counts_);
+    static const size_t radices[5] = {4, 8, 4, 3, 2};
+    std::vector<cpx<T>> tw;
+    size_t cur = n;
+    for (int r = 0; r < 5; ++r)
+      for (uint32_t c = 0; c < counts_[r]; ++c) {  // mod.rs:24-46
+        const size_t R = radices[r], m = cur / R;
+        for (size_t i = 0; i < m; ++i) {
+          tw.push_back({(T)1, (T)0});
+          for (size_t j = 1; j < R; ++j) tw.push_back(ref_twiddle(i * j, cur));
+        }
+        cur /= R;
+      }
+    if (tw.empty()) tw.push_back({(T)1, (T)0});
+    tw_.upload(tw);
+    group_ = (uint32_t)std::max<size_t>(1, 1024 / n);
+    smem_ = 2 * (size_t)group_ * n * sizeof(cpx<T>);
+#ifndef FOURIER_EMU
+    if (smem_ > 48 * 1024)
+      HIP_CHECK(hipFuncSetAttribute((const void*)&mixed_radix_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_));
+#endif
+  }
+  std::string describe() const {
+    static const int radices[5] = {4, 8, 4, 3, 2};
+    std::string d;
+    for (int r = 0; r < 5; ++r)
+      for (uint32_t c = 0; c < counts_[r]; ++c) d += (d.empty() ? "" : ".") + std::to_string(radices[r]);
+    return d;
+  }
+  void run(const cpx<T>* in, cpx<T>* out, size_t batch, bool forward, bool scaled, double scale, hipStream_t stream,
+           Profiler* prof) const {
+    if (batch == 0) return;
+    MixArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.in = in; a.out = out; a.tw = tw_.p; a.batch = batch; a.n = (uint32_t)n_; a.group = group_;
+    for (int r = 0; r < 5; ++r) a.counts[r] = counts_[r];
+    a.forward = forward; a.scaled = scaled; a.scale = scale;
+    const cpx<T> w3 = ref_twiddle(1, 3), w8 = ref_twiddle(1, 8);  // butterfly.rs:12,50
+    a.w3re = w3.re; a.w3im = w3.im; a.w8re = w8.re; a.w8im = w8.im;
+    const uint64_t grid = (batch + group_ - 1) / group_;
+    if (grid > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");
+    PROF_BEGIN(prof, 0);
+    FOURIER_LAUNCH(&mixed_radix_kernel<T>, grid, 256, smem_, stream, a);
+    PROF_END(prof);
+  }
+
+ private:
+  size_t n_;
+  uint32_t counts_[5];
+  uint32_t group_ = 1;
+  size_t smem_ = 0;
+  DevBuf tw_;
+};
+
+// ---------------------------------------------------------------------------------------------
 // host f64 radix-2 FFT, used only at plan time for the Bluestein w table (bluesteins.rs:46-47)
 static void host_fft(std::vector<double>& re, std::vector<double>& im) {
   const size_t m = re.size();
@@ -423,6 +507,9 @@ template <typename T> class Plan {
     if (is_pow2(n)) {
       eng_.reset(new Pow2Engine<T>(n));
       desc_ = "stockham " + eng_->describe();
+    } else if (MixedEngine<T>::handles(n)) {
+      mix_.reset(new MixedEngine<T>(n));
+      desc_ = "stockham mixed-radix " + mix_->describe();
     } else {
       init_bluestein();
       desc_ = "bluestein M=" + std::to_string(m_) + " inner " + eng_->describe();
@@ -438,6 +525,7 @@ template <typename T> class Plan {
   // kernel "slots" in launch order, as reported by profile(): names for bench.py / rocprof matching
   std::string slot_names() const {
     std::string d;
+    if (mix_) return "mixed_radix";
     auto passes = [&](const char* tag) {
       for (size_t p = 0; p < eng_->num_passes(); ++p) d += std::string(d.empty() ? "" : ",") + tag + std::to_string(p);
     };
@@ -447,6 +535,7 @@ template <typename T> class Plan {
   }
 
   double model_bytes() const {
+    if (mix_) return 2.0 * n_ * ELEM;
     if (!blu_) return 2.0 * n_ * ELEM * eng_->num_passes();
     // unfused: pre (n + table read, m write) + 2 inner FFTs + w table + post (n + table read, n write);
     // fused: the first / last inner pass read / write the n-point user array instead of an m-point sweep
@@ -477,6 +566,13 @@ template <typename T> class Plan {
     const cpx<T>* in = (const cpx<T>*)d_in;
     cpx<T>* out = (cpx<T>*)d_out;
     const bool in_place = (d_in == d_out);
+    if (mix_) {  // every pass stays in LDS: one launch, in place allowed (a workgroup reads its transforms first)
+      const bool scaled = code == ::fourier::c::FOURIER_TRANSFORM_IFFT || code == ::fourier::c::FOURIER_TRANSFORM_SQRT_SCALED_FFT ||
+                          code == ::fourier::c::FOURIER_TRANSFORM_SQRT_SCALED_IFFT;  // mod.rs:381-385
+      mix_->run(in, out, batch, !inverse, scaled,
+                scale, stream, prof);
+      return;
+    }
     const size_t per = (blu_ ? m_ : n_) * ELEM;
     size_t chunk = batch;
     if (chunk_bytes_) chunk = std::max<size_t>(1, std::min<size_t>(batch, chunk_bytes_ / per));
@@ -588,6 +684,7 @@ template <typename T> class Plan {
   int device_ = 0;
   bool blu_ = false;
   std::unique_ptr<Pow2Engine<T>> eng_;
+  std::unique_ptr<MixedEngine<T>> mix_;
   DevBuf xtab_, wtab_;
   mutable DevBuf scratch_, work_, hostio_;
   size_t chunk_bytes_ = 0;

@@ -573,6 +573,145 @@ __global__ void __launch_bounds__(256) tiny_dft_kernel(TinyArgs a) {
   }
 }
 
+// ---- native Stockham autosort for small mixed-radix sizes N = 2^a * 3^b (b > 0), N <= 4096 ----
+// This kernel is the reference's algorithm verbatim, one workgroup per group of transforms, all passes in
+// LDS: radix schedule [4,8,4,3,2] (autosort/mod.rs:20-21,104-116), per-pass twiddle table
+// [1, W^i, .., W^{(R-1)i}] (mod.rs:24-46), pass body out[j + R*s*i + s*k] = tw[i*R+k] * butterflyR(in[j + s*i + s*m*k'])_k
+// (mod.rs:203-284), butterflies in the reference's operation order (autosort/butterfly.rs:3-65,
+// vector/generic.rs:22-44) with FMA contraction off (Rust never fuses), then the scale pass (mod.rs:381-399).
+// Same tables, same order, same roundings: results are bit-identical to the CPU restatement.
+struct MixArgs {
+  const void* in; void* out; const void* tw;  // tw: forward table, Sum(size_cur) entries
+  uint64_t batch;
+  uint32_t n, group;      // transform length, transforms per workgroup
+  uint32_t counts[5];     // passes per radix of {4, 8, 4, 3, 2}
+  int forward, scaled;
+  double scale, w3re, w3im, w8re, w8im;  // compute_twiddle(1,3,true), compute_twiddle(1,8,true) as T values
+};
+
+#ifndef FOURIER_EMU
+#define FOURIER_NO_CONTRACT _Pragma("clang fp contract(off)")
+#else
+#define FOURIER_NO_CONTRACT
+#endif
+
+template <typename T> __device__ __forceinline__ cpx<T> ref_mul(cpx<T> a, cpx<T> b) {
+  FOURIER_NO_CONTRACT
+  const T rr = a.re * b.re, ii = a.im * b.im, ri = a.re * b.im, ir = a.im * b.re;
+  return {rr - ii, ri + ir};
+}
+template <typename T> __device__ __forceinline__ cpx<T> ref_add(cpx<T> a, cpx<T> b) { return {a.re + b.re, a.im + b.im}; }
+template <typename T> __device__ __forceinline__ cpx<T> ref_sub(cpx<T> a, cpx<T> b) { return {a.re - b.re, a.im - b.im}; }
+// generic.rs:34-44
+template <typename T> __device__ __forceinline__ cpx<T> ref_rotate(cpx<T> z, bool positive) {
+  return positive ? cpx<T>{-z.im, z.re} : cpx<T>{z.im, -z.re};
+}
+template <typename T> __device__ __forceinline__ void ref_bf2(cpx<T>& a, cpx<T>& b) {  // butterfly.rs:3-5
+  const cpx<T> s = ref_add(a, b), d = ref_sub(a, b);
+  a = s; b = d;
+}
+template <typename T> __device__ __forceinline__ void ref_bf4(cpx<T>* x, bool fwd) {  // butterfly.rs:26-43
+  cpx<T> a0 = x[0], a1 = x[2], a2 = x[1], a3 = x[3];
+  ref_bf2(a0, a1);  // a[0], a[1]
+  ref_bf2(a2, a3);  // a[2], a[3]
+  a3 = ref_rotate(a3, fwd);
+  ref_bf2(a0, a2);  // b[0], b[1]
+  ref_bf2(a1, a3);  // b[2], b[3]
+  x[0] = a0; x[1] = a3; x[2] = a2; x[3] = a1;  // [b0, b3, b1, b2]
+}
+template <typename T> __device__ __forceinline__ void ref_bf3(cpx<T>* x, cpx<T> t) {  // butterfly.rs:9-22
+  const cpx<T> tc{t.re, -t.im};
+  const cpx<T> y0 = ref_add(x[0], ref_add(x[1], x[2]));
+  const cpx<T> y1 = ref_add(x[0], ref_add(ref_mul(x[1], t), ref_mul(x[2], tc)));
+  const cpx<T> y2 = ref_add(x[0], ref_add(ref_mul(x[1], tc), ref_mul(x[2], t)));
+  x[0] = y0; x[1] = y1; x[2] = y2;
+}
+template <typename T> __device__ __forceinline__ void ref_bf8(cpx<T>* x, bool fwd, cpx<T> t) {  // butterfly.rs:47-65
+  const cpx<T> tneg{-t.re, t.im};
+  cpx<T> a1[4] = {x[0], x[2], x[4], x[6]};
+  cpx<T> b1[4] = {x[1], x[3], x[5], x[7]};
+  ref_bf4(a1, fwd);
+  ref_bf4(b1, fwd);
+  b1[1] = ref_mul(b1[1], t);
+  b1[2] = ref_rotate(b1[2], !fwd);
+  b1[3] = ref_mul(b1[3], tneg);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ref_bf2(a1[k], b1[k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { x[k] = a1[k]; x[4 + k] = b1[k]; }
+}
+
+template <typename T, int R>
+__device__ __forceinline__ void mixed_pass(const cpx<T>* __restrict__ src, cpx<T>* __restrict__ dst, const cpx<T>* __restrict__ tw,
+                                           uint32_t n, uint32_t nb, uint32_t size, uint32_t stride, bool fwd, cpx<T> w3,
+                                           cpx<T> w8) {
+  const uint32_t m = size / R, nbf = n / R;
+  for (uint32_t q = threadIdx.x; q < nb * nbf; q += blockDim.x) {
+    const uint32_t g = q / nbf, e = q - g * nbf, i = e / stride, j = e - i * stride;
+    const cpx<T>* in = src + g * n + j + stride * i;
+    cpx<T> x[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) x[k] = in[stride * m * k];
+    if constexpr (R == 2) ref_bf2(x[0], x[1]);
+    else if constexpr (R == 3) ref_bf3(x, w3);
+    else if constexpr (R == 4) ref_bf4(x, fwd);
+    else ref_bf8(x, fwd, w8);
+    if (size != (uint32_t)R) {  // mod.rs:238,272
+#pragma unroll
+      for (int k = 1; k < R; ++k) {
+        cpx<T> w = tw[i * R + k];
+        if (!fwd) w.im = -w.im;  // inverse table = conj (twiddle.rs:14-18)
+        x[k] = ref_mul(x[k], w);
+      }
+    }
+    cpx<T>* out = dst + g * n + j + R * stride * i;
+#pragma unroll
+    for (int k = 0; k < R; ++k) out[stride * k] = x[k];
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) mixed_radix_kernel(MixArgs a) {
+  FOURIER_DYN_SMEM(smem);
+  cpx<T>* buf0 = (cpx<T>*)smem;
+  cpx<T>* buf1 = buf0 + (size_t)a.group * a.n;
+  const uint64_t b0 = (uint64_t)blockIdx.x * a.group;
+  const uint32_t nb = (uint32_t)((a.batch - b0) < a.group ? (a.batch - b0) : a.group);
+  const uint32_t total = nb * a.n;
+  const cpx<T>* in = (const cpx<T>*)a.in + b0 * a.n;
+  cpx<T>* out = (cpx<T>*)a.out + b0 * a.n;
+  for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) buf0[idx] = in[idx];
+  __syncthreads();
+  const bool fwd = a.forward != 0;
+  cpx<T> w3{(T)a.w3re, (T)a.w3im}, w8{(T)a.w8re, (T)a.w8im};
+  if (!fwd) { w3.im = -w3.im; w8.im = -w8.im; }
+  const cpx<T>* tw = (const cpx<T>*)a.tw;
+  cpx<T>* src = buf0;
+  cpx<T>* dst = buf1;
+  uint32_t size = a.n, stride = 1;
+  const uint32_t radices[5] = {4, 8, 4, 3, 2};
+  for (int ri = 0; ri < 5; ++ri) {
+    for (uint32_t c = 0; c < a.counts[ri]; ++c) {
+      const uint32_t R = radices[ri];
+      if (R == 8) mixed_pass<T, 8>(src, dst, tw, a.n, nb, size, stride, fwd, w3, w8);
+      else if (R == 4) mixed_pass<T, 4>(src, dst, tw, a.n, nb, size, stride, fwd, w3, w8);
+      else if (R == 3) mixed_pass<T, 3>(src, dst, tw, a.n, nb, size, stride, fwd, w3, w8);
+      else mixed_pass<T, 2>(src, dst, tw, a.n, nb, size, stride, fwd, w3, w8);
+      __syncthreads();
+      tw += size;  // each pass consumes `size` entries (mod.rs:357,377)
+      size /= R;
+      stride *= R;
+      cpx<T>* t = src; src = dst; dst = t;
+    }
+  }
+  const T scale = (T)a.scale;
+  for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
+    cpx<T> y = src[idx];
+    if (a.scaled) y = {y.re * scale, y.im * scale};  // mod.rs:387-393
+    out[idx] = y;
+  }
+}
+
 // ---- Bluestein chirp-z pointwise steps (reference: fourier-algorithms/src/bluesteins.rs:229-258) ----
 struct BluArgs {
   const void* in; void* out; const void* xtab;

@@ -123,6 +123,25 @@ def test_bluestein_and_mixed_radix_sizes(fa, oracle, n):
             assert rel_l2(run_batch(plan, x.astype(dtype), code, inplace=True), ref) <= tl2, (n, code)
 
 
+MIXED_SIZES = sorted({(2 ** a) * (3 ** b) for a in range(13) for b in range(1, 8) if (2 ** a) * (3 ** b) <= 4096})
+
+
+def test_mixed_radix_sizes_are_bit_identical_to_the_oracle(fa, oracle):
+    """N = 2^a*3^b <= 4096 runs the reference's own radix schedule [4,8,4,3,2], tables and operation order
+    (autosort/mod.rs:20-46,203-284, butterfly.rs:3-65) natively: every transform code, both precisions,
+    in and out of place must equal the CPU restatement bit for bit."""
+    for n in MIXED_SIZES[::3] + [3, 243, 3072, 3888]:
+        x = np.stack([hash_normal(11 + b, n) for b in range(3)])
+        for dtype in (np.complex64, np.complex128):
+            plan = make(fa, n, dtype)
+            assert "mixed-radix" in plan.describe()
+            for code in range(5):
+                ref = oracle.transform_batch(x.astype(dtype), code)
+                assert np.array_equal(run_batch(plan, x.astype(dtype), code), ref), (n, dtype, code)
+                assert np.array_equal(run_batch(plan, x.astype(dtype), code, inplace=True), ref), (n, dtype, code)
+    assert "bluestein" in make(fa, 6144, np.complex64).describe()  # above the LDS-resident limit
+
+
 def test_bluestein_fusion_matches_unfused(fa):
     """The chirp steps fused into the inner passes (M >= 4096) give the same values as the separate
     blu_pre / blu_post sweeps (bluesteins.rs:229-258), for every transform code, in and out of place."""

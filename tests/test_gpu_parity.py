@@ -156,6 +156,22 @@ def test_baseline_sizes_vs_oracle_and_golden(torch, fa, oracle, n, dtype, tl2, t
         assert rel_l2(gi, ri) <= tl2, (n, code)
 
 
+def test_mixed_radix_sizes_are_bit_identical_to_the_oracle(torch, fa, oracle):
+    """2^a*3^b <= 4096: the reference's radix-4/8/3/2 schedule, tables and operation order on the GPU with
+    FMA contraction off -> integer-exact agreement with the CPU restatement (not just a tolerance)."""
+    sizes = sorted({(2 ** a) * (3 ** b) for a in range(13) for b in range(1, 8) if (2 ** a) * (3 ** b) <= 4096})
+    for n in sizes:
+        x = np.stack([hash_normal(11 + b, n) for b in range(4)])
+        for dtype in (np.complex64, np.complex128):
+            plan = make(fa, n, dtype)
+            assert "mixed-radix" in plan.describe()
+            for code in range(5):
+                ref = oracle.transform_batch(x.astype(dtype), code)
+                assert np.array_equal(gpu_batch(torch, fa, plan, x.astype(dtype), code), ref), (n, dtype, code)
+            assert np.array_equal(gpu_batch(torch, fa, plan, x.astype(dtype), 0, inplace=True),
+                                  oracle.transform_batch(x.astype(dtype), 0)), n
+
+
 def test_bluestein_fusion_matches_unfused(torch, fa):
     for n in (1025, 999983):
         x = np.stack([hash_uniform(70 + b, n) for b in range(2)]).astype(np.complex64)
