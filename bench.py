@@ -55,10 +55,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):  # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import fourier_amd
@@ -164,7 +165,10 @@ def main():
             except Exception:
                 traffic = None
         out["roofline"] = {
-            "bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "bound": "hbm", "kernel": dom,
+            "rocprof_name": f"fourier_hip::fft_pass_kernel<{'float' if args.dtype == 'f32' else 'double'}, ...> "
+                            f"({'first' if dom == 'pass0' else 'last'} pass of plan {plan.describe()})",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": batch * alg_bytes_per / max(kernels[dom]["launches_per_step"], 1),
             "kernels": {k: {"ms_per_step": round(v["ms_per_step"], 4), "launches_per_step": v["launches_per_step"]}

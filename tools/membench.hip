@@ -250,8 +250,11 @@ __global__ void __launch_bounds__(512, 4) k_fused_pipe(const v4u* __restrict__ A
   const unsigned xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
   const unsigned team_in_xcd = slot / wgs_per_team, w = slot % wgs_per_team;
   const unsigned nteams = 8 * teams_per_xcd, team = xcd * teams_per_xcd + team_in_xcd;
-  unsigned* ctr1 = ctrs + team * 64;
-  unsigned* ctr2 = ctrs + team * 64 + 32;
+  // one counter PER PHASE (a single monotonic sum lets fast workgroups' later arrivals stand in for slow
+  // workgroups' earlier ones -- the stale-data bug of the first version)
+  const uint64_t mine_max = (ntransforms + nteams - 1) / nteams + 1;
+  unsigned* ctr1 = ctrs + 8192 + (uint64_t)team * 2 * mine_max;
+  unsigned* ctr2 = ctr1 + mine_max;
   unsigned* abort_flag = ctrs + 4096;
   v4u* S0 = S + (uint64_t)team * (2 * 512 * 1024);  // 2 x 8 MiB per team
   const uint64_t rowunits = 512, xform = 1024 * rowunits;
@@ -267,7 +270,7 @@ __global__ void __launch_bounds__(512, 4) k_fused_pipe(const v4u* __restrict__ A
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = __builtin_nontemporal_load(s + (uint64_t)(th + 64 * r) * rowunits);
         if (tile == w && i >= 2) {  // buffer (i&1) was last read by phase B of local transform i-2
-          if (!team_wait(ctr2, (unsigned)(i - 1) * wgs_per_team, abort_flag, false)) return;
+          if (!team_wait(ctr2 + (i - 2), (unsigned)wgs_per_team, abort_flag, false)) return;
         }
         v4u* d = Sg + (uint64_t)(tile * 8 + cg) * 1024;
         if (use_sc1) {
@@ -278,18 +281,18 @@ __global__ void __launch_bounds__(512, 4) k_fused_pipe(const v4u* __restrict__ A
           for (int r = 0; r < 16; ++r) d[th + 64 * r] = v[r];
         }
       }
-      team_arrive(ctr1, !use_sc1);
+      team_arrive(ctr1 + i, !use_sc1);
     }
     if (i >= 1) {
       const uint64_t t = team + (i - 1) * nteams;
       const v4u* Sg = S0 + ((i - 1) & 1) * (512 * 1024);
-      if (!team_wait(ctr1, (unsigned)i * wgs_per_team, abort_flag, true)) return;
+      if (!team_wait(ctr1 + (i - 1), (unsigned)wgs_per_team, abort_flag, true)) return;
       for (unsigned tile = w; tile < 64; tile += wgs_per_team) {
         const v4u* s = Sg + tile * 8 + cg;
         v4u v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = load_flavour(s + (uint64_t)(th + 64 * r) * rowunits, load_fl);
-        if (tile + wgs_per_team >= 64) team_arrive(ctr2, false);
+        if (tile + wgs_per_team >= 64) team_arrive(ctr2 + (i - 1), false);
         v4u* d = B + t * xform + tile * 8 + cg;
 #pragma unroll
         for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(v[r], d + (uint64_t)(th + 64 * r) * rowunits);
@@ -301,7 +304,7 @@ __global__ void __launch_bounds__(512, 4) k_fused_pipe(const v4u* __restrict__ A
 extern "C" int mb_fused_pipe(const void* A, void* B, void* S, void* ctrs, uint64_t bytes, int teams_per_xcd, int wgs_per_team,
                              int lds_bytes, int use_sc1, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  hipMemsetAsync(ctrs, 0, 4097 * 4, st);
+  hipMemsetAsync(ctrs, 0, (8192 + 64 * 2 * 2048) * 4, st);
   hipFuncSetAttribute((const void*)k_fused_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   const unsigned blocks = 8 * teams_per_xcd * wgs_per_team;
   k_fused_pipe<<<blocks, 512, lds_bytes, st>>>((const v4u*)A, (v4u*)B, (v4u*)S, (unsigned*)ctrs, bytes / (8 << 20), teams_per_xcd, wgs_per_team, use_sc1);

@@ -67,10 +67,10 @@ def main():
         return
     if "--pipe" in sys.argv:
         S = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
-        ctrs = torch.zeros(8192, dtype=torch.int32, device=dev)
+        ctrs = torch.zeros(8192 + 64 * 2 * 2048 + 1024, dtype=torch.int32, device=dev)
         nt = big // (8 << 20)
-        for sc1 in (1, 1, 1 + 16):
-            for tpx, wpt in ((1, 64), (2, 32), (4, 16)):
+        for sc1 in (1, 1, 1 + 16, 0):
+            for tpx, wpt in ((1, 64), (2, 32), (4, 16), (1, 32)):
                 b.zero_()
                 t = timeit(lambda: L.mb_fused_pipe(a.data_ptr(), b.data_ptr(), S.data_ptr(), ctrs.data_ptr(), big, tpx, wpt, 69632, sc1, st), reps=3, warm=1)
                 torch.cuda.synchronize()
