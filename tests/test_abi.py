@@ -38,6 +38,33 @@ def test_library_exports_every_declared_symbol(libpath):
     assert not missing, missing
 
 
+def test_library_loads_and_every_symbol_resolves_without_a_gpu(libpath):
+    """dlopen + dlsym of every declared entry point (no compute: this container has no GPU).  Without a
+    device, plan creation must fail the way the reference's FFI does on a panic: NULL, no abort
+    (fourier-ffi/src/lib.rs:18-19), and the product layer must raise instead of falling back to the CPU."""
+    import ctypes
+
+    from fourier_amd import _lib
+
+    cdll = _lib.bind(ctypes.CDLL(libpath))
+    for sym in declared_symbols():
+        assert getattr(cdll, sym) is not None
+    try:
+        import torch
+
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if not has_gpu:
+        assert not cdll.fourier_create_float(8) and not cdll.fourier_create_double(8)
+        assert cdll.fourier_hip_size_float(None) == 0
+        cdll.fourier_destroy_float(None)
+        import fourier_amd
+
+        with pytest.raises(fourier_amd.FourierError):
+            fourier_amd.create_fft_f32(8)
+
+
 def test_python_binding_lists_the_same_symbols():
     from fourier_amd import _lib
 
