@@ -61,10 +61,3 @@ def lib():
             pass
         _lib = bind(ctypes.CDLL(LIB_PATH))
     return _lib
-
-
-def use_library(cdll):
-    """Test hook: route the operator layer through an already-bound CDLL (the CPU emulation build
-    of the same sources under tests/emu).  Never called by product code."""
-    global _lib
-    _lib = cdll

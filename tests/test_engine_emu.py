@@ -23,11 +23,11 @@ def fa():
     from fourier_amd import _lib
 
     prev = _lib._lib
-    _lib.use_library(build_emu.load())
+    _lib._lib = build_emu.load()  # test-side monkeypatch: route the operator layer to the emulation build
     import fourier_amd
 
     yield fourier_amd
-    _lib.use_library(prev)
+    _lib._lib = prev
 
 
 def make(fa, n, dtype):
@@ -248,7 +248,7 @@ def test_lds_layouts_are_bank_conflict_light(fa):
         "import numpy as np\n"
         "from emu import build_emu\n"
         "from fourier_amd import _lib\n"
-        "c = build_emu.load(); _lib.use_library(c)\n"
+        "c = build_emu.load(); _lib._lib = c\n"
         "import fourier_amd as fa\n"
         "n = 1 << 20\n"
         "p = fa.create_fft_f32(n); x = np.ones((1, n), np.complex64); y = np.empty_like(x)\n"

@@ -16,7 +16,7 @@ sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests")
 import numpy as np, torch, torch.distributed as dist
 from emu import build_emu
 from fourier_amd import _lib
-_lib.use_library(build_emu.load())
+_lib._lib = build_emu.load()  # test-side monkeypatch: route the operator layer to the emulation build
 import fourier_amd as fa
 from fourier_amd import shard
 from helpers import hash_normal

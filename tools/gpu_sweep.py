@@ -88,7 +88,7 @@ def main():
         for path in sorted(glob.glob(os.path.join(ROOT, "fourier_amd", "lib", "variants", "libfourier_*.so"))):
             name = os.path.basename(path)[len("libfourier_"):-3]
             try:
-                _lib.use_library(_lib.bind(ctypes.CDLL(path)))
+                _lib._lib = _lib.bind(ctypes.CDLL(path))
                 plan = F.create_fft_f32(n, 0)
                 med, best = time_plan(plan, x, y, batch)
                 prof = plan.profile_batch_ptr(x.data_ptr(), y.data_ptr(), batch, 0, torch.cuda.current_stream().cuda_stream)
@@ -96,7 +96,7 @@ def main():
                 del plan
             except Exception as e:  # keep sweeping
                 emit(tag="variant:" + name, error=repr(e))
-        _lib.use_library(base_lib)
+        _lib._lib = base_lib
 
     if "xcd" in what:
         for xcd in (0, 1):
