@@ -167,6 +167,33 @@ template <typename T> static KernelInfo get_kernel(int L, int mode, int io = IO_
   throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "no kernel for pass length " + std::to_string(L));
 }
 
+enum { MODE_TWOLEVEL = 4 };  // host-side tag for fft_twolevel_kernel (both passes in one launch)
+
+template <typename T, int L1, int L2> static KernelInfo make_twolevel_info() {
+  constexpr int VEC = 16 / (2 * (int)sizeof(T));
+  using CA = TileCfg<T, L1, L2 / VEC>;
+  using CB = TileCfg<T, L2, L1 / VEC>;
+  KernelInfo k;
+  k.fn = &fft_twolevel_kernel<T, L1, L2>;
+  k.L = L1; k.CG = L2 / VEC; k.NT = CA::NT; k.COLS = L2; k.R3 = 1;
+  k.smem = CA::EXCH_BYTES > CB::EXCH_BYTES ? CA::EXCH_BYTES : CB::EXCH_BYTES;
+  return k;
+}
+// single-launch plans: 2^11 = 64x32 (72 % of HBM peak vs 57 % for the row kernel), 2^12 = 64x64, 2^13 = 128x64, 2^14 = 128x128, 2^15 = 256x128 (f32 only: the
+// transform must fit one workgroup's registers, 1024 threads x 16 points x VEC)
+template <typename T> static bool get_twolevel_kernel(int k, KernelInfo& info, int& l1, int& l2) {
+  switch (k) {
+    case 11: info = make_twolevel_info<T, 64, 32>(); l1 = 64; l2 = 32; return true;
+    case 12: info = make_twolevel_info<T, 64, 64>(); l1 = 64; l2 = 64; return true;
+    case 13: info = make_twolevel_info<T, 128, 64>(); l1 = 128; l2 = 64; return true;
+    case 14: info = make_twolevel_info<T, 128, 128>(); l1 = 128; l2 = 128; return true;
+    case 15:
+      if constexpr (sizeof(T) == 4) { info = make_twolevel_info<T, 256, 128>(); l1 = 256; l2 = 128; return true; }
+      return false;
+    default: return false;
+  }
+}
+
 static inline int ilog2(uint64_t v) { int l = 0; while ((1ull << l) < v) ++l; return l; }
 static inline bool is_pow2(uint64_t v) { return v && !(v & (v - 1)); }
 
@@ -219,6 +246,7 @@ template <typename T> class Pow2Engine {
     KernelInfo k;
     KernelInfo k_blu;  // IO_BLU_IN variant of a FIRST pass / IO_BLU_OUT variant of a LAST pass (lazy)
     bool has_blu = false;
+    StageTables<T>* st2 = nullptr;  // MODE_TWOLEVEL: stage tables of the second pass length
     uint64_t s, size, cn;
     uint32_t lo_bits = 0;
     DevBuf tw_lo, tw_hi;
@@ -229,6 +257,38 @@ template <typename T> class Pow2Engine {
     if (!is_pow2(n)) throw EngineError(::fourier::c::FOURIER_HIP_INVALID_ARGUMENT, "Pow2Engine: size not a power of two");
     const int k = ilog2(n);
     std::vector<int> lens;
+    KernelInfo tl;
+    int tl1 = 0, tl2 = 0;
+    if (!getenv("FOURIER_NO_TWOLEVEL") && get_twolevel_kernel<T>(k, tl, tl1, tl2)) {
+      // one launch, one HBM round trip: both passes inside a workgroup
+      auto pass = std::unique_ptr<Pass>(new Pass());
+      pass->mode = MODE_TWOLEVEL;
+      pass->k = tl;
+      pass->s = 1; pass->size = n; pass->cn = 1;
+      for (int L : {tl1, tl2}) {
+        if (stage_.find(L) == stage_.end()) {
+          auto st = std::unique_ptr<StageTables<T>>(new StageTables<T>());
+          make_stage_tables<T>(L, *st);
+          stage_.emplace(L, std::move(st));
+        }
+      }
+      pass->st = stage_[tl1].get();
+      pass->st2 = stage_[tl2].get();
+      {  // full inter-pass twiddle table W_N^{i*k1}, laid out [k1][i] (f64 trig, cast: twiddle.rs:7-19)
+        std::vector<cpx<T>> tw((size_t)n);
+        for (int k1 = 0; k1 < tl1; ++k1)
+          for (int i = 0; i < tl2; ++i) {
+            double re, im;
+            unit_root((uint64_t)i * (uint64_t)k1, n, re, im);
+            tw[(size_t)k1 * tl2 + i] = {(T)re, (T)im};
+          }
+        pass->tw_lo.upload(tw);
+      }
+      set_smem_attribute(pass->k);
+      desc_override_ = std::to_string(tl1) + "x" + std::to_string(tl2) + " one-launch";
+      passes_.push_back(std::move(pass));
+      return;
+    }
     if (k <= 3) {
       tiny_ = true;
     } else if (k <= 11) {
@@ -260,24 +320,31 @@ template <typename T> class Pow2Engine {
         it = stage_.emplace(L, std::move(st)).first;
       }
       pass->st = it->second.get();
-      if (pass->mode == MODE_FIRST || pass->mode == MODE_MID) {
-        // two-level table of W_size^{e}: e = (e >> lo_bits) << lo_bits | (e & mask)
-        const int lb = (ilog2(size) + 1) / 2;
-        pass->lo_bits = (uint32_t)lb;
-        std::vector<cpx<T>> lo((size_t)1 << lb), hi((size_t)(size >> lb));
-        for (size_t e = 0; e < lo.size(); ++e) { double re, im; unit_root(e, size, re, im); lo[e] = {(T)re, (T)im}; }
-        for (size_t h = 0; h < hi.size(); ++h) { double re, im; unit_root((uint64_t)h << lb, size, re, im); hi[h] = {(T)re, (T)im}; }
-        pass->tw_lo.upload(lo);
-        pass->tw_hi.upload(hi);
-      }
-#ifndef FOURIER_EMU
-      if (pass->k.smem > 48 * 1024)
-        HIP_CHECK(hipFuncSetAttribute((const void*)pass->k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass->k.smem));
-#endif
+      if (pass->mode == MODE_FIRST || pass->mode == MODE_MID) make_two_level(*pass, size);
+      set_smem_attribute(pass->k);
       passes_.push_back(std::move(pass));
       s *= (uint64_t)L;
       size /= (uint64_t)L;
     }
+  }
+
+  // two-level table of W_size^{e}: e = (e >> lo_bits) << lo_bits | (e & mask)
+  static void make_two_level(Pass& pass, uint64_t size) {
+    const int lb = (ilog2(size) + 1) / 2;
+    pass.lo_bits = (uint32_t)lb;
+    std::vector<cpx<T>> lo((size_t)1 << lb), hi((size_t)(size >> lb));
+    for (size_t e = 0; e < lo.size(); ++e) { double re, im; unit_root(e, size, re, im); lo[e] = {(T)re, (T)im}; }
+    for (size_t h = 0; h < hi.size(); ++h) { double re, im; unit_root((uint64_t)h << lb, size, re, im); hi[h] = {(T)re, (T)im}; }
+    pass.tw_lo.upload(lo);
+    pass.tw_hi.upload(hi);
+  }
+  static void set_smem_attribute(const KernelInfo& k) {
+#ifndef FOURIER_EMU
+    if (k.smem > 48 * 1024)
+      HIP_CHECK(hipFuncSetAttribute((const void*)k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.smem));
+#else
+    (void)k;
+#endif
   }
 
   // Bluestein fusion is available when the plan has separate first and last passes.
@@ -301,6 +368,7 @@ template <typename T> class Pow2Engine {
   bool needs_scratch(bool in_place) const { return passes_.size() == 3 || (passes_.size() == 2 && in_place); }
   std::string describe() const {
     if (tiny_) return "tiny(" + std::to_string(n_) + ")";
+    if (!desc_override_.empty()) return desc_override_;
     std::string d;
     for (size_t p = 0; p < passes_.size(); ++p) d += (p ? "x" : "") + std::to_string(passes_[p]->k.L);
     return d;
@@ -347,6 +415,7 @@ template <typename T> class Pow2Engine {
       std::memset(&a, 0, sizeof(a));
       a.in = src[p]; a.out = dst[p];
       a.tw1 = ps.st->tw1.p; a.tw2 = ps.st->tw2.p;
+      if (ps.mode == MODE_TWOLEVEL) a.tw2 = ps.st2->tw1.p;
       a.tw_lo = ps.tw_lo.p; a.tw_hi = ps.tw_hi.p;
       a.mul = (p + 1 == np) ? mul : nullptr;
       a.n = n_; a.cn = ps.cn; a.s = ps.s;
@@ -359,7 +428,11 @@ template <typename T> class Pow2Engine {
       a.swap_out = (p + 1 == np) && inverse;
       a.scale = (p + 1 == np) ? scale : 1.0;
       uint64_t grid;
-      if (ps.mode == MODE_ROWS) {
+      if (ps.mode == MODE_TWOLEVEL) {
+        a.total_cols = batch;
+        a.tiles = 1;
+        grid = batch;  // one workgroup per transform
+      } else if (ps.mode == MODE_ROWS) {
         a.total_cols = batch;
         a.tiles = 1;
         grid = (batch + ps.k.COLS - 1) / ps.k.COLS;
@@ -377,6 +450,7 @@ template <typename T> class Pow2Engine {
  private:
   size_t n_;
   bool tiny_ = false;
+  std::string desc_override_;
   std::vector<std::unique_ptr<Pass>> passes_;
   std::map<int, std::unique_ptr<StageTables<T>>> stage_;
 };

@@ -20,10 +20,14 @@
 #include <stdint.h>
 
 #ifdef FOURIER_EMU
+#define FOURIER_SCHED_FENCE()
 #define FOURIER_DYN_SMEM(name) unsigned char* name = hipemu::smem()
 #define LDS_NOTE(p, bytes, w, site) hipemu::lds_note((p), (bytes), (w), (site))
 #else
 #include <hip/hip_runtime.h>
+// stops hipcc from hoisting a whole block of table loads above the arithmetic that consumes them
+// (it otherwise keeps all 16 twiddle units live at once and spills under the 128-VGPR budget)
+#define FOURIER_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define FOURIER_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #define LDS_NOTE(p, bytes, w, site)
 #endif
@@ -53,6 +57,11 @@ enum { IO_PLAIN = 0, IO_BLU_IN = 1, IO_BLU_OUT = 2 };
 //   2 = additionally no LDS exchange (pure load -> store), 3 = no inter-pass twiddle only
 #ifndef FOURIER_ABLATE
 #define FOURIER_ABLATE 0
+#endif
+//   FOURIER_SPLIT_THRESHOLD: exchange buffers above this many bytes are exchanged as two planes (re, im):
+//   half the LDS per workgroup, twice the workgroups per CU (16 KiB measured best over 2^8..2^20, r01 sweep)
+#ifndef FOURIER_SPLIT_THRESHOLD
+#define FOURIER_SPLIT_THRESHOLD (16 * 1024)
 #endif
 #ifndef FOURIER_NT_LOAD
 #define FOURIER_NT_LOAD 1
@@ -196,7 +205,7 @@ template <typename T, int L, int CG> struct TileCfg {
   // cg (the row-contiguous mapping) hit distinct banks.
   static constexpr int PADU = (Q == 1) ? 0 : ((CG >= 32) ? L : (L * CG) / 32);
   static constexpr int UNITS = (Q == 1) ? 0 : L * CG + PADU;
-  static constexpr bool SPLIT = (size_t)UNITS * 16 > 80 * 1024;  // exchange re and im planes separately
+  static constexpr bool SPLIT = (size_t)UNITS * 16 > FOURIER_SPLIT_THRESHOLD;  // exchange re and im planes separately
   static constexpr size_t EXCH_BYTES = SPLIT ? (size_t)UNITS * 8 : (size_t)UNITS * 16;
   static constexpr size_t TABU_OFF = (EXCH_BYTES + 15) & ~(size_t)15;
   static constexpr size_t TABU_BYTES = (size_t)COLS * 16 * sizeof(cpx<T>);
@@ -539,6 +548,167 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
       }
       store_unit<T, FINAL && FOURIER_NT_STORE>(p + a.s * (uint64_t)(Q * r), u);
     }
+  }
+}
+
+// ---- mid sizes N = L1 x L2 <= 2^15 (f32) / 2^14 (f64): BOTH Stockham passes in one launch ----
+// One workgroup owns one whole transform in registers (N/16 points per ... 16 points x VEC per thread),
+// so HBM sees it once in and once out instead of twice: pass A = column FFT of length L1 over the
+// L1 x L2 matrix + twiddle W_N^{i*k1} (mod.rs:203-284 with R = L1, s = 1), an in-LDS transpose instead of
+// the HBM round trip, pass B = column FFT of length L2 over the L2 x L1 matrix (R = L2, s = L1).
+// L1, L2 in {64, 128, 256}: radix 16 x (L/16), two stages each.
+template <typename T, int L, int CG>
+__device__ __forceinline__ void two_stage_fft(RegTile<T, L, CG>& x, int th, int cg, unsigned char* smem, const cpx<T>* tw1,
+                                              unsigned site) {
+  using C = TileCfg<T, L, CG>;
+  constexpr int VEC = C::VEC, Q = C::Q, R2 = C::R2;
+  static_assert(C::R3 == 1 && Q > 1, "two_stage_fft: 32 <= L <= 256");
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) dft16(x[v]);
+  const cpx<T>* t1 = tw1 + th * 16;
+  FOURIER_SCHED_FENCE();
+#pragma unroll
+  for (int k = 1; k < 16; ++k) {
+    const cpx<T> w = t1[k];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) x[v][k] = cmul(x[v][k], w);
+    if ((k & 3) == 3) FOURIER_SCHED_FENCE();
+  }
+  lds_exchange<T, L, CG, 0>(x, smem, cg, [=](int r) { return 16 * th + r; }, th, cg, site);
+  FOURIER_SCHED_FENCE();
+  constexpr int NB2 = 16 / R2;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v)
+#pragma unroll
+    for (int u = 0; u < NB2; ++u) {
+      cpx<T> t[R2];
+#pragma unroll
+      for (int k = 0; k < R2; ++k) t[k] = x[v][u + NB2 * k];
+      dft_r<T, R2>(t);
+#pragma unroll
+      for (int k = 0; k < R2; ++k) x[v][u + NB2 * k] = t[k];
+    }
+}
+
+template <typename T, int L1, int L2>
+__global__ void __launch_bounds__((L1 / 16) * (L2 / (16 / (2 * (int)sizeof(T)))),
+                                  FOURIER_MIN_WAVES((L1 / 16) * (L2 / (16 / (2 * (int)sizeof(T))))))
+    fft_twolevel_kernel(PassArgs a) {
+  constexpr int VEC = 16 / (2 * (int)sizeof(T));
+  constexpr int CG1 = L2 / VEC, CG2 = L1 / VEC, Q1 = L1 / 16, Q2 = L2 / 16, N = L1 * L2;
+  using CA = TileCfg<T, L1, CG1>;
+  using CB = TileCfg<T, L2, CG2>;
+  static_assert(Q1 * CG1 == Q2 * CG2, "same thread count in both phases");
+  FOURIER_DYN_SMEM(smem);
+  const int tid = (int)threadIdx.x;
+  uint64_t blk = blockIdx.x;
+  if (a.nxcd > 1) {
+    const uint64_t nwg = gridDim.x, nx = a.nxcd, xcd = blk % nx, q = nwg / nx, r = nwg % nx;
+    blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + blk / nx;
+  }
+  const cpx<T>* __restrict__ in = (const cpx<T>*)a.in + blk * N;
+  cpx<T>* __restrict__ out = (cpx<T>*)a.out + blk * N;
+
+  // ---- phase A: rows k' = th + Q1*r of the L1 x L2 matrix, columns i = cg*VEC + v
+  int th = tid / CG1, cg = tid % CG1;
+  cpx<T> x[VEC][16];
+  {
+    const cpx<T>* p = in + (uint64_t)th * L2 + cg * VEC;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const Unit16<T> u = load_unit<T, FOURIER_NT_LOAD>(p + (Q1 * r) * L2);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
+    }
+  }
+  if (a.swap_in) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[v][r] = {x[v][r].im, x[v][r].re};
+  }
+  two_stage_fft<T, L1, CG1>(x, th, cg, smem, (const cpx<T>*)a.tw1, 0);
+  // register r now holds k1 = th + Q1*r of column i: inter-pass twiddle W_N^{i*k1}.  N <= 2^15, so the
+  // full table (the reference's per-pass layout idea, mod.rs:24-46) is kept, stored [k1][i] so that a
+  // thread reads it with the same coalesced 16-byte units as the data; it stays L2-resident.
+  {
+    const cpx<T>* tw = (const cpx<T>*)a.tw_lo + (uint64_t)th * L2 + cg * VEC;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const Unit16<T> u = *(const Unit16<T>*)(tw + (Q1 * r) * L2);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) x[v][r] = cmul(x[v][r], cpx<T>{u.a[2 * v], u.a[2 * v + 1]});
+      if ((r & 3) == 3) FOURIER_SCHED_FENCE();
+    }
+  }
+
+  // ---- transpose through LDS: element (i, k1) -> row i, column k1 of the L2 x L1 matrix
+  const int th2 = tid / CG2, cg2 = tid % CG2;
+  {
+    constexpr bool SPLIT = CB::SPLIT;
+    __syncthreads();  // the reads of phase A's exchange are done
+#pragma unroll
+    for (int plane = 0; plane < (SPLIT ? 2 : 1); ++plane) {
+      if (plane == 1) __syncthreads();
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const int i = cg * VEC + v;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k1 = th + Q1 * r;
+          const int unit = CB::template unit_index<0>(i, k1 / VEC);
+          if constexpr (SPLIT) {
+            T* p = (T*)(smem + (size_t)unit * 8) + (k1 % VEC);
+            LDS_NOTE(p, sizeof(T), true, 8 + plane);
+            *p = plane ? x[v][r].im : x[v][r].re;
+          } else {
+            cpx<T>* p = (cpx<T>*)(smem + (size_t)unit * 16) + (k1 % VEC);
+            LDS_NOTE(p, 2 * sizeof(T), true, 8);
+            *p = x[v][r];
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int unit = CB::template unit_index<0>(th2 + Q2 * r, cg2);
+        if constexpr (SPLIT) {
+          const Unit8<T>* p = (const Unit8<T>*)smem + unit;
+          LDS_NOTE(p, 8, false, 10 + plane);
+          const Unit8<T> u = *p;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            if (plane) x[v][r].im = u.a[v]; else x[v][r].re = u.a[v];
+          }
+        } else {
+          const Unit16<T>* p = (const Unit16<T>*)smem + unit;
+          LDS_NOTE(p, 16, false, 10);
+          const Unit16<T> u = *p;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- phase B: rows i = th2 + Q2*r of the L2 x L1 matrix, columns k1 = cg2*VEC + v
+  two_stage_fft<T, L2, CG2>(x, th2, cg2, smem, (const cpx<T>*)a.tw2, 12);
+  // register r now holds k2 = th2 + Q2*r: X[k1 + L1*k2]
+  const T scale = (T)a.scale;
+  const cpx<T>* __restrict__ mul = (const cpx<T>*)a.mul;
+  cpx<T>* p = out + (uint64_t)th2 * L1 + cg2 * VEC;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    Unit16<T> u;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      cpx<T> y = x[v][r];
+      if (mul) y = cmul(y, mul[(th2 + Q2 * r) * L1 + cg2 * VEC + v]);
+      if (a.swap_out) y = {y.im, y.re};
+      u.a[2 * v] = y.re * scale; u.a[2 * v + 1] = y.im * scale;
+    }
+    store_unit<T, FOURIER_NT_STORE>(p + (Q2 * r) * L1, u);
   }
 }
 

@@ -92,7 +92,7 @@ def test_ffi_impulse_roundtrip(fa, dtype):
     assert np.abs(out - x).max() <= 1e-10
 
 
-@pytest.mark.parametrize("n", [16, 64, 512, 2048, 4096, 8192, 1 << 16])
+@pytest.mark.parametrize("n", [16, 64, 512, 2048, 4096, 8192, 1 << 14, 1 << 15, 1 << 16])
 @pytest.mark.parametrize("dtype,tl2,tmax", [(np.complex64, 1e-6, 2e-6), (np.complex128, 5e-14, 1e-13)])
 def test_pow2_sizes_all_codes_vs_oracle(fa, oracle, n, dtype, tl2, tmax):
     plan = make(fa, n, dtype)
@@ -153,6 +153,25 @@ def test_bluestein_fusion_matches_unfused(fa):
             a, b = run_batch(fused, x, code), run_batch(plain, x, code)
             assert np.array_equal(a, b), (n, code)
             assert np.array_equal(run_batch(fused, x, code, inplace=True), a), (n, code)
+
+
+def test_one_launch_plans_match_the_two_launch_plans(fa, monkeypatch):
+    """2^12..2^15 run both Stockham passes inside one workgroup (one HBM round trip); the two-launch
+    plan of the same size (forced with FOURIER_NO_TWOLEVEL) must agree to rounding."""
+    for n in (4096, 8192, 1 << 14, 1 << 15):
+        x = np.stack([hash_normal(500 + b, n) for b in range(2)]).astype(np.complex64)
+        one = make(fa, n, np.complex64)
+        assert "one-launch" in one.describe()
+        monkeypatch.setenv("FOURIER_NO_TWOLEVEL", "1")
+        two = make(fa, n, np.complex64)
+        monkeypatch.delenv("FOURIER_NO_TWOLEVEL")
+        assert "one-launch" not in two.describe()
+        for code in (0, 1, 3):
+            a, b = run_batch(one, x, code), run_batch(two, x, code)
+            assert rel_l2(a, b) <= 3e-7, (n, code, rel_l2(a, b))
+            assert np.array_equal(run_batch(one, x, code, inplace=True), a)
+    assert "one-launch" in make(fa, 1 << 14, np.complex128).describe()
+    assert "one-launch" not in make(fa, 1 << 15, np.complex128).describe()  # f64 2^15 does not fit a workgroup
 
 
 def test_three_pass_plan(fa):
@@ -225,15 +244,20 @@ def test_error_behaviour_matches_reference_ffi(fa):
 
 
 def test_profile_hook_reports_every_kernel(fa):
-    plan = make(fa, 4096, np.complex64)
-    x = hash_normal(1, 4096).astype(np.complex64)[None, :]
+    plan = make(fa, 1 << 16, np.complex64)  # 256 x 256: two launches
+    x = hash_normal(1, 1 << 16).astype(np.complex64)[None, :]
     y = np.empty_like(x)
     prof = plan.profile_batch_ptr(x.ctypes.data, y.ctypes.data, 1, 0)
     assert [p[0] for p in prof] == ["pass0", "pass1"] and all(p[2] == 1 for p in prof)
+    one = make(fa, 4096, np.complex64)  # 64 x 64 inside one workgroup: a single launch
+    x1 = hash_normal(1, 4096).astype(np.complex64)[None, :]
+    y1 = np.empty_like(x1)
+    assert [p[0] for p in one.profile_batch_ptr(x1.ctypes.data, y1.ctypes.data, 1, 0)] == ["pass0"]
     assert rel_l2(y[0], np.fft.fft(x[0].astype(np.complex128))) <= 1e-6
     planb = make(fa, 1000, np.complex64)
     xb = hash_normal(1, 1000).astype(np.complex64)[None, :]
-    names = [p[0] for p in planb.profile_batch_ptr(xb.ctypes.data, np.empty_like(xb).ctypes.data, 1, 0)]
+    yb = np.empty_like(xb)
+    names = [p[0] for p in planb.profile_batch_ptr(xb.ctypes.data, yb.ctypes.data, 1, 0)]
     assert names == ["blu_pre", "fwd_pass0", "inv_pass0", "blu_post"]
 
 

@@ -98,7 +98,7 @@ def test_ffi_impulse_roundtrip(fa, dtype):
     assert np.abs(out - x).max() <= 1e-10
 
 
-@pytest.mark.parametrize("n", [1, 2, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 1 << 14, 1 << 16, 1 << 18])
+@pytest.mark.parametrize("n", [1, 2, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 1 << 14, 1 << 15, 1 << 16, 1 << 18])
 @pytest.mark.parametrize("dtype,tl2,tmax", [(np.complex64, 1e-6, 2e-6), (np.complex128, 5e-14, 1e-13)])
 def test_pow2_all_codes_vs_oracle(torch, fa, oracle, n, dtype, tl2, tmax):
     plan = make(fa, n, dtype)

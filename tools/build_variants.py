@@ -18,6 +18,9 @@ VARIANTS = {
     "nt_both": ["-DFOURIER_NT_LOAD=1", "-DFOURIER_NT_STORE=1"],
     "cg4": ["-DFOURIER_CG_1024=4"],
     "cg16": ["-DFOURIER_CG_1024=16"],
+    "split16k": ["-DFOURIER_SPLIT_THRESHOLD=(16*1024)"],
+    "split32k": ["-DFOURIER_SPLIT_THRESHOLD=(32*1024)"],
+    "split0": ["-DFOURIER_SPLIT_THRESHOLD=0"],
     "abl1": ["-DFOURIER_ABLATE=1"],
     "abl2": ["-DFOURIER_ABLATE=2"],
     "abl3": ["-DFOURIER_ABLATE=3"],

@@ -129,7 +129,7 @@ def main():
         del y
         torch.cuda.empty_cache()
         for real, esz in (("f32", 8), ("f64", 16)):
-            for lg in (10, 12, 14, 16, 18, 20, 21, 22, 24):
+            for lg in (8, 10, 11, 12, 13, 14, 15, 16, 18, 20, 21, 22, 24):
                 nn = 1 << lg
                 bb = max(1, min((8 << 30) // (nn * esz), 1 << 20))
                 cdt = torch.complex64 if real == "f32" else torch.complex128
