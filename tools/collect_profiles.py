@@ -43,8 +43,8 @@ def main(tag):
             b = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
             out["per_launch_bytes"][k] = b
             # bench.py names kernels by slot: MODE template argument 0 = pass0 (FIRST), 2 = pass1 (LAST)
-            mode = k.split(",")[-1].strip().split(">")[0].strip()
-            out["per_launch_bytes"]["pass0" if mode == "0" else "pass1"] = b
+            targs = [t.strip() for t in k[k.index("<") + 1:k.index(">")].split(",")]  # <T, L, CG, MODE, IO>
+            out["per_launch_bytes"]["pass0" if targs[3] == "0" else "pass1"] = b
     json.dump(out, open(os.path.join(P, f"{tag}_pmc_traffic.json"), "w"), indent=1)
     json.dump(out, open(os.path.join(P, "traffic_latest.json"), "w"), indent=1)
     print(json.dumps(out["per_launch_bytes"], indent=1))
