@@ -194,6 +194,24 @@ template <typename T> static bool get_twolevel_kernel(int k, KernelInfo& info, i
   }
 }
 
+template <typename T, int L1, int L2> static KernelInfo make_blu_small_info() {
+  KernelInfo k = make_twolevel_info<T, L1, L2>();
+  k.fn = &bluestein_small_kernel<T, L1, L2>;
+  return k;
+}
+template <typename T> static bool get_blu_small_kernel(int k, KernelInfo& info) {
+  switch (k) {
+    case 11: info = make_blu_small_info<T, 64, 32>(); return true;
+    case 12: info = make_blu_small_info<T, 64, 64>(); return true;
+    case 13: info = make_blu_small_info<T, 128, 64>(); return true;
+    case 14: info = make_blu_small_info<T, 128, 128>(); return true;
+    case 15:
+      if constexpr (sizeof(T) == 4) { info = make_blu_small_info<T, 256, 128>(); return true; }
+      return false;
+    default: return false;
+  }
+}
+
 static inline int ilog2(uint64_t v) { int l = 0; while ((1ull << l) < v) ++l; return l; }
 static inline bool is_pow2(uint64_t v) { return v && !(v & (v - 1)); }
 
@@ -284,6 +302,7 @@ template <typename T> class Pow2Engine {
           }
         pass->tw_lo.upload(tw);
       }
+      tl1_ = tl1; tl2_ = tl2;
       set_smem_attribute(pass->k);
       desc_override_ = std::to_string(tl1) + "x" + std::to_string(tl2) + " one-launch";
       passes_.push_back(std::move(pass));
@@ -345,6 +364,40 @@ template <typename T> class Pow2Engine {
 #else
     (void)k;
 #endif
+  }
+
+  // Whole-Bluestein-in-one-launch (bluestein_small_kernel) is available when this (inner) plan is a
+  // one-launch two-level plan: it additionally needs the inter-pass table of the role-swapped L2 x L1 problem.
+  bool enable_bluestein_small() {
+    if (tiny_ || passes_.size() != 1 || passes_[0]->mode != MODE_TWOLEVEL) return false;
+    if (!get_blu_small_kernel<T>(ilog2(n_), blu_small_)) return false;
+    std::vector<cpx<T>> tw(n_);
+    for (int k1 = 0; k1 < tl2_; ++k1)      // swapped roles: k1' < L2, i' < L1, layout [k1'][i']
+      for (int i = 0; i < tl1_; ++i) {
+        double re, im;
+        unit_root((uint64_t)i * (uint64_t)k1, n_, re, im);
+        tw[(size_t)k1 * tl1_ + i] = {(T)re, (T)im};
+      }
+    passes_[0]->tw_hi.upload(tw);
+    set_smem_attribute(blu_small_);
+    return true;
+  }
+  // in/out: USER arrays (batch stride n_user); xtab: chirp (n_user), wtab: FFT'd chirp / M (n_ entries)
+  void run_bluestein_small(const cpx<T>* in, cpx<T>* out, size_t batch, const void* xtab, const void* wtab, uint64_t n_user,
+                           bool inverse, double scale, hipStream_t stream, Profiler* prof, unsigned nxcd) const {
+    if (batch == 0) return;
+    const Pass& ps = *passes_[0];
+    PassArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.in = in; a.out = out;
+    a.tw1 = ps.st->tw1.p; a.tw2 = ps.st2->tw1.p;
+    a.tw_lo = ps.tw_lo.p; a.tw_hi = ps.tw_hi.p;
+    a.mul = wtab; a.blu_x = xtab; a.blu_n = n_user; a.blu_swap = inverse;
+    a.n = n_; a.scale = scale; a.nxcd = nxcd;
+    if (batch > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");
+    PROF_BEGIN(prof, 0);
+    FOURIER_LAUNCH(blu_small_.fn, batch, blu_small_.NT, blu_small_.smem, stream, a);
+    PROF_END(prof);
   }
 
   // Bluestein fusion is available when the plan has separate first and last passes.
@@ -450,6 +503,8 @@ template <typename T> class Pow2Engine {
  private:
   size_t n_;
   bool tiny_ = false;
+  int tl1_ = 0, tl2_ = 0;   // pass lengths of a one-launch (MODE_TWOLEVEL) plan
+  KernelInfo blu_small_;
   std::string desc_override_;
   std::vector<std::unique_ptr<Pass>> passes_;
   std::map<int, std::unique_ptr<StageTables<T>>> stage_;
@@ -586,7 +641,7 @@ template <typename T> class Plan {
       desc_ = "stockham mixed-radix " + mix_->describe();
     } else {
       init_bluestein();
-      desc_ = "bluestein M=" + std::to_string(m_) + " inner " + eng_->describe();
+      desc_ = "bluestein M=" + std::to_string(m_) + " inner " + eng_->describe() + (small_fused_ ? " fused" : "");
     }
     desc_ += sizeof(T) == 4 ? " f32" : " f64";
   }
@@ -604,6 +659,7 @@ template <typename T> class Plan {
       for (size_t p = 0; p < eng_->num_passes(); ++p) d += std::string(d.empty() ? "" : ",") + tag + std::to_string(p);
     };
     if (!blu_) { passes("pass"); return d; }
+    if (small_fused_) return "bluestein_one_launch";
     d = "blu_pre"; passes("fwd_pass"); passes("inv_pass"); d += ",blu_post";  // blu_pre/post stay empty when fused
     return d;
   }
@@ -613,6 +669,7 @@ template <typename T> class Plan {
     if (!blu_) return 2.0 * n_ * ELEM * eng_->num_passes();
     // unfused: pre (n + table read, m write) + 2 inner FFTs + w table + post (n + table read, n write);
     // fused: the first / last inner pass read / write the n-point user array instead of an m-point sweep
+    if (small_fused_) return (double)ELEM * 2.0 * n_;  // tables stay L2-resident
     if (fused_) return (double)ELEM * (2.0 * 2.0 * m_ * eng_->num_passes() - 2.0 * (m_ - n_) + m_ + 2.0 * n_);
     return (double)ELEM * ((2.0 * n_ + m_) + 2.0 * 2.0 * m_ * eng_->num_passes() + m_ + 3.0 * n_);
   }
@@ -621,7 +678,11 @@ template <typename T> class Plan {
     if (key == "chunk_bytes" && v >= 0) { chunk_bytes_ = (size_t)v; return 0; }
     if (key == "scratch" && (v == 0 || v == 1)) { force_scratch_ = (v == 1); return 0; }
     if (key == "xcd_swizzle" && (v == 0 || v == 1)) { nxcd_ = v ? 8 : 1; return 0; }
-    if (key == "bluestein_fusion" && (v == 0 || v == 1)) { fused_ = (v == 1) && blu_ && eng_->can_fuse_bluestein(); return 0; }
+    if (key == "bluestein_fusion" && (v == 0 || v == 1)) {
+      fused_ = (v == 1) && blu_ && eng_->can_fuse_bluestein();
+      small_fused_ = (v == 1) && blu_ && eng_->enable_bluestein_small();
+      return 0;
+    }
     return ::fourier::c::FOURIER_HIP_INVALID_ARGUMENT;
   }
 
@@ -663,6 +724,10 @@ template <typename T> class Plan {
       return;
     }
     // Bluestein (bluesteins.rs:215-259): work = x.in (zero padded) ; FFT_M ; .w ; IFFT_M ; out = work.x.scale
+    if (small_fused_) {  // M <= 2^15: the whole chirp-z in one launch, no work array
+      eng_->run_bluestein_small(in, out, batch, xtab_.p, wtab_.p, n_, inverse, scale, stream, prof, nxcd_);
+      return;
+    }
     work_.ensure(chunk * m_ * ELEM);
     if (eng_->needs_scratch(true) || fused_) scratch_.ensure(chunk * m_ * ELEM);
     cpx<T>* work = (cpx<T>*)work_.p;
@@ -728,6 +793,7 @@ template <typename T> class Plan {
     eng_.reset(new Pow2Engine<T>(m_));
     eng_->enable_bluestein_fusion();
     fused_ = eng_->can_fuse_bluestein();
+    small_fused_ = eng_->enable_bluestein_small();
     // chirp exp(-i*pi*k^2/n), angle reduced exactly with k^2 mod 2n (the reference leaves it
     // unreduced, bluesteins.rs:10,31,57; the reduction only removes f64 argument error)
     std::vector<double> cr(n_), ci(n_);
@@ -764,6 +830,7 @@ template <typename T> class Plan {
   size_t chunk_bytes_ = 0;
   bool force_scratch_ = false;
   bool fused_ = false;  // Bluestein: chirp steps fused into the inner passes
+  bool small_fused_ = false;  // Bluestein with M <= 2^15: everything in one launch
   unsigned nxcd_ = 8;
   mutable int status_ = 0;
   std::string desc_;

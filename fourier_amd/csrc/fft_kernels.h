@@ -590,58 +590,34 @@ __device__ __forceinline__ void two_stage_fft(RegTile<T, L, CG>& x, int th, int 
     }
 }
 
+// Both passes of an N = L1 x L2 transform on register-resident data.  In: thread (th = tid / CG1,
+// cg = tid % CG1) holds rows th + Q1*r of the L1 x L2 row-major matrix (element row*L2 + col), columns
+// cg*VEC + v.  Out: thread (th2 = tid / CG2, cg2 = tid % CG2) holds X[k1 + L1*k2] for k2 = th2 + Q2*r,
+// k1 = cg2*VEC + v -- i.e. exactly the input layout of an L2 x L1 problem, so the core can be chained.
 template <typename T, int L1, int L2>
-__global__ void __launch_bounds__((L1 / 16) * (L2 / (16 / (2 * (int)sizeof(T)))),
-                                  FOURIER_MIN_WAVES((L1 / 16) * (L2 / (16 / (2 * (int)sizeof(T))))))
-    fft_twolevel_kernel(PassArgs a) {
+__device__ __forceinline__ void twolevel_core(cpx<T> (*x)[16], int tid, unsigned char* smem, const cpx<T>* tw1_a,
+                                              const cpx<T>* tw1_b, const cpx<T>* tw_full, unsigned site) {
   constexpr int VEC = 16 / (2 * (int)sizeof(T));
-  constexpr int CG1 = L2 / VEC, CG2 = L1 / VEC, Q1 = L1 / 16, Q2 = L2 / 16, N = L1 * L2;
-  using CA = TileCfg<T, L1, CG1>;
+  constexpr int CG1 = L2 / VEC, CG2 = L1 / VEC, Q1 = L1 / 16, Q2 = L2 / 16;
   using CB = TileCfg<T, L2, CG2>;
   static_assert(Q1 * CG1 == Q2 * CG2, "same thread count in both phases");
-  FOURIER_DYN_SMEM(smem);
-  const int tid = (int)threadIdx.x;
-  uint64_t blk = blockIdx.x;
-  if (a.nxcd > 1) {
-    const uint64_t nwg = gridDim.x, nx = a.nxcd, xcd = blk % nx, q = nwg / nx, r = nwg % nx;
-    blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + blk / nx;
-  }
-  const cpx<T>* __restrict__ in = (const cpx<T>*)a.in + blk * N;
-  cpx<T>* __restrict__ out = (cpx<T>*)a.out + blk * N;
-
-  // ---- phase A: rows k' = th + Q1*r of the L1 x L2 matrix, columns i = cg*VEC + v
-  int th = tid / CG1, cg = tid % CG1;
-  cpx<T> x[VEC][16];
-  {
-    const cpx<T>* p = in + (uint64_t)th * L2 + cg * VEC;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const Unit16<T> u = load_unit<T, FOURIER_NT_LOAD>(p + (Q1 * r) * L2);
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
-    }
-  }
-  if (a.swap_in) {
-#pragma unroll
-    for (int v = 0; v < VEC; ++v)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) x[v][r] = {x[v][r].im, x[v][r].re};
-  }
-  two_stage_fft<T, L1, CG1>(x, th, cg, smem, (const cpx<T>*)a.tw1, 0);
+  typedef cpx<T> Regs[VEC][16];
+  Regs& xr = *reinterpret_cast<Regs*>(x);
+  const int th = tid / CG1, cg = tid % CG1;
+  two_stage_fft<T, L1, CG1>(xr, th, cg, smem, tw1_a, site);
   // register r now holds k1 = th + Q1*r of column i: inter-pass twiddle W_N^{i*k1}.  N <= 2^15, so the
   // full table (the reference's per-pass layout idea, mod.rs:24-46) is kept, stored [k1][i] so that a
   // thread reads it with the same coalesced 16-byte units as the data; it stays L2-resident.
   {
-    const cpx<T>* tw = (const cpx<T>*)a.tw_lo + (uint64_t)th * L2 + cg * VEC;
+    const cpx<T>* tw = tw_full + (uint64_t)th * L2 + cg * VEC;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const Unit16<T> u = *(const Unit16<T>*)(tw + (Q1 * r) * L2);
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) x[v][r] = cmul(x[v][r], cpx<T>{u.a[2 * v], u.a[2 * v + 1]});
+      for (int v = 0; v < VEC; ++v) xr[v][r] = cmul(xr[v][r], cpx<T>{u.a[2 * v], u.a[2 * v + 1]});
       if ((r & 3) == 3) FOURIER_SCHED_FENCE();
     }
   }
-
   // ---- transpose through LDS: element (i, k1) -> row i, column k1 of the L2 x L1 matrix
   const int th2 = tid / CG2, cg2 = tid % CG2;
   {
@@ -659,12 +635,12 @@ __global__ void __launch_bounds__((L1 / 16) * (L2 / (16 / (2 * (int)sizeof(T))))
           const int unit = CB::template unit_index<0>(i, k1 / VEC);
           if constexpr (SPLIT) {
             T* p = (T*)(smem + (size_t)unit * 8) + (k1 % VEC);
-            LDS_NOTE(p, sizeof(T), true, 8 + plane);
-            *p = plane ? x[v][r].im : x[v][r].re;
+            LDS_NOTE(p, sizeof(T), true, site + 8 + plane);
+            *p = plane ? xr[v][r].im : xr[v][r].re;
           } else {
             cpx<T>* p = (cpx<T>*)(smem + (size_t)unit * 16) + (k1 % VEC);
-            LDS_NOTE(p, 2 * sizeof(T), true, 8);
-            *p = x[v][r];
+            LDS_NOTE(p, 2 * sizeof(T), true, site + 8);
+            *p = xr[v][r];
           }
         }
       }
@@ -674,27 +650,63 @@ __global__ void __launch_bounds__((L1 / 16) * (L2 / (16 / (2 * (int)sizeof(T))))
         const int unit = CB::template unit_index<0>(th2 + Q2 * r, cg2);
         if constexpr (SPLIT) {
           const Unit8<T>* p = (const Unit8<T>*)smem + unit;
-          LDS_NOTE(p, 8, false, 10 + plane);
+          LDS_NOTE(p, 8, false, site + 10 + plane);
           const Unit8<T> u = *p;
 #pragma unroll
           for (int v = 0; v < VEC; ++v) {
-            if (plane) x[v][r].im = u.a[v]; else x[v][r].re = u.a[v];
+            if (plane) xr[v][r].im = u.a[v]; else xr[v][r].re = u.a[v];
           }
         } else {
           const Unit16<T>* p = (const Unit16<T>*)smem + unit;
-          LDS_NOTE(p, 16, false, 10);
+          LDS_NOTE(p, 16, false, site + 10);
           const Unit16<T> u = *p;
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
+          for (int v = 0; v < VEC; ++v) xr[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
         }
       }
     }
     __syncthreads();
   }
-
   // ---- phase B: rows i = th2 + Q2*r of the L2 x L1 matrix, columns k1 = cg2*VEC + v
-  two_stage_fft<T, L2, CG2>(x, th2, cg2, smem, (const cpx<T>*)a.tw2, 12);
+  two_stage_fft<T, L2, CG2>(xr, th2, cg2, smem, tw1_b, site + 12);
+}
+
+#define FOURIER_TWOLEVEL_NT(T, L1, L2) ((L1 / 16) * (L2 / (16 / (2 * (int)sizeof(T)))))
+
+template <typename T, int L1, int L2>
+__global__ void __launch_bounds__(FOURIER_TWOLEVEL_NT(T, L1, L2), FOURIER_MIN_WAVES(FOURIER_TWOLEVEL_NT(T, L1, L2)))
+    fft_twolevel_kernel(PassArgs a) {
+  constexpr int VEC = 16 / (2 * (int)sizeof(T));
+  constexpr int CG1 = L2 / VEC, CG2 = L1 / VEC, Q1 = L1 / 16, Q2 = L2 / 16, N = L1 * L2;
+  FOURIER_DYN_SMEM(smem);
+  const int tid = (int)threadIdx.x;
+  uint64_t blk = blockIdx.x;
+  if (a.nxcd > 1) {
+    const uint64_t nwg = gridDim.x, nx = a.nxcd, xcd = blk % nx, q = nwg / nx, r = nwg % nx;
+    blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + blk / nx;
+  }
+  const cpx<T>* __restrict__ in = (const cpx<T>*)a.in + blk * N;
+  cpx<T>* __restrict__ out = (cpx<T>*)a.out + blk * N;
+  const int th = tid / CG1, cg = tid % CG1;
+  cpx<T> x[VEC][16];
+  {
+    const cpx<T>* p = in + (uint64_t)th * L2 + cg * VEC;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const Unit16<T> u = load_unit<T, FOURIER_NT_LOAD>(p + (Q1 * r) * L2);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
+    }
+  }
+  if (a.swap_in) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[v][r] = {x[v][r].im, x[v][r].re};
+  }
+  twolevel_core<T, L1, L2>(x, tid, smem, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw2, (const cpx<T>*)a.tw_lo, 0);
   // register r now holds k2 = th2 + Q2*r: X[k1 + L1*k2]
+  const int th2 = tid / CG2, cg2 = tid % CG2;
   const T scale = (T)a.scale;
   const cpx<T>* __restrict__ mul = (const cpx<T>*)a.mul;
   cpx<T>* p = out + (uint64_t)th2 * L1 + cg2 * VEC;
@@ -709,6 +721,77 @@ __global__ void __launch_bounds__((L1 / 16) * (L2 / (16 / (2 * (int)sizeof(T))))
       u.a[2 * v] = y.re * scale; u.a[2 * v + 1] = y.im * scale;
     }
     store_unit<T, FOURIER_NT_STORE>(p + (Q2 * r) * L1, u);
+  }
+}
+
+// ---- whole Bluestein chirp-z (bluesteins.rs:215-259) in ONE launch for M = L1 x L2 <= 2^15 ----
+// work = x (.) in (zero padded to M) -> FFT_M -> (.) w -> IFFT_M -> (.) x (.) scale, all on the
+// register-resident M-point array of one workgroup: the forward two-level core, then the same core with the
+// roles of L1 and L2 exchanged (its input layout is the other's output layout).  HBM sees the N-point user
+// array once in and once out; the tables (x: N, w: M, twiddles) stay L2-resident.
+template <typename T, int L1, int L2>
+__global__ void __launch_bounds__(FOURIER_TWOLEVEL_NT(T, L1, L2), FOURIER_MIN_WAVES(FOURIER_TWOLEVEL_NT(T, L1, L2)))
+    bluestein_small_kernel(PassArgs a) {
+  constexpr int VEC = 16 / (2 * (int)sizeof(T));
+  constexpr int CG1 = L2 / VEC, CG2 = L1 / VEC, Q1 = L1 / 16, Q2 = L2 / 16;
+  FOURIER_DYN_SMEM(smem);
+  const int tid = (int)threadIdx.x;
+  uint64_t blk = blockIdx.x;
+  if (a.nxcd > 1) {
+    const uint64_t nwg = gridDim.x, nx = a.nxcd, xcd = blk % nx, q = nwg / nx, r = nwg % nx;
+    blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + blk / nx;
+  }
+  const uint32_t n = (uint32_t)a.blu_n;
+  const cpx<T>* __restrict__ in = (const cpx<T>*)a.in + blk * a.blu_n;
+  cpx<T>* __restrict__ out = (cpx<T>*)a.out + blk * a.blu_n;
+  const cpx<T>* __restrict__ xt = (const cpx<T>*)a.blu_x;
+  const int th = tid / CG1, cg = tid % CG1;
+  cpx<T> x[VEC][16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const uint32_t idx = (uint32_t)((th + Q1 * r) * L2 + cg * VEC + v);
+      cpx<T> val{0, 0};
+      if (idx < n) {  // bluesteins.rs:229-234
+        val = in[idx];
+        if (a.blu_swap) val = {val.im, val.re};
+        val = cmul(xt[idx], val);
+      }
+      x[v][r] = val;
+    }
+  }
+  twolevel_core<T, L1, L2>(x, tid, smem, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw2, (const cpx<T>*)a.tw_lo, 0);
+  {  // (.) w (already FFT'd and scaled by 1/M on the host), then swap for the inverse transform (bluesteins.rs:236-239)
+    const int th2 = tid / CG2, cg2 = tid % CG2;
+    const cpx<T>* w = (const cpx<T>*)a.mul + (uint64_t)th2 * L1 + cg2 * VEC;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const Unit16<T> u = *(const Unit16<T>*)(w + (Q2 * r) * L1);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const cpx<T> y = cmul(x[v][r], cpx<T>{u.a[2 * v], u.a[2 * v + 1]});
+        x[v][r] = {y.im, y.re};
+      }
+      if ((r & 3) == 3) FOURIER_SCHED_FENCE();
+    }
+  }
+  __syncthreads();
+  twolevel_core<T, L2, L1>(x, tid, smem, (const cpx<T>*)a.tw2, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw_hi, 32);
+  // back in the original layout: register r holds index (th + Q1*r)*L2 + cg*VEC + v of the swapped inverse
+  const T scale = (T)a.scale;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const uint32_t idx = (uint32_t)((th + Q1 * r) * L2 + cg * VEC + v);
+      if (idx < n) {  // bluesteins.rs:240-258
+        cpx<T> y{x[v][r].im, x[v][r].re};
+        y = cmul(y, xt[idx]);
+        if (a.blu_swap) y = {y.im, y.re};
+        out[idx] = {y.re * scale, y.im * scale};
+      }
+    }
   }
 }
 

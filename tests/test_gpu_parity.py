@@ -173,13 +173,13 @@ def test_mixed_radix_sizes_are_bit_identical_to_the_oracle(torch, fa, oracle):
 
 
 def test_bluestein_fusion_matches_unfused(torch, fa):
-    for n in (1025, 999983):
+    for n in (1025, 3125, 10007, 999983):  # one-launch chirp-z (M <= 2^15) and pass-fused (M = 2^21)
         x = np.stack([hash_uniform(70 + b, n) for b in range(2)]).astype(np.complex64)
         fused, plain = make(fa, n, np.complex64), make(fa, n, np.complex64)
         plain.set_option("bluestein_fusion", 0)
         for code in (0, 1, 4):
             a, b = gpu_batch(torch, fa, fused, x, code), gpu_batch(torch, fa, plain, x, code)
-            assert rel_l2(a, b) <= 1e-7, (n, code, rel_l2(a, b))
+            assert rel_l2(a, b) <= 3e-7, (n, code, rel_l2(a, b))  # different factorisation order, same tolerance class
             assert np.array_equal(gpu_batch(torch, fa, fused, x, code, inplace=True), a), (n, code)
 
 
