@@ -199,8 +199,23 @@ template <typename T, int L1, int L2> static KernelInfo make_blu_small_info() {
   k.fn = &bluestein_small_kernel<T, L1, L2>;
   return k;
 }
+template <typename T, int L, int CG> static KernelInfo make_blu_rows_info() {
+  using C = TileCfg<T, L, CG>;
+  KernelInfo k;
+  k.fn = &bluestein_rows_kernel<T, L, CG>;
+  k.L = L; k.CG = CG; k.NT = C::NT; k.COLS = C::COLS; k.R3 = C::R3;
+  k.smem = C::EXCH_BYTES;
+  return k;
+}
 template <typename T> static bool get_blu_small_kernel(int k, KernelInfo& info) {
   switch (k) {
+    case 4: info = make_blu_rows_info<T, 16, 64>(); return true;   // same tile shapes as the row kernels
+    case 5: info = make_blu_rows_info<T, 32, 32>(); return true;
+    case 6: info = make_blu_rows_info<T, 64, 16>(); return true;
+    case 7: info = make_blu_rows_info<T, 128, 16>(); return true;
+    case 8: info = make_blu_rows_info<T, 256, 16>(); return true;
+    case 9: info = make_blu_rows_info<T, 512, FOURIER_CG_512>(); return true;
+    case 10: info = make_blu_rows_info<T, 1024, FOURIER_CG_1024>(); return true;
     case 11: info = make_blu_small_info<T, 64, 32>(); return true;
     case 12: info = make_blu_small_info<T, 64, 64>(); return true;
     case 13: info = make_blu_small_info<T, 128, 64>(); return true;
@@ -369,7 +384,13 @@ template <typename T> class Pow2Engine {
   // Whole-Bluestein-in-one-launch (bluestein_small_kernel) is available when this (inner) plan is a
   // one-launch two-level plan: it additionally needs the inter-pass table of the role-swapped L2 x L1 problem.
   bool enable_bluestein_small() {
-    if (tiny_ || passes_.size() != 1 || passes_[0]->mode != MODE_TWOLEVEL) return false;
+    if (tiny_ || passes_.size() != 1) return false;
+    if (passes_[0]->mode == MODE_ROWS) {  // M <= 1024: row core twice, COLS transforms per workgroup
+      if (!get_blu_small_kernel<T>(ilog2(n_), blu_small_)) return false;
+      set_smem_attribute(blu_small_);
+      return true;
+    }
+    if (passes_[0]->mode != MODE_TWOLEVEL) return false;
     if (!get_blu_small_kernel<T>(ilog2(n_), blu_small_)) return false;
     std::vector<cpx<T>> tw(n_);
     for (int k1 = 0; k1 < tl2_; ++k1)      // swapped roles: k1' < L2, i' < L1, layout [k1'][i']
@@ -390,13 +411,15 @@ template <typename T> class Pow2Engine {
     PassArgs a;
     std::memset(&a, 0, sizeof(a));
     a.in = in; a.out = out;
-    a.tw1 = ps.st->tw1.p; a.tw2 = ps.st2->tw1.p;
+    const bool rows = (ps.mode == MODE_ROWS);
+    a.tw1 = ps.st->tw1.p; a.tw2 = rows ? ps.st->tw2.p : ps.st2->tw1.p;
     a.tw_lo = ps.tw_lo.p; a.tw_hi = ps.tw_hi.p;
     a.mul = wtab; a.blu_x = xtab; a.blu_n = n_user; a.blu_swap = inverse;
-    a.n = n_; a.scale = scale; a.nxcd = nxcd;
-    if (batch > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");
+    a.n = n_; a.scale = scale; a.nxcd = nxcd; a.total_cols = batch;
+    const uint64_t grid = rows ? (batch + blu_small_.COLS - 1) / blu_small_.COLS : batch;
+    if (grid > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");
     PROF_BEGIN(prof, 0);
-    FOURIER_LAUNCH(blu_small_.fn, batch, blu_small_.NT, blu_small_.smem, stream, a);
+    FOURIER_LAUNCH(blu_small_.fn, grid, blu_small_.NT, blu_small_.smem, stream, a);
     PROF_END(prof);
   }
 

@@ -671,6 +671,131 @@ __device__ __forceinline__ void twolevel_core(cpx<T> (*x)[16], int tid, unsigned
   two_stage_fft<T, L2, CG2>(xr, th2, cg2, smem, tw1_b, site + 12);
 }
 
+// L-point FFT (16 <= L <= 1024) of register-resident columns with up to three stages (16 x R2 x R3), the
+// row-kernel's core as a chainable function: register r holds position th + Q*r on entry AND on exit
+// (natural order), so two calls can follow each other without any re-layout.
+template <typename T, int L, int CG>
+__device__ __forceinline__ void rows_fft(RegTile<T, L, CG>& x, int th, int cg, unsigned char* smem, const cpx<T>* tw1,
+                                         const cpx<T>* tw2, unsigned site) {
+  using C = TileCfg<T, L, CG>;
+  constexpr int VEC = C::VEC, Q = C::Q, R2 = C::R2, R3 = C::R3;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) dft16(x[v]);
+  if constexpr (Q > 1) {
+    const cpx<T>* t1 = tw1 + th * 16;
+    FOURIER_SCHED_FENCE();
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+      const cpx<T> w = t1[k];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) x[v][k] = cmul(x[v][k], w);
+      if ((k & 3) == 3) FOURIER_SCHED_FENCE();
+    }
+    lds_exchange<T, L, CG, 0>(x, smem, cg, [=](int r) { return 16 * th + r; }, th, cg, site);
+    FOURIER_SCHED_FENCE();
+    constexpr int NB2 = 16 / R2;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+#pragma unroll
+      for (int u = 0; u < NB2; ++u) {
+        cpx<T> t[R2];
+#pragma unroll
+        for (int k = 0; k < R2; ++k) t[k] = x[v][u + NB2 * k];
+        dft_r<T, R2>(t);
+#pragma unroll
+        for (int k = 0; k < R2; ++k) x[v][u + NB2 * k] = t[k];
+      }
+    if constexpr (R3 > 1) {
+      const cpx<T>* t2 = tw2 + (th >> 4) * 16;
+#pragma unroll
+      for (int k = 1; k < 16; ++k) {
+        const cpx<T> w = t2[k];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) x[v][k] = cmul(x[v][k], w);
+        if ((k & 3) == 3) FOURIER_SCHED_FENCE();
+      }
+      const int jw = th & 15, iw = th >> 4;
+      __syncthreads();
+      lds_exchange<T, L, CG, 0>(x, smem, cg, [=](int r) { return jw + 16 * (16 * iw + r); }, th, cg, site + 4);
+      constexpr int NB3 = 16 / R3;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v)
+#pragma unroll
+        for (int u = 0; u < NB3; ++u) {
+          cpx<T> t[R3];
+#pragma unroll
+          for (int k = 0; k < R3; ++k) t[k] = x[v][u + NB3 * k];
+          dft_r<T, R3>(t);
+#pragma unroll
+          for (int k = 0; k < R3; ++k) x[v][u + NB3 * k] = t[k];
+        }
+    }
+  }
+}
+
+// ---- whole Bluestein chirp-z in ONE launch for M = L <= 1024: COLS transforms per workgroup ----
+// Same chain as bluestein_small_kernel with the row core: x(.)in -> FFT_M -> (.)w -> swap -> FFT_M -> swap
+// -> (.)x(.)scale; lane-contiguous 8/16-byte accesses to the N-point user arrays.
+template <typename T, int L, int CG>
+__global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG)) bluestein_rows_kernel(PassArgs a) {
+  using C = TileCfg<T, L, CG>;
+  constexpr int VEC = C::VEC, Q = C::Q, COLS = C::COLS;
+  FOURIER_DYN_SMEM(smem);
+  const int tid = (int)threadIdx.x;
+  const int th = tid % Q, cg = tid / Q;
+  const uint32_t n = (uint32_t)a.blu_n;
+  const uint64_t g0 = (uint64_t)blockIdx.x * COLS;
+  const cpx<T>* __restrict__ xt = (const cpx<T>*)a.blu_x;
+  const cpx<T>* __restrict__ wt = (const cpx<T>*)a.mul;
+  cpx<T> x[VEC][16];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    const uint64_t g = g0 + (uint64_t)(cg * VEC + v);
+    const bool valid = g < a.total_cols;
+    const cpx<T>* p = (const cpx<T>*)a.in + g * a.blu_n;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const uint32_t pos = (uint32_t)(th + Q * r);
+      cpx<T> val{0, 0};
+      if (valid && pos < n) {
+        val = p[pos];
+        if (a.blu_swap) val = {val.im, val.re};
+        val = cmul(xt[pos], val);
+      }
+      x[v][r] = val;
+    }
+  }
+  rows_fft<T, L, CG>(x, th, cg, smem, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw2, 0);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const cpx<T> w = wt[th + Q * r];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const cpx<T> y = cmul(x[v][r], w);
+      x[v][r] = {y.im, y.re};
+    }
+  }
+  if constexpr (Q > 1) __syncthreads();
+  rows_fft<T, L, CG>(x, th, cg, smem, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw2, 16);
+  const T scale = (T)a.scale;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    const uint64_t g = g0 + (uint64_t)(cg * VEC + v);
+    if (g >= a.total_cols) continue;
+    cpx<T>* p = (cpx<T>*)a.out + g * a.blu_n;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const uint32_t pos = (uint32_t)(th + Q * r);
+      if (pos < n) {
+        cpx<T> y{x[v][r].im, x[v][r].re};
+        y = cmul(y, xt[pos]);
+        if (a.blu_swap) y = {y.im, y.re};
+        p[pos] = {y.re * scale, y.im * scale};
+      }
+    }
+  }
+}
+
 #define FOURIER_TWOLEVEL_NT(T, L1, L2) ((L1 / 16) * (L2 / (16 / (2 * (int)sizeof(T)))))
 
 template <typename T, int L1, int L2>

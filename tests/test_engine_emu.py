@@ -146,7 +146,7 @@ def test_bluestein_fusion_matches_unfused(fa):
     """The fused Bluestein forms (whole chirp-z in one launch for M <= 2^15; chirp steps fused into the
     inner passes above) give the same values, to rounding, as the separate blu_pre / blu_post sweeps
     (bluesteins.rs:229-258), for every transform code, in and out of place."""
-    for n in (1025, 3000, 40000):
+    for n in (10, 100, 439, 1025, 3000, 40000):
         x = np.stack([hash_normal(70 + b, n) for b in range(2)]).astype(np.complex64)
         fused, plain = make(fa, n, np.complex64), make(fa, n, np.complex64)
         plain.set_option("bluestein_fusion", 0)
@@ -256,7 +256,8 @@ def test_profile_hook_reports_every_kernel(fa):
     y1 = np.empty_like(x1)
     assert [p[0] for p in one.profile_batch_ptr(x1.ctypes.data, y1.ctypes.data, 1, 0)] == ["pass0"]
     assert rel_l2(y[0], np.fft.fft(x[0].astype(np.complex128))) <= 1e-6
-    planb = make(fa, 100, np.complex64)  # M = 256: separate chirp kernels around a row-kernel inner FFT
+    planb = make(fa, 100, np.complex64)  # M = 256; with fusion off: separate chirp kernels around the inner FFT
+    planb.set_option("bluestein_fusion", 0)
     xb = hash_normal(1, 100).astype(np.complex64)[None, :]
     yb = np.empty_like(xb)
     names = [p[0] for p in planb.profile_batch_ptr(xb.ctypes.data, yb.ctypes.data, 1, 0)]

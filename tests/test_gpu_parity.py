@@ -173,7 +173,7 @@ def test_mixed_radix_sizes_are_bit_identical_to_the_oracle(torch, fa, oracle):
 
 
 def test_bluestein_fusion_matches_unfused(torch, fa):
-    for n in (1025, 3125, 10007, 999983):  # one-launch chirp-z (M <= 2^15) and pass-fused (M = 2^21)
+    for n in (10, 125, 439, 1025, 3125, 10007, 999983):  # one-launch chirp-z (M <= 2^15) and pass-fused (M = 2^21)
         x = np.stack([hash_uniform(70 + b, n) for b in range(2)]).astype(np.complex64)
         fused, plain = make(fa, n, np.complex64), make(fa, n, np.complex64)
         plain.set_option("bluestein_fusion", 0)
