@@ -179,8 +179,9 @@ template <typename T, int L1, int L2> static KernelInfo make_twolevel_info() {
   k.smem = CA::EXCH_BYTES > CB::EXCH_BYTES ? CA::EXCH_BYTES : CB::EXCH_BYTES;
   return k;
 }
-// single-launch plans: 2^11 = 64x32 (72 % of HBM peak vs 57 % for the row kernel), 2^12 = 64x64, 2^13 = 128x64, 2^14 = 128x128, 2^15 = 256x128 (f32 only: the
-// transform must fit one workgroup's registers, 1024 threads x 16 points x VEC)
+// single-launch plans: 2^11 = 64x32 (72 % of the HBM peak vs 57 % for the row kernel), 2^12 = 64x64,
+// 2^13 = 128x64, 2^14 = 128x128, 2^15 = 256x128 (f32 only: the transform must fit one workgroup's
+// registers, at most 1024 threads x 16 points x VEC)
 template <typename T> static bool get_twolevel_kernel(int k, KernelInfo& info, int& l1, int& l2) {
   switch (k) {
     case 11: info = make_twolevel_info<T, 64, 32>(); l1 = 64; l2 = 32; return true;
@@ -233,8 +234,7 @@ static inline bool is_pow2(uint64_t v) { return v && !(v & (v - 1)); }
 // exp(-2*pi*i*e/size) in f64 (the reference evaluates twiddles in f64 and casts: twiddle.rs:7-19)
 static inline void unit_root(uint64_t e, uint64_t size, double& re, double& im) {
   e %= size;
-  // octant reduction keeps the argument small so the f64 result is correctly rounded to ~1 ulp
-  const double frac = (double)e / (double)size;  // exact for power-of-two sizes
+  const double frac = (double)e / (double)size;  // exact for power-of-two sizes; the quarter turns are exact below
   const double ang = 2.0 * M_PI * frac;
   re = std::cos(ang);
   im = -std::sin(ang);

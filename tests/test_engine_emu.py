@@ -176,6 +176,24 @@ def test_one_launch_plans_match_the_two_launch_plans(fa, monkeypatch):
     assert "one-launch" not in make(fa, 1 << 15, np.complex128).describe()  # f64 2^15 does not fit a workgroup
 
 
+def test_random_sizes_batches_codes_vs_oracle(fa, oracle):
+    """Seeded random sweep over every plan family (tiny, row, one-launch, mixed-radix, all Bluestein forms):
+    random size, batch, transform code, precision, in/out of place -- against the CPU restatement."""
+    rng = np.random.default_rng(20260926)
+    sizes = [int(v) for v in rng.integers(1, 6000, 28)] + [4096 + 1, 8192, 12345]
+    for n in sizes:
+        dtype = np.complex64 if rng.integers(0, 2) else np.complex128
+        batch = int(rng.integers(1, 5))
+        code = int(rng.integers(0, 5))
+        x = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(dtype)
+        plan = make(fa, n, dtype)
+        ref = oracle.transform_batch(x, code)
+        tol = 2e-6 if dtype == np.complex64 else 1e-11  # f64: the oracle's own unreduced-chirp error dominates
+        for inplace in (False, True):
+            got = run_batch(plan, x, code, inplace)
+            assert rel_l2(got, ref) <= tol, (n, plan.describe(), batch, code, inplace, rel_l2(got, ref))
+
+
 def test_three_pass_plan(fa):
     # 2^23 = 256 x 256 x 128: exercises the middle (uniform-twiddle) pass
     n = 1 << 23

@@ -183,6 +183,24 @@ def test_bluestein_fusion_matches_unfused(torch, fa):
             assert np.array_equal(gpu_batch(torch, fa, fused, x, code, inplace=True), a), (n, code)
 
 
+def test_random_sizes_batches_codes_vs_oracle(torch, fa, oracle):
+    """Seeded random sweep over every plan family: random size (1..70000), batch, transform code, precision,
+    in/out of place, against the CPU restatement of the reference."""
+    rng = np.random.default_rng(20260926)
+    sizes = [int(v) for v in rng.integers(1, 6000, 150)] + [int(v) for v in rng.integers(6000, 70000, 40)]
+    for n in sizes:
+        dtype = np.complex64 if rng.integers(0, 2) else np.complex128
+        batch = int(rng.integers(1, 9))
+        code = int(rng.integers(0, 5))
+        x = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(dtype)
+        plan = make(fa, n, dtype)
+        ref = oracle.transform_batch(x, code)
+        tol = 2e-6 if dtype == np.complex64 else 5e-11
+        for inplace in (False, True):
+            got = gpu_batch(torch, fa, plan, x, code, inplace)
+            assert rel_l2(got, ref) <= tol, (n, plan.describe(), batch, code, inplace, rel_l2(got, ref))
+
+
 def test_three_pass_size(torch, fa):
     n = 1 << 23
     plan = make(fa, n, np.complex64)
