@@ -228,6 +228,17 @@ template <typename T> static bool get_blu_small_kernel(int k, KernelInfo& info) 
   }
 }
 
+enum { MODE_ODD_LAST = 5 };  // host-side tag for odd_last_kernel (final radix-3^b pass of a 2^a*3^b plan)
+typedef void (*OddKernel)(OddArgs);
+template <typename T> static OddKernel get_odd_kernel(int r) {
+  switch (r) {
+    case 3: return &odd_last_kernel<T, 3>;
+    case 9: return &odd_last_kernel<T, 9>;
+    case 27: return &odd_last_kernel<T, 27>;
+    default: return nullptr;
+  }
+}
+
 static inline int ilog2(uint64_t v) { int l = 0; while ((1ull << l) < v) ++l; return l; }
 static inline bool is_pow2(uint64_t v) { return v && !(v & (v - 1)); }
 
@@ -280,19 +291,33 @@ template <typename T> class Pow2Engine {
     KernelInfo k_blu;  // IO_BLU_IN variant of a FIRST pass / IO_BLU_OUT variant of a LAST pass (lazy)
     bool has_blu = false;
     StageTables<T>* st2 = nullptr;  // MODE_TWOLEVEL: stage tables of the second pass length
+    OddKernel odd_fn = nullptr;     // MODE_ODD_LAST
+    int odd_r = 0;
     uint64_t s, size, cn;
     uint32_t lo_bits = 0;
     DevBuf tw_lo, tw_hi;
     StageTables<T>* st = nullptr;
   };
 
+  // Large mixed sizes N = 2^a * 3^b (12 <= a <= 30, 1 <= b <= 3): the 2^a part runs as big-radix passes
+  // (FIRST, MID...), the 3^b part as one final odd-radix Stockham pass -- the reference's own order, radix 3
+  // after the powers of two (RADICES = [4,8,4,3,2], autosort/mod.rs:21).
+  static bool handles_mixed(size_t n) {
+    size_t p3 = 1;
+    while (n % 3 == 0 && p3 < 27) { n /= 3; p3 *= 3; }
+    return p3 > 1 && is_pow2(n) && n >= 4096 && n <= ((size_t)1 << 30);
+  }
+
   explicit Pow2Engine(size_t n) : n_(n) {
-    if (!is_pow2(n)) throw EngineError(::fourier::c::FOURIER_HIP_INVALID_ARGUMENT, "Pow2Engine: size not a power of two");
-    const int k = ilog2(n);
+    size_t p3 = 1, p2 = n;
+    while (p2 % 3 == 0 && p3 < 27) { p2 /= 3; p3 *= 3; }
+    if (!is_pow2(p2) || (p3 > 1 && p2 < 4096))
+      throw EngineError(::fourier::c::FOURIER_HIP_INVALID_ARGUMENT, "StockhamEngine: size must be 2^a or 2^a*3^b (a >= 12, b <= 3)");
+    const int k = ilog2(p2);
     std::vector<int> lens;
     KernelInfo tl;
     int tl1 = 0, tl2 = 0;
-    if (!getenv("FOURIER_NO_TWOLEVEL") && get_twolevel_kernel<T>(k, tl, tl1, tl2)) {
+    if (p3 == 1 && !getenv("FOURIER_NO_TWOLEVEL") && get_twolevel_kernel<T>(k, tl, tl1, tl2)) {
       // one launch, one HBM round trip: both passes inside a workgroup
       auto pass = std::unique_ptr<Pass>(new Pass());
       pass->mode = MODE_TWOLEVEL;
@@ -339,7 +364,7 @@ template <typename T> class Pow2Engine {
     for (size_t p = 0; p < lens.size(); ++p) {
       auto pass = std::unique_ptr<Pass>(new Pass());
       const int L = 1 << lens[p];
-      pass->mode = lens.size() == 1 ? MODE_ROWS : (p == 0 ? MODE_FIRST : (p + 1 == lens.size() ? MODE_LAST : MODE_MID));
+      pass->mode = lens.size() == 1 ? MODE_ROWS : (p == 0 ? MODE_FIRST : (p + 1 == lens.size() && p3 == 1 ? MODE_LAST : MODE_MID));
       pass->k = get_kernel<T>(L, pass->mode);
       pass->s = s; pass->size = size; pass->cn = n / L;
       if (pass->mode != MODE_ROWS) {
@@ -360,13 +385,21 @@ template <typename T> class Pow2Engine {
       s *= (uint64_t)L;
       size /= (uint64_t)L;
     }
+    if (p3 > 1) {  // final odd-radix pass: size == R == p3, stride s == 2^a
+      auto pass = std::unique_ptr<Pass>(new Pass());
+      pass->mode = MODE_ODD_LAST;
+      pass->odd_r = (int)p3;
+      pass->odd_fn = get_odd_kernel<T>((int)p3);
+      pass->s = s; pass->size = size; pass->cn = n / p3;
+      passes_.push_back(std::move(pass));
+    }
   }
 
   // two-level table of W_size^{e}: e = (e >> lo_bits) << lo_bits | (e & mask)
   static void make_two_level(Pass& pass, uint64_t size) {
     const int lb = (ilog2(size) + 1) / 2;
     pass.lo_bits = (uint32_t)lb;
-    std::vector<cpx<T>> lo((size_t)1 << lb), hi((size_t)(size >> lb));
+    std::vector<cpx<T>> lo((size_t)1 << lb), hi((size_t)(size >> lb) + 1);  // +1: size need not be a power of two
     for (size_t e = 0; e < lo.size(); ++e) { double re, im; unit_root(e, size, re, im); lo[e] = {(T)re, (T)im}; }
     for (size_t h = 0; h < hi.size(); ++h) { double re, im; unit_root((uint64_t)h << lb, size, re, im); hi[h] = {(T)re, (T)im}; }
     pass.tw_lo.upload(lo);
@@ -441,12 +474,13 @@ template <typename T> class Pow2Engine {
 
   size_t size() const { return n_; }
   size_t num_passes() const { return tiny_ ? 1 : passes_.size(); }
-  bool needs_scratch(bool in_place) const { return passes_.size() == 3 || (passes_.size() == 2 && in_place); }
+  bool needs_scratch(bool in_place) const { return passes_.size() >= 3 || (passes_.size() == 2 && in_place); }
   std::string describe() const {
     if (tiny_) return "tiny(" + std::to_string(n_) + ")";
     if (!desc_override_.empty()) return desc_override_;
     std::string d;
-    for (size_t p = 0; p < passes_.size(); ++p) d += (p ? "x" : "") + std::to_string(passes_[p]->k.L);
+    for (size_t p = 0; p < passes_.size(); ++p)
+      d += (p ? "x" : "") + std::to_string(passes_[p]->mode == MODE_ODD_LAST ? passes_[p]->odd_r : passes_[p]->k.L);
     return d;
   }
 
@@ -474,19 +508,40 @@ template <typename T> class Pow2Engine {
     }
     const size_t np = passes_.size();
     const bool in_place = ((const void*)in == (const void*)out);
-    const cpx<T>* src[3] = {in, nullptr, nullptr};
-    cpx<T>* dst[3] = {out, nullptr, nullptr};
-    if (np == 2) {
-      cpx<T>* X = (in_place || force_scratch || blu.io == IO_BLU_OUT) ? scratch : out;
-      dst[0] = X; src[1] = X; dst[1] = out;
-    } else if (np == 3) {
-      if (blu.io == IO_BLU_OUT) {  // the user-side output is shorter than n: never use it as an intermediate
-        dst[0] = scratch; src[1] = scratch; dst[1] = (cpx<T>*)in; src[2] = in; dst[2] = out;
-      } else if (in_place) { dst[0] = scratch; src[1] = scratch; dst[1] = out; src[2] = out; dst[2] = out; }
-      else { dst[0] = out; src[1] = out; dst[1] = scratch; src[2] = scratch; dst[2] = out; }
+    // Every pass but the last is out of place (its tile footprints differ between input and output); the
+    // last one (LAST / ODD_LAST / ROWS / TWOLEVEL) may run in place.  Ping-pong between `out` and the
+    // scratch so that the final result lands in `out` and `in` is never written.
+    const cpx<T>* src[8] = {in};
+    cpx<T>* dst[8] = {out};
+    if (np > 8) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "too many passes");
+    if (np >= 2) {
+      const bool start_scratch = in_place || blu.io == IO_BLU_OUT || (force_scratch && np == 2);
+      for (size_t p = 0; p + 1 < np; ++p) {
+        const bool to_scratch = start_scratch ? (p % 2 == 0) : (p % 2 == 1);
+        dst[p] = to_scratch ? scratch : out;
+        if (blu.io == IO_BLU_OUT && !to_scratch) dst[p] = (cpx<T>*)in;  // user-side output is shorter than n
+        src[p + 1] = dst[p];
+      }
+      dst[np - 1] = out;
     }
     for (size_t p = 0; p < np; ++p) {
       const Pass& ps = *passes_[p];
+      if (ps.mode == MODE_ODD_LAST) {
+        OddArgs o;
+        std::memset(&o, 0, sizeof(o));
+        o.in = src[p]; o.out = dst[p]; o.mul = mul;
+        o.n = n_; o.s = ps.s; o.batch = batch;
+        o.swap_out = inverse; o.scale = scale;
+        for (int e = 0; e < ps.odd_r; ++e) unit_root((uint64_t)e, (uint64_t)ps.odd_r, o.wr[e], o.wi[e]);
+        constexpr int VEC = 16 / (2 * (int)sizeof(T));
+        const uint64_t threads = (uint64_t)batch * (ps.s / VEC);
+        const uint64_t grid = (threads + 255) / 256;
+        if (grid > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");
+        PROF_BEGIN(prof, slot0 + (int)p);
+        FOURIER_LAUNCH(ps.odd_fn, grid, 256, 0, stream, o);
+        PROF_END(prof);
+        continue;
+      }
       PassArgs a;
       std::memset(&a, 0, sizeof(a));
       a.in = src[p]; a.out = dst[p];
@@ -662,6 +717,9 @@ template <typename T> class Plan {
     } else if (MixedEngine<T>::handles(n)) {
       mix_.reset(new MixedEngine<T>(n));
       desc_ = "stockham mixed-radix " + mix_->describe();
+    } else if (Pow2Engine<T>::handles_mixed(n)) {
+      eng_.reset(new Pow2Engine<T>(n));  // big-radix passes over the 2^a part, then a radix-3^b pass
+      desc_ = "stockham " + eng_->describe();
     } else {
       init_bluestein();
       desc_ = "bluestein M=" + std::to_string(m_) + " inner " + eng_->describe() + (small_fused_ ? " fused" : "");

@@ -1090,6 +1090,88 @@ __global__ void __launch_bounds__(256) mixed_radix_kernel(MixArgs a) {
   }
 }
 
+// ---- final odd-radix Stockham pass for large N = 2^a * 3^b: R = 3^b in {3, 9, 27}, s = 2^a, m = 1 ----
+// out[j + s*k] = DFT_R(in[j + s*k'])_k  (autosort/mod.rs:203-284 with size == R: no twiddle, :238).  The
+// reference reaches radix 3 last as well (RADICES = [4,8,4,3,2], mod.rs:21).  One thread owns VEC adjacent
+// columns j (one 16-byte unit per row) and all R rows: fully coalesced, in place allowed.
+struct OddArgs {
+  const void* in; void* out; const void* mul;
+  uint64_t n, s, batch;       // transform length, stride (= n / R), transforms
+  int swap_out;
+  double scale;
+  double wr[27], wi[27];      // W_R^e = exp(-2*pi*i*e/R), e < R (f64 on the host, cast on use)
+};
+
+// radix-3 butterfly, forward: W3 = -1/2 - i*sqrt(3)/2 (the values of butterfly.rs:9-22, regrouped)
+template <typename T> __device__ __forceinline__ void dft3(cpx<T>& a, cpx<T>& b, cpx<T>& c) {
+  const T h = (T)0.86602540378443864676;
+  const cpx<T> s = {b.re + c.re, b.im + c.im}, d = {b.re - c.re, b.im - c.im};
+  const cpx<T> m = {a.re - (T)0.5 * s.re, a.im - (T)0.5 * s.im};
+  const cpx<T> r = {h * d.im, -h * d.re};  // -i*h*d
+  a = {a.re + s.re, a.im + s.im};
+  b = {m.re + r.re, m.im + r.im};
+  c = {m.re - r.re, m.im - r.im};
+}
+// natural-order DFT of R = 3^b points at x[0], x[STRIDE], ... using the table W_RT^e (RT = top-level radix)
+template <typename T, int R, int RT, int STRIDE>
+__device__ __forceinline__ void dft_pow3(cpx<T>* x, const OddArgs& a) {
+  if constexpr (R == 3) {
+    dft3(x[0], x[STRIDE], x[2 * STRIDE]);
+  } else {
+    constexpr int M = R / 3;
+    // decimation in time: sub-transforms over n = 3*q + c (c = 0,1,2)
+    cpx<T> e[3][M];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+      for (int q = 0; q < M; ++q) e[c][q] = x[(3 * q + c) * STRIDE];
+      dft_pow3<T, M, RT, 1>(e[c], a);
+    }
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+      cpx<T> u = e[0][k];
+      cpx<T> v = cmul(e[1][k], cpx<T>{(T)a.wr[(RT / R) * k], (T)a.wi[(RT / R) * k]});
+      cpx<T> w = cmul(e[2][k], cpx<T>{(T)a.wr[(RT / R) * 2 * k], (T)a.wi[(RT / R) * 2 * k]});
+      dft3(u, v, w);
+      x[k * STRIDE] = u; x[(k + M) * STRIDE] = v; x[(k + 2 * M) * STRIDE] = w;
+    }
+  }
+}
+
+template <typename T, int R>
+__global__ void __launch_bounds__(256) odd_last_kernel(OddArgs a) {
+  constexpr int VEC = 16 / (2 * (int)sizeof(T));
+  const uint64_t units = a.s / VEC;                       // 16-byte units per row
+  const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= a.batch * units) return;
+  const uint64_t b = gid / units, u = gid - b * units;
+  const cpx<T>* in = (const cpx<T>*)a.in + b * a.n + u * VEC;
+  cpx<T>* out = (cpx<T>*)a.out + b * a.n + u * VEC;
+  cpx<T> x[VEC][R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const Unit16<T> v = load_unit<T, false>(in + (uint64_t)k * a.s);
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) x[c][k] = {v.a[2 * c], v.a[2 * c + 1]};
+  }
+#pragma unroll
+  for (int c = 0; c < VEC; ++c) dft_pow3<T, R, R, 1>(x[c], a);
+  const T scale = (T)a.scale;
+  const cpx<T>* mul = (const cpx<T>*)a.mul;
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    Unit16<T> v;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      cpx<T> y = x[c][k];
+      if (mul) y = cmul(y, mul[u * VEC + c + (uint64_t)k * a.s]);
+      if (a.swap_out) y = {y.im, y.re};
+      v.a[2 * c] = y.re * scale; v.a[2 * c + 1] = y.im * scale;
+    }
+    store_unit<T, FOURIER_NT_STORE>(out + (uint64_t)k * a.s, v);
+  }
+}
+
 // ---- Bluestein chirp-z pointwise steps (reference: fourier-algorithms/src/bluesteins.rs:229-258) ----
 struct BluArgs {
   const void* in; void* out; const void* xtab;

@@ -142,6 +142,22 @@ def test_mixed_radix_sizes_are_bit_identical_to_the_oracle(fa, oracle):
     assert "bluestein" in make(fa, 6144, np.complex64).describe()  # above the LDS-resident limit
 
 
+def test_large_mixed_radix_sizes_run_natively(fa, oracle):
+    """N = 2^a*3^b (a >= 12, b <= 3): big-radix passes over the 2^a part + one final radix-3^b Stockham pass
+    (the reference's order, RADICES = [4,8,4,3,2]); every code, in and out of place, against the oracle."""
+    for n, want in ((3 * 4096, "64x64x3"), (9 * 8192, "128x64x9"), (27 * 4096, "64x64x27")):
+        x = np.stack([hash_normal(80 + b, n) for b in range(2)])
+        for dtype, tl2 in ((np.complex64, 1e-6), (np.complex128, 5e-14)):
+            plan = make(fa, n, dtype)
+            assert plan.describe().startswith("stockham " + want), plan.describe()
+            for code in range(5):
+                ref = oracle.transform_batch(x.astype(dtype), code)
+                assert rel_l2(run_batch(plan, x.astype(dtype), code), ref) <= tl2, (n, code)
+                assert rel_l2(run_batch(plan, x.astype(dtype), code, inplace=True), ref) <= tl2, (n, code)
+    assert "bluestein" in make(fa, 81 * 4096, np.complex64).describe()  # 3^4: beyond the odd pass's radices
+    assert "bluestein" in make(fa, 3 * 2048, np.complex64).describe()   # too little 2^a for two tiled passes
+
+
 def test_bluestein_fusion_matches_unfused(fa):
     """The fused Bluestein forms (whole chirp-z in one launch for M <= 2^15; chirp steps fused into the
     inner passes above) give the same values, to rounding, as the separate blu_pre / blu_post sweeps

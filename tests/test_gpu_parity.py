@@ -172,6 +172,22 @@ def test_mixed_radix_sizes_are_bit_identical_to_the_oracle(torch, fa, oracle):
                                   oracle.transform_batch(x.astype(dtype), 0)), n
 
 
+@pytest.mark.parametrize("n", [3 * 4096, 9 * 4096, 27 * 4096, 3 * (1 << 15), 9 * (1 << 16), 3 * (1 << 18), 27 * (1 << 16), 3 * (1 << 23)])
+def test_large_mixed_radix_sizes_vs_oracle(torch, fa, oracle, n):
+    """2^a*3^b (a >= 12, b <= 3) natively: big-radix passes + a final radix-3^b pass."""
+    x = np.stack([hash_uniform(90 + b, n) for b in range(2)])
+    for dtype, tl2 in ((np.complex64, 1e-6), (np.complex128, 5e-14)):
+        if n > (1 << 24) and dtype == np.complex128:
+            continue
+        plan = make(fa, n, dtype)
+        assert plan.describe().startswith("stockham") and "x3" in plan.describe().replace("x9", "x3").replace("x27", "x3")
+        for code in (0, 1, 3):
+            ref = oracle.transform_batch(x.astype(dtype), code, nthreads=2)
+            assert rel_l2(gpu_batch(torch, fa, plan, x.astype(dtype), code), ref) <= tl2, (n, code)
+        assert rel_l2(gpu_batch(torch, fa, plan, x.astype(dtype), 0, inplace=True),
+                      oracle.transform_batch(x.astype(dtype), 0, nthreads=2)) <= tl2
+
+
 def test_bluestein_fusion_matches_unfused(torch, fa):
     for n in (10, 125, 439, 1025, 3125, 10007, 999983):  # one-launch chirp-z (M <= 2^15) and pass-fused (M = 2^21)
         x = np.stack([hash_uniform(70 + b, n) for b in range(2)]).astype(np.complex64)

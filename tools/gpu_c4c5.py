@@ -35,6 +35,9 @@ if __name__ == "__main__":
     run("C4 f64 fused", 999983, 256, "f64")
     run("prime 65537", 65537, 8192)
     run("mixed 3*2^18", 3 << 18, 1024)
+    run("mixed 9*2^16", 9 << 16, 1024)
+    run("mixed 27*2^14", 27 << 14, 2048)
+    run("mixed 3*2^12", 3 << 12, 65536)
     run("C5 chunk 2^22", 1 << 22, 1024)
     run("2^21", 1 << 21, 1024)
     run("2^24 3-pass", 1 << 24, 128)
