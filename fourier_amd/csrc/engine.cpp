@@ -592,7 +592,8 @@ template <typename T> class Pow2Engine {
 // small mixed-radix sizes (2^a * 3^b, b > 0, N <= 4096): the reference's own schedule and tables
 template <typename T> class MixedEngine {
  public:
-  static constexpr size_t MAX_N = 4096;
+  // both LDS ping-pong buffers of one transform must fit a workgroup: 2 * N * sizeof(complex) <= 144 KiB
+  static constexpr size_t MAX_N = (144 * 1024) / (2 * sizeof(cpx<T>));  // 9216 (f32), 4608 (f64)
   // autosort/mod.rs:104-116: one radix-4 first when divisible, then greedily 8, 4, 3, 2
   static bool factor(size_t size, uint32_t counts[5]) {
     static const size_t radices[5] = {4, 8, 4, 3, 2};

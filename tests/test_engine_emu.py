@@ -139,7 +139,11 @@ def test_mixed_radix_sizes_are_bit_identical_to_the_oracle(fa, oracle):
                 ref = oracle.transform_batch(x.astype(dtype), code)
                 assert np.array_equal(run_batch(plan, x.astype(dtype), code), ref), (n, dtype, code)
                 assert np.array_equal(run_batch(plan, x.astype(dtype), code, inplace=True), ref), (n, dtype, code)
-    assert "bluestein" in make(fa, 6144, np.complex64).describe()  # above the LDS-resident limit
+    assert "mixed-radix" in make(fa, 6144, np.complex64).describe()  # 2 x 48 KiB of LDS
+    assert "bluestein" in make(fa, 6144, np.complex128).describe()   # f64: above the LDS-resident limit (4608)
+    for n, dtype in ((6144, np.complex64), (9216, np.complex64), (4608, np.complex128)):
+        xb = np.stack([hash_normal(21 + b, n) for b in range(2)]).astype(dtype)
+        assert np.array_equal(run_batch(make(fa, n, dtype), xb, 0), oracle.transform_batch(xb, 0)), n
 
 
 def test_large_mixed_radix_sizes_run_natively(fa, oracle):
@@ -155,7 +159,7 @@ def test_large_mixed_radix_sizes_run_natively(fa, oracle):
                 assert rel_l2(run_batch(plan, x.astype(dtype), code), ref) <= tl2, (n, code)
                 assert rel_l2(run_batch(plan, x.astype(dtype), code, inplace=True), ref) <= tl2, (n, code)
     assert "bluestein" in make(fa, 81 * 4096, np.complex64).describe()  # 3^4: beyond the odd pass's radices
-    assert "bluestein" in make(fa, 3 * 2048, np.complex64).describe()   # too little 2^a for two tiled passes
+    assert "bluestein" in make(fa, 3 * 2048, np.complex128).describe()  # too little 2^a for two tiled passes
 
 
 def test_bluestein_fusion_matches_unfused(fa):
