@@ -112,6 +112,7 @@ struct PassArgs {
   uint64_t total_cols;  // ROWS mode: number of transforms in this launch
   uint32_t lo_bits;
   uint32_t nxcd;      // >1: remap blockIdx so that each XCD (blockIdx % nxcd) walks a contiguous tile range
+  uint32_t xcd_interleave;  // 1: XCD x takes every nxcd-th transform instead of a contiguous 1/nxcd of the batch
   const void* blu_x;  // Bluestein chirp table x[0..blu_n) (IO_BLU_IN / IO_BLU_OUT)
   uint64_t blu_n;     // user transform length (batch stride of the user-side buffer)
   int blu_swap;       // user-level inverse: swap re/im of the user data
@@ -320,8 +321,15 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
   // with tools/membench.py --xcd).  Bijective for any grid size; affects speed only.
   uint64_t blk = blockIdx.x;
   if (a.nxcd > 1) {
-    const uint64_t nwg = gridDim.x, nx = a.nxcd, xcd = blk % nx, q = nwg / nx, r = nwg % nx;
-    blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + blk / nx;
+    const uint64_t nwg = gridDim.x, nx = a.nxcd, xcd = blk % nx;
+    if (a.xcd_interleave && a.tiles > 0 && nwg % (nx * a.tiles) == 0) {
+      // XCD x takes transforms x, x + 8, x + 16, ...: the eight XCDs work on eight ADJACENT transforms
+      const uint64_t slot = blk / nx;
+      blk = ((slot / a.tiles) * nx + xcd) * a.tiles + slot % a.tiles;
+    } else {
+      const uint64_t q = nwg / nx, r = nwg % nx;
+      blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + blk / nx;
+    }
   }
   const cpx<T>* __restrict__ in = (const cpx<T>*)a.in;
   cpx<T>* __restrict__ out = (cpx<T>*)a.out;
