@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #endif
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -167,6 +168,28 @@ template <typename T> static KernelInfo get_kernel(int L, int mode, int io = IO_
   throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "no kernel for pass length " + std::to_string(L));
 }
 
+// fft_conv_kernel: forward LAST + (.) w + inverse FIRST of a Bluestein plan, same tile shapes as the passes
+template <typename T, int L, int CG> static KernelInfo make_conv_info() {
+  using C = TileCfg<T, L, CG>;
+  KernelInfo k;
+  k.fn = &fft_conv_kernel<T, L, CG>;
+  k.L = L; k.CG = CG; k.NT = C::NT; k.COLS = C::COLS; k.R3 = C::R3;
+  k.smem = C::smem_bytes(MODE_FIRST);
+  return k;
+}
+template <typename T> static KernelInfo get_conv_kernel(int L) {
+  switch (L) {
+    case 64: return make_conv_info<T, 64, 16>();
+    case 128: return make_conv_info<T, 128, 16>();
+    case 256: return make_conv_info<T, 256, 16>();
+    case 512: return make_conv_info<T, 512, FOURIER_CG_512>();
+    case 1024: return make_conv_info<T, 1024, FOURIER_CG_1024>();
+    case 2048: return make_conv_info<T, 2048, FOURIER_CG_2048>();
+    default: break;
+  }
+  throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "no conv kernel for pass length " + std::to_string(L));
+}
+
 enum { MODE_TWOLEVEL = 4 };  // host-side tag for fft_twolevel_kernel (both passes in one launch)
 
 template <typename T, int L1, int L2> static KernelInfo make_twolevel_info() {
@@ -308,7 +331,9 @@ template <typename T> class Pow2Engine {
     return p3 > 1 && is_pow2(n) && n >= 4096 && n <= ((size_t)1 << 30);
   }
 
-  explicit Pow2Engine(size_t n) : n_(n) {
+  // mirror: the pass lengths in reverse order (the inverse inner FFT of a conv-fused Bluestein plan must start
+  // with the length the forward one ends with)
+  explicit Pow2Engine(size_t n, bool mirror = false) : n_(n) {
     size_t p3 = 1, p2 = n;
     while (p2 % 3 == 0 && p3 < 27) { p2 /= 3; p3 *= 3; }
     if (!is_pow2(p2) || (p3 > 1 && p2 < 4096))
@@ -360,6 +385,8 @@ template <typename T> class Pow2Engine {
     } else {
       throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "power-of-two sizes above 2^30 are not supported");
     }
+    // FOURIER_REVERSE_LENS: development switch, swaps which pass gets the longer length (A/B timing only)
+    if (mirror != (getenv("FOURIER_REVERSE_LENS") != nullptr)) std::reverse(lens.begin(), lens.end());
     uint64_t s = 1, size = n;
     for (size_t p = 0; p < lens.size(); ++p) {
       auto pass = std::unique_ptr<Pass>(new Pass());
@@ -524,12 +551,21 @@ template <typename T> class Pow2Engine {
       }
       dst[np - 1] = out;
     }
-    for (size_t p = 0; p < np; ++p) {
+    for (size_t p = 0; p < np; ++p)
+      launch_pass(p, src[p], dst[p], batch, inverse, scale, mul, stream, prof, slot0 + (int)p, nxcd, blu);
+  }
+
+  // One pass of the schedule.  inverse / scale / mul take effect on the passes they belong to (leading swap on
+  // pass 0, trailing swap + scale + pointwise multiplier on the last pass).
+  void launch_pass(size_t p, const cpx<T>* src, cpx<T>* dst, size_t batch, bool inverse, double scale, const cpx<T>* mul,
+                   hipStream_t stream, Profiler* prof, int slot, unsigned nxcd, BluIO blu = BluIO()) const {
+    const size_t np = passes_.size();
+    {
       const Pass& ps = *passes_[p];
       if (ps.mode == MODE_ODD_LAST) {
         OddArgs o;
         std::memset(&o, 0, sizeof(o));
-        o.in = src[p]; o.out = dst[p]; o.mul = mul;
+        o.in = src; o.out = dst; o.mul = mul;
         o.n = n_; o.s = ps.s; o.batch = batch;
         o.swap_out = inverse; o.scale = scale;
         for (int e = 0; e < ps.odd_r; ++e) unit_root((uint64_t)e, (uint64_t)ps.odd_r, o.wr[e], o.wi[e]);
@@ -537,14 +573,14 @@ template <typename T> class Pow2Engine {
         const uint64_t threads = (uint64_t)batch * (ps.s / VEC);
         const uint64_t grid = (threads + 255) / 256;
         if (grid > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");
-        PROF_BEGIN(prof, slot0 + (int)p);
+        PROF_BEGIN(prof, slot);
         FOURIER_LAUNCH(ps.odd_fn, grid, 256, 0, stream, o);
         PROF_END(prof);
-        continue;
+        return;
       }
       PassArgs a;
       std::memset(&a, 0, sizeof(a));
-      a.in = src[p]; a.out = dst[p];
+      a.in = src; a.out = dst;
       a.tw1 = ps.st->tw1.p; a.tw2 = ps.st->tw2.p;
       if (ps.mode == MODE_TWOLEVEL) a.tw2 = ps.st2->tw1.p;
       a.tw_lo = ps.tw_lo.p; a.tw_hi = ps.tw_hi.p;
@@ -573,17 +609,51 @@ template <typename T> class Pow2Engine {
         grid = (uint64_t)batch * a.tiles;
       }
       if (grid > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");
-      PROF_BEGIN(prof, slot0 + (int)p);
+      PROF_BEGIN(prof, slot);
       FOURIER_LAUNCH(kk.fn, grid, kk.NT, kk.smem, stream, a);
       PROF_END(prof);
     }
+  }
+
+  // Bluestein middle: this plan's LAST pass + (.) wtab + the FIRST pass of an inverse plan that starts with the
+  // same length, in one launch (fft_conv_kernel).  src and dst are M-point work arrays, dst != src.
+  bool can_conv() const { return !tiny_ && passes_.size() >= 2 && passes_.back()->mode == MODE_LAST; }
+  void enable_conv() {
+    if (!can_conv()) return;
+    conv_ = get_conv_kernel<T>(passes_.back()->k.L);
+    set_smem_attribute(conv_);
+  }
+  bool palindromic() const {
+    for (size_t p = 0; p < passes_.size(); ++p)
+      if (passes_[p]->k.L != passes_[passes_.size() - 1 - p]->k.L) return false;
+    return true;
+  }
+  void launch_conv(const cpx<T>* src, cpx<T>* dst, size_t batch, const void* wtab, hipStream_t stream, Profiler* prof, int slot,
+                   unsigned nxcd) const {
+    const Pass& first = *passes_.front();
+    const Pass& last = *passes_.back();
+    PassArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.in = src; a.out = dst;
+    a.tw1 = last.st->tw1.p; a.tw2 = last.st->tw2.p;
+    a.tw_lo = first.tw_lo.p; a.tw_hi = first.tw_hi.p; a.lo_bits = first.lo_bits;  // W_M^e, the table of any first pass
+    a.mul = wtab;
+    a.n = n_; a.cn = last.cn; a.s = last.s;
+    a.tiles = last.cn / conv_.COLS;
+    a.nxcd = nxcd & 0xff;
+    a.scale = 1.0;
+    const uint64_t grid = (uint64_t)batch * a.tiles;
+    if (grid > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");
+    PROF_BEGIN(prof, slot);
+    FOURIER_LAUNCH(conv_.fn, grid, conv_.NT, conv_.smem, stream, a);
+    PROF_END(prof);
   }
 
  private:
   size_t n_;
   bool tiny_ = false;
   int tl1_ = 0, tl2_ = 0;   // pass lengths of a one-launch (MODE_TWOLEVEL) plan
-  KernelInfo blu_small_;
+  KernelInfo blu_small_, conv_;
   std::string desc_override_;
   std::vector<std::unique_ptr<Pass>> passes_;
   std::map<int, std::unique_ptr<StageTables<T>>> stage_;
@@ -744,6 +814,10 @@ template <typename T> class Plan {
     if (!blu_) { passes("pass"); return d; }
     if (small_fused_) return "bluestein_one_launch";
     d = "blu_pre"; passes("fwd_pass"); passes("inv_pass"); d += ",blu_post";  // blu_pre/post stay empty when fused
+    if (fused_ && conv_) {  // the last forward pass and the first inverse pass are one launch (inv_pass0 stays empty)
+      const std::string from = "fwd_pass" + std::to_string(eng_->num_passes() - 1);
+      d.replace(d.find(from), from.size(), "conv_pass");
+    }
     return d;
   }
 
@@ -753,6 +827,7 @@ template <typename T> class Plan {
     // unfused: pre (n + table read, m write) + 2 inner FFTs + w table + post (n + table read, n write);
     // fused: the first / last inner pass read / write the n-point user array instead of an m-point sweep
     if (small_fused_) return (double)ELEM * 2.0 * n_;  // tables stay L2-resident
+    if (fused_ && conv_) return (double)ELEM * (2.0 * m_ * (2.0 * eng_->num_passes() - 1.0) - 2.0 * (m_ - n_) + m_ + 2.0 * n_);
     if (fused_) return (double)ELEM * (2.0 * 2.0 * m_ * eng_->num_passes() - 2.0 * (m_ - n_) + m_ + 2.0 * n_);
     return (double)ELEM * ((2.0 * n_ + m_) + 2.0 * 2.0 * m_ * eng_->num_passes() + m_ + 3.0 * n_);
   }
@@ -766,6 +841,7 @@ template <typename T> class Plan {
       small_fused_ = (v == 1) && blu_ && eng_->enable_bluestein_small();
       return 0;
     }
+    if (key == "bluestein_conv" && (v == 0 || v == 1)) { conv_ = (v == 1) && conv_ok_; return 0; }
     return ::fourier::c::FOURIER_HIP_INVALID_ARGUMENT;
   }
 
@@ -818,6 +894,31 @@ template <typename T> class Plan {
       const size_t nb = std::min(chunk, batch - b0);
       BluArgs pre{in + b0 * n_, work, xtab_.p, (uint64_t)n_, (uint64_t)m_, (uint64_t)nb, inverse, 1.0};
       const int np = (int)eng_->num_passes();
+      if (fused_ && conv_) {
+        // three sweeps instead of four: first forward pass (chirp-in fused), the conv kernel (last forward pass,
+        // (.) w, first inverse pass), last inverse pass (chirp-out fused); intermediates ping-pong work/scratch
+        typename Pow2Engine<T>::BluIO bin, bout;
+        bin.io = IO_BLU_IN; bin.xtab = xtab_.p; bin.n = n_; bin.swap = inverse;
+        bout.io = IO_BLU_OUT; bout.xtab = xtab_.p; bout.n = n_; bout.swap = inverse;
+        const Pow2Engine<T>& inv = eng_inv_ ? *eng_inv_ : *eng_;
+        cpx<T>* bufs[2] = {work, (cpx<T>*)scratch_.p};
+        const cpx<T>* src = in + b0 * n_;
+        int cur = 0;
+        for (int p = 0; p + 1 < np; ++p) {
+          eng_->launch_pass((size_t)p, src, bufs[cur], nb, false, 1.0, nullptr, stream, prof, 1 + p, nxcd_, p == 0 ? bin : typename Pow2Engine<T>::BluIO());
+          src = bufs[cur]; cur ^= 1;
+        }
+        eng_->launch_conv(src, bufs[cur], nb, wtab_.p, stream, prof, np, nxcd_);
+        src = bufs[cur]; cur ^= 1;
+        for (int p = 1; p < np; ++p) {
+          const bool last = (p + 1 == np);
+          cpx<T>* dst = last ? out + b0 * n_ : bufs[cur];
+          inv.launch_pass((size_t)p, src, dst, nb, true, last ? scale : 1.0, nullptr, stream, prof, 1 + np + p, nxcd_,
+                          last ? bout : typename Pow2Engine<T>::BluIO());
+          src = dst; cur ^= 1;
+        }
+        continue;
+      }
       if (fused_) {
         // chirp multiply + zero pad fused into the forward inner FFT's first pass, chirp * scale fused into
         // the inverse inner FFT's last pass: no separate sweeps over the M-point work array
@@ -877,6 +978,16 @@ template <typename T> class Plan {
     eng_->enable_bluestein_fusion();
     fused_ = eng_->can_fuse_bluestein();
     small_fused_ = eng_->enable_bluestein_small();
+    if (fused_ && eng_->can_conv()) {
+      // the inverse inner FFT must begin with the pass length the forward one ends with: the same plan when the
+      // lengths read the same in both directions, otherwise its mirror image
+      eng_->enable_conv();
+      if (!eng_->palindromic()) {
+        eng_inv_.reset(new Pow2Engine<T>(m_, true));
+        eng_inv_->enable_bluestein_fusion();
+      }
+      conv_ = conv_ok_ = true;
+    }
     // chirp exp(-i*pi*k^2/n), angle reduced exactly with k^2 mod 2n (the reference leaves it
     // unreduced, bluesteins.rs:10,31,57; the reduction only removes f64 argument error)
     std::vector<double> cr(n_), ci(n_);
@@ -906,7 +1017,7 @@ template <typename T> class Plan {
   size_t n_, m_ = 0;
   int device_ = 0;
   bool blu_ = false;
-  std::unique_ptr<Pow2Engine<T>> eng_;
+  std::unique_ptr<Pow2Engine<T>> eng_, eng_inv_;  // eng_inv_: mirrored inverse plan of a conv-fused Bluestein
   std::unique_ptr<MixedEngine<T>> mix_;
   DevBuf xtab_, wtab_;
   mutable DevBuf scratch_, work_, hostio_;
@@ -914,6 +1025,7 @@ template <typename T> class Plan {
   bool force_scratch_ = false;
   bool fused_ = false;  // Bluestein: chirp steps fused into the inner passes
   bool small_fused_ = false;  // Bluestein with M <= 2^15: everything in one launch
+  bool conv_ = false, conv_ok_ = false;  // Bluestein: forward LAST + (.)w + inverse FIRST in one launch
   unsigned nxcd_ = 8;
   mutable int status_ = 0;
   std::string desc_;

@@ -51,7 +51,8 @@ enum { MODE_FIRST = 0, MODE_MID = 1, MODE_LAST = 2, MODE_ROWS = 3 };
 enum { IO_PLAIN = 0, IO_BLU_IN = 1, IO_BLU_OUT = 2 };
 
 // Build-time knobs (tools/build_variants.py A/B-tests them on the GPU):
-//   FOURIER_NT_LOAD  = 1 (default): first-pass input loads are non-temporal (streamed once)
+//   FOURIER_NT_LOAD  = 2 (default): the data loads of every pass are non-temporal (each element is read once per
+//   pass; -10% on the last pass of the 2^20 plan, r01 session 8); 1 = first pass only, 0 = none
 //   FOURIER_NT_STORE = 1 (default): final-pass output stores are non-temporal (+1% measured, r01 sweep)
 //   FOURIER_ABLATE (timing experiments only, results are wrong): 1 = no butterflies / twiddles,
 //   2 = additionally no LDS exchange (pure load -> store), 3 = no inter-pass twiddle only
@@ -64,7 +65,7 @@ enum { IO_PLAIN = 0, IO_BLU_IN = 1, IO_BLU_OUT = 2 };
 #define FOURIER_SPLIT_THRESHOLD (16 * 1024)
 #endif
 #ifndef FOURIER_NT_LOAD
-#define FOURIER_NT_LOAD 1
+#define FOURIER_NT_LOAD 2
 #endif
 #ifndef FOURIER_NT_STORE
 #define FOURIER_NT_STORE 1
@@ -93,6 +94,32 @@ template <typename T, bool NT> __device__ __forceinline__ void store_unit(void* 
   else *(v4u*)p = v;
 #else
   *(Unit16<T>*)p = u;
+#endif
+}
+
+// 16-byte accesses to arrays that are only 8-byte aligned (f32 user arrays of odd length inside a batch):
+// global_load/store_dwordx4 need dword alignment only.
+template <typename T> __device__ __forceinline__ Unit16<T> load_unit_a8(const void* p) {
+  Unit16<T> u;
+#ifndef FOURIER_EMU
+  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+  struct __attribute__((packed, aligned(8))) V { v4u v; };
+  const v4u v = ((const V*)p)->v;
+  __builtin_memcpy(&u, &v, 16);
+#else
+  __builtin_memcpy(&u, p, 16);
+#endif
+  return u;
+}
+template <typename T> __device__ __forceinline__ void store_unit_a8(void* p, const Unit16<T>& u) {
+#ifndef FOURIER_EMU
+  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+  struct __attribute__((packed, aligned(8))) V { v4u v; };
+  V w;
+  __builtin_memcpy(&w.v, &u, 16);
+  *(V*)p = w;
+#else
+  __builtin_memcpy(p, &u, 16);
 #endif
 }
 
@@ -297,6 +324,98 @@ __device__ __forceinline__ cpx<T> two_level_twiddle(const PassArgs& a, uint64_t 
 //   MODE_MID  : s >= COLS. column-tile load/store, twiddle W_size^{i*k} with i uniform per tile.
 //   MODE_LAST : size == L. column-tile load/store, no twiddle; mul / swap_out / scale on store.
 //   MODE_ROWS : whole transforms of length L, contiguous rows; mul / swap_out / scale on store.
+// ---- in-tile DFT of length L = 16 x R2 x R3 on a register tile (the body of every pass kernel) ----
+// In: thread (th, cg) holds rows th + Q*r of columns cg*VEC + v.  Out: register r holds output index
+// k = th + Q*r; for MODE_FIRST the last exchange also switches the thread mapping from cg-fastest ("A") to
+// th-fastest ("B", th = thB, cg = cgB) for the row-contiguous store.  Uses the exchange buffer at smem.
+template <typename T, int L, int CG, int MODE>
+__device__ __forceinline__ void tile_core(RegTile<T, L, CG>& x, int& th, int& cg, const int thB, const int cgB,
+                                          unsigned char* smem, const cpx<T>* tw1, const cpx<T>* tw2) {
+  using C = TileCfg<T, L, CG>;
+  constexpr int VEC = C::VEC, Q = C::Q, R2 = C::R2, R3 = C::R3;
+  constexpr bool IN_ROWS = (MODE == MODE_ROWS);
+  // ---- stage 1: radix 16 over rows th + Q*k'  ->  positions 16*th + k, twiddle W_L^{th*k}
+  constexpr bool DO_MATH = (FOURIER_ABLATE != 1 && FOURIER_ABLATE != 2);
+  constexpr bool DO_EXCH = (FOURIER_ABLATE != 2);
+  if constexpr (DO_MATH) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) dft16(x[v]);
+  }
+
+  if constexpr (Q > 1) {
+    if constexpr (DO_MATH) {
+      const cpx<T>* t1 = tw1 + th * 16;
+#pragma unroll
+      for (int k = 1; k < 16; ++k) {
+        const cpx<T> w = t1[k];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) x[v][k] = cmul(x[v][k], w);
+      }
+    }
+    {
+      const bool remap = (MODE == MODE_FIRST) && (R3 == 1);
+      const int th_r = remap ? thB : th, cg_r = remap ? cgB : cg;
+      const int th_w = th;
+      // both sides cg-fastest and split planes -> xor layout; anything row-contiguous -> skew layout
+      constexpr int LAY1 = (C::SPLIT && !IN_ROWS && !(MODE == MODE_FIRST && R3 == 1)) ? 1 : 0;
+      if constexpr (DO_EXCH)
+        lds_exchange<T, L, CG, LAY1>(x, smem, cg, [=](int r) { return 16 * th_w + r; }, th_r, cg_r, 0);
+      th = th_r; cg = cg_r;
+    }
+
+    // ---- stage 2: radix R2 on butterflies q = th + Q*u (register sets {u + NB2*k'})
+    constexpr int NB2 = 16 / R2;
+    if constexpr (DO_MATH)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+#pragma unroll
+      for (int u = 0; u < NB2; ++u) {
+        cpx<T> t[R2];
+#pragma unroll
+        for (int k = 0; k < R2; ++k) t[k] = x[v][u + NB2 * k];
+        dft_r<T, R2>(t);
+#pragma unroll
+        for (int k = 0; k < R2; ++k) x[v][u + NB2 * k] = t[k];
+      }
+
+    if constexpr (R3 > 1) {
+      // here R2 == 16, one butterfly per thread: q = th, j = th & 15, i = th >> 4
+      if constexpr (DO_MATH) {
+        const cpx<T>* t2 = tw2 + (th >> 4) * 16;
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+          const cpx<T> w = t2[k];
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) x[v][k] = cmul(x[v][k], w);
+        }
+      }
+      {
+        const bool remap = (MODE == MODE_FIRST);
+        const int th_r = remap ? thB : th, cg_r = remap ? cgB : cg;
+        const int jw = th & 15, iw = th >> 4;
+        __syncthreads();  // all reads of exchange 1 are done before the buffer is rewritten
+        if constexpr (DO_EXCH)
+        lds_exchange<T, L, CG, 0>(x, smem, cg, [=](int r) { return jw + 16 * (16 * iw + r); }, th_r, cg_r, 4);
+        th = th_r; cg = cg_r;
+      }
+      // ---- stage 3: radix R3 on register sets {u + NB3*k'}
+      constexpr int NB3 = 16 / R3;
+      if constexpr (DO_MATH)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v)
+#pragma unroll
+        for (int u = 0; u < NB3; ++u) {
+          cpx<T> t[R3];
+#pragma unroll
+          for (int k = 0; k < R3; ++k) t[k] = x[v][u + NB3 * k];
+          dft_r<T, R3>(t);
+#pragma unroll
+          for (int k = 0; k < R3; ++k) x[v][u + NB3 * k] = t[k];
+        }
+    }
+  }
+}
+
 template <typename T, int L, int CG, int MODE, int IO = IO_PLAIN>
 __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG)) fft_pass_kernel(PassArgs a) {
   static_assert(IO == IO_PLAIN || (IO == IO_BLU_IN && MODE == MODE_FIRST) || (IO == IO_BLU_OUT && MODE == MODE_LAST),
@@ -373,6 +492,16 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const uint64_t idx0 = (uint64_t)(th + Q * r) * a.cn + c0 + (uint64_t)(cg * VEC);
+      if (idx0 + VEC <= a.blu_n) {  // whole unit inside the user array: one 16-byte load each for data and chirp
+        const Unit16<T> u = load_unit_a8<T>(p + idx0), c = load_unit<T, false>(xt + idx0);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          cpx<T> val{u.a[2 * v], u.a[2 * v + 1]};
+          if (a.blu_swap) val = {val.im, val.re};
+          x[v][r] = cmul(cpx<T>{c.a[2 * v], c.a[2 * v + 1]}, val);
+        }
+        continue;
+      }
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         const uint64_t idx = idx0 + v;
@@ -389,7 +518,7 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
     const cpx<T>* p = in + b * a.n + (uint64_t)th * a.cn + c0 + (uint64_t)(cg * VEC);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const Unit16<T> u = load_unit<T, (MODE == MODE_FIRST) && FOURIER_NT_LOAD>(p + (uint64_t)(Q * r) * a.cn);
+      const Unit16<T> u = load_unit<T, (MODE == MODE_FIRST && FOURIER_NT_LOAD != 0) || FOURIER_NT_LOAD == 2>(p + (uint64_t)(Q * r) * a.cn);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
     }
@@ -401,90 +530,12 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
       for (int r = 0; r < 16; ++r) x[v][r] = {x[v][r].im, x[v][r].re};
   }
 
-  // ---- stage 1: radix 16 over rows th + Q*k'  ->  positions 16*th + k, twiddle W_L^{th*k}
-  constexpr bool DO_MATH = (FOURIER_ABLATE != 1 && FOURIER_ABLATE != 2);
-  constexpr bool DO_EXCH = (FOURIER_ABLATE != 2);
-  if constexpr (DO_MATH) {
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) dft16(x[v]);
-  }
-
-  if constexpr (Q > 1) {
-    if constexpr (DO_MATH) {
-      const cpx<T>* t1 = (const cpx<T>*)a.tw1 + th * 16;
-#pragma unroll
-      for (int k = 1; k < 16; ++k) {
-        const cpx<T> w = t1[k];
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) x[v][k] = cmul(x[v][k], w);
-      }
-    }
-    {
-      const bool remap = (MODE == MODE_FIRST) && (R3 == 1);
-      const int th_r = remap ? thB : th, cg_r = remap ? cgB : cg;
-      const int th_w = th;
-      // both sides cg-fastest and split planes -> xor layout; anything row-contiguous -> skew layout
-      constexpr int LAY1 = (C::SPLIT && !IN_ROWS && !(MODE == MODE_FIRST && R3 == 1)) ? 1 : 0;
-      if constexpr (DO_EXCH)
-        lds_exchange<T, L, CG, LAY1>(x, smem, cg, [=](int r) { return 16 * th_w + r; }, th_r, cg_r, 0);
-      th = th_r; cg = cg_r;
-    }
-
-    // ---- stage 2: radix R2 on butterflies q = th + Q*u (register sets {u + NB2*k'})
-    constexpr int NB2 = 16 / R2;
-    if constexpr (DO_MATH)
-#pragma unroll
-    for (int v = 0; v < VEC; ++v)
-#pragma unroll
-      for (int u = 0; u < NB2; ++u) {
-        cpx<T> t[R2];
-#pragma unroll
-        for (int k = 0; k < R2; ++k) t[k] = x[v][u + NB2 * k];
-        dft_r<T, R2>(t);
-#pragma unroll
-        for (int k = 0; k < R2; ++k) x[v][u + NB2 * k] = t[k];
-      }
-
-    if constexpr (R3 > 1) {
-      // here R2 == 16, one butterfly per thread: q = th, j = th & 15, i = th >> 4
-      if constexpr (DO_MATH) {
-        const cpx<T>* t2 = (const cpx<T>*)a.tw2 + (th >> 4) * 16;
-#pragma unroll
-        for (int k = 1; k < 16; ++k) {
-          const cpx<T> w = t2[k];
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) x[v][k] = cmul(x[v][k], w);
-        }
-      }
-      {
-        const bool remap = (MODE == MODE_FIRST);
-        const int th_r = remap ? thB : th, cg_r = remap ? cgB : cg;
-        const int jw = th & 15, iw = th >> 4;
-        __syncthreads();  // all reads of exchange 1 are done before the buffer is rewritten
-        if constexpr (DO_EXCH)
-        lds_exchange<T, L, CG, 0>(x, smem, cg, [=](int r) { return jw + 16 * (16 * iw + r); }, th_r, cg_r, 4);
-        th = th_r; cg = cg_r;
-      }
-      // ---- stage 3: radix R3 on register sets {u + NB3*k'}
-      constexpr int NB3 = 16 / R3;
-      if constexpr (DO_MATH)
-#pragma unroll
-      for (int v = 0; v < VEC; ++v)
-#pragma unroll
-        for (int u = 0; u < NB3; ++u) {
-          cpx<T> t[R3];
-#pragma unroll
-          for (int k = 0; k < R3; ++k) t[k] = x[v][u + NB3 * k];
-          dft_r<T, R3>(t);
-#pragma unroll
-          for (int k = 0; k < R3; ++k) x[v][u + NB3 * k] = t[k];
-        }
-    }
-  }
+  // ---- in-tile DFT_L: register r <- row th + Q*r  ==>  register r holds output index k = th + Q*r
+  tile_core<T, L, CG, MODE>(x, th, cg, thB, cgB, smem, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw2);
   // now register r holds output index k = th + Q*r of columns (cg*VEC + v)
 
   // ---- inter-pass twiddle W_size^{i*k} = W^{i*th} * tabU[col][r]
-  if constexpr (TWIDDLED && DO_MATH && FOURIER_ABLATE != 3) {
+  if constexpr (TWIDDLED && FOURIER_ABLATE == 0) {
     if constexpr (Q == 1) __syncthreads();  // tabU visibility when there was no exchange barrier
     const cpx<T>* tabU = (const cpx<T>*)(smem + C::TABU_OFF);
 #pragma unroll
@@ -525,9 +576,24 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
     cpx<T>* p = out + b * a.blu_n;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
+      const uint64_t idx0 = off + a.s * (uint64_t)(Q * r);
+      if (idx0 + VEC <= a.blu_n) {
+        const Unit16<T> c = load_unit<T, false>(xt + idx0);
+        Unit16<T> u;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          cpx<T> y = x[v][r];
+          if (a.swap_out) y = {y.im, y.re};
+          y = cmul(y, cpx<T>{c.a[2 * v], c.a[2 * v + 1]});
+          if (a.blu_swap) y = {y.im, y.re};
+          u.a[2 * v] = y.re * scale; u.a[2 * v + 1] = y.im * scale;
+        }
+        store_unit_a8<T>(p + idx0, u);
+        continue;
+      }
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
-        const uint64_t idx = off + a.s * (uint64_t)(Q * r) + v;
+        const uint64_t idx = idx0 + v;
         if (idx < a.blu_n) {
           cpx<T> y = x[v][r];
           if (a.swap_out) y = {y.im, y.re};
@@ -556,6 +622,86 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
       }
       store_unit<T, FINAL && FOURIER_NT_STORE>(p + a.s * (uint64_t)(Q * r), u);
     }
+  }
+}
+
+#ifndef FOURIER_CONV_MIN_WAVES
+#define FOURIER_CONV_MIN_WAVES(NT) FOURIER_MIN_WAVES(NT)
+#endif
+// ---- Bluestein middle (bluesteins.rs:236-239): LAST pass of the forward inner FFT, (.) w, and FIRST pass of
+// the inverse inner FFT in ONE launch.  The last forward pass (R = L, s = M/L) leaves X[j + (M/L)*k] of its
+// column tile in registers; an inverse FFT whose first pass has the same length (R = L, s = 1, m = M/L) reads
+// exactly those elements as its columns i = j, so the M-point spectrum never goes back to HBM: one read and
+// one write of the work array instead of two of each.  The inverse is swap . DFT . swap (mod.rs:366-387):
+// the leading swap happens here, the trailing one in the inverse plan's last pass.
+template <typename T, int L, int CG>
+__global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16) * CG)) fft_conv_kernel(PassArgs a) {
+  using C = TileCfg<T, L, CG>;
+  constexpr int VEC = C::VEC, Q = C::Q, COLS = C::COLS;
+  static_assert(Q > 1, "conv kernel: L >= 32");
+  FOURIER_DYN_SMEM(smem);
+  const int tid = (int)threadIdx.x;
+  int th = tid / CG, cg = tid % CG;
+  const int thB = tid % Q, cgB = tid / Q;
+  uint64_t blk = blockIdx.x;
+  if (a.nxcd > 1) {
+    const uint64_t nwg = gridDim.x, nx = a.nxcd, xcd = blk % nx, q = nwg / nx, r = nwg % nx;
+    blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + blk / nx;
+  }
+  const uint64_t b = blk / a.tiles, c0 = (blk % a.tiles) * COLS;
+  const cpx<T>* __restrict__ in = (const cpx<T>*)a.in + b * a.n;
+  cpx<T>* __restrict__ out = (cpx<T>*)a.out + b * a.n;
+
+  // inter-pass twiddle table of the inverse FFT's first pass: tabU[col][r] = W_M^{i_col * Q * r}
+  cpx<T>* tabU = (cpx<T>*)(smem + C::TABU_OFF);
+  for (int idx = tid; idx < COLS * 16; idx += C::NT) {
+    const uint64_t i = c0 + (uint64_t)(idx >> 4);
+    tabU[idx] = two_level_twiddle<T>(a, i * (uint64_t)(Q * (idx & 15)));
+  }
+
+  // forward LAST pass: rows th + Q*r (stride cn) of columns c0 + cg*VEC + v
+  cpx<T> x[VEC][16];
+  const uint64_t off = (uint64_t)th * a.cn + c0 + (uint64_t)(cg * VEC);
+  {
+    const cpx<T>* p = in + off;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const Unit16<T> u = load_unit<T, FOURIER_NT_LOAD == 2>(p + (uint64_t)(Q * r) * a.cn);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
+    }
+  }
+  tile_core<T, L, CG, MODE_LAST>(x, th, cg, thB, cgB, smem, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw2);
+  // register r holds X[c + cn*(th + Q*r)]: (.) w (FFT'd chirp, 1/M folded in), then the inverse's leading swap
+  {
+    const cpx<T>* w = (const cpx<T>*)a.mul + off;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const Unit16<T> u = load_unit<T, false>(w + (uint64_t)(Q * r) * a.cn);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const cpx<T> y = cmul(x[v][r], cpx<T>{u.a[2 * v], u.a[2 * v + 1]});
+        x[v][r] = {y.im, y.re};
+      }
+    }
+  }
+  __syncthreads();  // every read of the last exchange is done before the buffer is rewritten
+  // inverse FIRST pass on the same tile (columns i = c0 + ..., s = 1), thread mapping switches to th-fastest
+  tile_core<T, L, CG, MODE_FIRST>(x, th, cg, thB, cgB, smem, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw2);
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    const uint64_t i = c0 + (uint64_t)(cg * VEC + v);
+    const cpx<T> base = two_level_twiddle<T>(a, i * (uint64_t)th);
+    const cpx<T>* tu = tabU + (cg * VEC + v) * 16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[v][r] = cmul(x[v][r], cmul(base, tu[r]));
+  }
+  // transposed store: column i's L outputs are contiguous
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    cpx<T>* p = out + (c0 + (uint64_t)(cg * VEC + v)) * L + th;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[Q * r] = x[v][r];
   }
 }
 
@@ -826,7 +972,7 @@ __global__ void __launch_bounds__(FOURIER_TWOLEVEL_NT(T, L1, L2), FOURIER_MIN_WA
     const cpx<T>* p = in + (uint64_t)th * L2 + cg * VEC;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const Unit16<T> u = load_unit<T, FOURIER_NT_LOAD>(p + (Q1 * r) * L2);
+      const Unit16<T> u = load_unit<T, (FOURIER_NT_LOAD != 0)>(p + (Q1 * r) * L2);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
     }

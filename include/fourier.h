@@ -117,8 +117,11 @@ const char *fourier_hip_status_string(int status);
  *                  (keeps the inter-pass intermediate inside the 256 MiB Infinity Cache); 0 = whole batch
  *   "scratch"      1 = always route the intermediate through the plan's reused scratch buffer,
  *                  0 = use the output buffer as intermediate when out of place (default)
- *   "xcd_swizzle"  1 (default) = XCD-aware workgroup->tile mapping, 0 = plain blockIdx order
- *   "bluestein_fusion" 1 (default where the inner FFT has >= 2 passes) = chirp steps fused into the inner passes */
+ *   "xcd_swizzle"  1 (default) = XCD-aware workgroup->tile mapping (each XCD owns a contiguous run of transforms),
+ *                  2 = XCDs interleaved over adjacent transforms, 0 = plain blockIdx order
+ *   "bluestein_fusion" 1 (default where the inner FFT has >= 2 passes) = chirp steps fused into the inner passes
+ *   "bluestein_conv"   1 (default with bluestein_fusion) = the forward inner FFT's last pass, the multiply by the
+ *                  transformed chirp and the inverse inner FFT's first pass run as one launch */
 int fourier_hip_set_option_float(FOURIER_STRUCT fourier_fft_float *, const char *key, long long value);
 int fourier_hip_set_option_double(FOURIER_STRUCT fourier_fft_double *, const char *key, long long value);
 

@@ -177,6 +177,45 @@ def test_bluestein_fusion_matches_unfused(fa):
     assert "fused" in make(fa, 3000, np.complex64).describe()
 
 
+def test_bluestein_conv_kernel_matches_separate_passes(fa, oracle):
+    """Large Bluestein plans run the forward inner FFT's last pass, the multiply by the transformed chirp
+    and the inverse inner FFT's first pass as ONE launch (bluesteins.rs:236-239 in a single sweep).
+    Where the pass lengths are a palindrome (256x256) the same plan serves both directions and the values
+    are bit-identical to the separate-pass form; otherwise the inverse runs the mirrored plan (512x256 forward,
+    256x512 inverse) and agrees to rounding.  Both stay within the oracle tolerance."""
+    for n, dtype, exact, tol in ((20000, np.complex64, True, 2e-6), (40000, np.complex64, False, 2e-6),
+                                 (10000, np.complex128, False, 5e-11), (70001, np.complex128, True, 5e-11)):
+        x = np.stack([hash_normal(7 + b, n) for b in range(2)]).astype(dtype)
+        conv, plain = make(fa, n, dtype), make(fa, n, dtype)
+        plain.set_option("bluestein_conv", 0)
+        y = np.empty_like(x)
+        names = [p[0] for p in conv.profile_batch_ptr(x.ctypes.data, y.ctypes.data, 2, 0) if p[2] > 0]
+        assert names == ["fwd_pass0", "conv_pass", "inv_pass1"], names
+        assert [p[0] for p in plain.profile_batch_ptr(x.ctypes.data, y.ctypes.data, 2, 0) if p[2] > 0] == \
+            ["fwd_pass0", "fwd_pass1", "inv_pass0", "inv_pass1"]
+        for code in range(5):
+            a, b, ref = run_batch(conv, x, code), run_batch(plain, x, code), oracle.transform_batch(x, code)
+            if exact:
+                assert np.array_equal(a, b), (n, code)
+            else:
+                assert rel_l2(a, b) <= (3e-7 if dtype == np.complex64 else 1e-15), (n, code, rel_l2(a, b))
+            assert rel_l2(a, ref) <= tol, (n, code, rel_l2(a, ref))
+            assert np.array_equal(run_batch(conv, x, code, inplace=True), a), (n, code)
+
+
+def test_bluestein_conv_three_pass_inner_plan(fa):
+    # M = 2^23: forward 256x256x128, inverse mirrored 128x256x256, middle launch = last forward + first inverse
+    n = 2200000
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)[None, :]
+    plan = make(fa, n, np.complex64)
+    assert "M=8388608 inner 256x256x128" in plan.describe()
+    y = np.empty_like(x)
+    names = [p[0] for p in plan.profile_batch_ptr(x.ctypes.data, y.ctypes.data, 1, 0) if p[2] > 0]
+    assert names == ["fwd_pass0", "fwd_pass1", "conv_pass", "inv_pass1", "inv_pass2"], names
+    assert rel_l2(y[0], np.fft.fft(x[0].astype(np.complex128))) <= 2e-6
+
+
 def test_one_launch_plans_match_the_two_launch_plans(fa, monkeypatch):
     """2^12..2^15 run both Stockham passes inside one workgroup (one HBM round trip); the two-launch
     plan of the same size (forced with FOURIER_NO_TWOLEVEL) must agree to rounding."""

@@ -201,6 +201,29 @@ def test_bluestein_fusion_matches_unfused(torch, fa):
             assert np.array_equal(gpu_batch(torch, fa, fused, x, code, inplace=True), a), (n, code)
 
 
+@pytest.mark.parametrize("n,dtype,tol", [(20000, np.complex64, 2e-6), (40000, np.complex64, 2e-6), (65537, np.complex64, 2e-6),
+                                         (999983, np.complex64, 2e-6), (2200000, np.complex64, 2e-6),
+                                         (10000, np.complex128, 5e-11), (70001, np.complex128, 5e-11),
+                                         (999983, np.complex128, 1e-9)])
+def test_bluestein_conv_kernel_vs_separate_passes_and_oracle(torch, fa, oracle, n, dtype, tol):
+    """Large Bluestein: last forward pass + (.) w + first inverse pass in one launch (conv_pass) against the
+    separate-pass form and the oracle, every transform code, in and out of place."""
+    x = np.stack([hash_uniform(170 + b, n) for b in range(2)]).astype(dtype)
+    conv, plain = make(fa, n, dtype), make(fa, n, dtype)
+    plain.set_option("bluestein_conv", 0)
+    d = torch.from_numpy(x).cuda()
+    o = torch.empty_like(d)
+    names = [p[0] for p in conv.profile_batch_ptr(d.data_ptr(), o.data_ptr(), 2, 0, 0) if p[2] > 0]
+    assert "conv_pass" in names and "inv_pass0" not in names, names
+    for code in range(5):
+        a, b = gpu_batch(torch, fa, conv, x, code), gpu_batch(torch, fa, plain, x, code)
+        assert rel_l2(a, b) <= (3e-7 if dtype == np.complex64 else 1e-15), (n, code, rel_l2(a, b))
+        assert np.array_equal(gpu_batch(torch, fa, conv, x, code, inplace=True), a), (n, code)
+        if code in (0, 1):
+            ref = oracle.transform_batch(x, code, nthreads=2)
+            assert rel_l2(a, ref) <= tol, (n, code, rel_l2(a, ref))
+
+
 def test_random_sizes_batches_codes_vs_oracle(torch, fa, oracle):
     """Seeded random sweep over every plan family: random size (1..70000), batch, transform code, precision,
     in/out of place, against the CPU restatement of the reference."""

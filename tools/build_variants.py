@@ -13,6 +13,9 @@ VARIANTS = {
     "base": [],
     "slp": ["-fslp-vectorize"],
     "waves1": ["-DFOURIER_MIN_WAVES(NT)=1"],
+    "nt_first": ["-DFOURIER_NT_LOAD=1"],
+    "nt_none": ["-DFOURIER_NT_LOAD=0", "-DFOURIER_NT_STORE=0"],
+    "conv_1wg": ["-DFOURIER_CONV_MIN_WAVES(NT)=((NT)>=512?2:1)"],
     "nt_load": ["-DFOURIER_NT_LOAD=1"],
     "nt_store": ["-DFOURIER_NT_STORE=1"],
     "nt_both": ["-DFOURIER_NT_LOAD=1", "-DFOURIER_NT_STORE=1"],
