@@ -588,7 +588,7 @@ template <typename T> class Pow2Engine {
       a.n = n_; a.cn = ps.cn; a.s = ps.s;
       a.lo_bits = ps.lo_bits;
       a.nxcd = nxcd & 0xff;
-      a.xcd_interleave = (nxcd >> 8) & 1;
+      a.xcd_interleave = (nxcd >> 8) & 3;
       const bool blu_here = ps.has_blu && ((blu.io == IO_BLU_IN && p == 0) || (blu.io == IO_BLU_OUT && p + 1 == np));
       if (blu_here) { a.blu_x = blu.xtab; a.blu_n = blu.n; a.blu_swap = blu.swap; }
       const KernelInfo& kk = blu_here ? ps.k_blu : ps.k;
@@ -641,6 +641,7 @@ template <typename T> class Pow2Engine {
     a.n = n_; a.cn = last.cn; a.s = last.s;
     a.tiles = last.cn / conv_.COLS;
     a.nxcd = nxcd & 0xff;
+    a.xcd_interleave = (nxcd >> 8) & 3;
     a.scale = 1.0;
     const uint64_t grid = (uint64_t)batch * a.tiles;
     if (grid > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");
@@ -835,7 +836,7 @@ template <typename T> class Plan {
   int set_option(const std::string& key, long long v) {
     if (key == "chunk_bytes" && v >= 0) { chunk_bytes_ = (size_t)v; return 0; }
     if (key == "scratch" && (v == 0 || v == 1)) { force_scratch_ = (v == 1); return 0; }
-    if (key == "xcd_swizzle" && v >= 0 && v <= 2) { nxcd_ = v == 0 ? 1 : (v == 1 ? 8 : (8 | 0x100)); return 0; }
+    if (key == "xcd_swizzle" && v >= 0 && v <= 3) { nxcd_ = v == 0 ? 1 : (8 | ((unsigned)(v - 1) << 8)); return 0; }
     if (key == "bluestein_fusion" && (v == 0 || v == 1)) {
       fused_ = (v == 1) && blu_ && eng_->can_fuse_bluestein();
       small_fused_ = (v == 1) && blu_ && eng_->enable_bluestein_small();

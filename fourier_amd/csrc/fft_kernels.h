@@ -53,7 +53,8 @@ enum { IO_PLAIN = 0, IO_BLU_IN = 1, IO_BLU_OUT = 2 };
 // Build-time knobs (tools/build_variants.py A/B-tests them on the GPU):
 //   FOURIER_NT_LOAD  = 2 (default): the data loads of every pass are non-temporal (each element is read once per
 //   pass; -10% on the last pass of the 2^20 plan, r01 session 8); 1 = first pass only, 0 = none
-//   FOURIER_NT_STORE = 1 (default): final-pass output stores are non-temporal (+1% measured, r01 sweep)
+//   FOURIER_NT_STORE = 2 (default): output stores are non-temporal -- the final pass's (+1%), and the intermediate
+//   ones of passes up to L = 1024 (+2%; the one-workgroup-per-CU L = 2048 passes lose 8% with them); 1 = final only
 //   FOURIER_ABLATE (timing experiments only, results are wrong): 1 = no butterflies / twiddles,
 //   2 = additionally no LDS exchange (pure load -> store), 3 = no inter-pass twiddle only
 #ifndef FOURIER_ABLATE
@@ -68,7 +69,7 @@ enum { IO_PLAIN = 0, IO_BLU_IN = 1, IO_BLU_OUT = 2 };
 #define FOURIER_NT_LOAD 2
 #endif
 #ifndef FOURIER_NT_STORE
-#define FOURIER_NT_STORE 1
+#define FOURIER_NT_STORE 2
 #endif
 
 // 16-byte global accesses (global_load_dwordx4 / global_store_dwordx4)
@@ -94,6 +95,21 @@ template <typename T, bool NT> __device__ __forceinline__ void store_unit(void* 
   else *(v4u*)p = v;
 #else
   *(Unit16<T>*)p = u;
+#endif
+}
+
+// one complex element (8 / 16 bytes), optionally non-temporal
+template <typename T, bool NT> __device__ __forceinline__ void store_elem(cpx<T>* p, const cpx<T>& y) {
+#ifndef FOURIER_EMU
+  if constexpr (NT) {
+    typedef T v2 __attribute__((ext_vector_type(2)));
+    v2 v = {y.re, y.im};
+    __builtin_nontemporal_store(v, (v2*)p);
+  } else {
+    *p = y;
+  }
+#else
+  *p = y;
 #endif
 }
 
@@ -139,7 +155,7 @@ struct PassArgs {
   uint64_t total_cols;  // ROWS mode: number of transforms in this launch
   uint32_t lo_bits;
   uint32_t nxcd;      // >1: remap blockIdx so that each XCD (blockIdx % nxcd) walks a contiguous tile range
-  uint32_t xcd_interleave;  // 1: XCD x takes every nxcd-th transform instead of a contiguous 1/nxcd of the batch
+  uint32_t xcd_interleave;  // block -> tile mapping mode, see xcd_remap()
   const void* blu_x;  // Bluestein chirp table x[0..blu_n) (IO_BLU_IN / IO_BLU_OUT)
   uint64_t blu_n;     // user transform length (batch stride of the user-side buffer)
   int blu_swap;       // user-level inverse: swap re/im of the user data
@@ -324,6 +340,26 @@ __device__ __forceinline__ cpx<T> two_level_twiddle(const PassArgs& a, uint64_t 
 //   MODE_MID  : s >= COLS. column-tile load/store, twiddle W_size^{i*k} with i uniform per tile.
 //   MODE_LAST : size == L. column-tile load/store, no twiddle; mul / swap_out / scale on store.
 //   MODE_ROWS : whole transforms of length L, contiguous rows; mul / swap_out / scale on store.
+// Workgroup b is dispatched to XCD b % 8 (observed, MI355X_MICROARCH.md).  Bijective remap of the block index so
+// that each XCD's L2/TLB sees a compact working set; affects speed only.
+//   mode 0: every XCD owns a contiguous range of tiles (= whole transforms): each 2 MiB page and each DRAM row is
+//           touched by one XCD instead of all eight (+11..16% on the strided tile pattern, tools/membench.py --xcd)
+//   mode 1: XCD x takes transforms x, x + 8, ... (eight XCDs on eight adjacent transforms; measured slower)
+//   mode 2: XCD x owns the x-th eighth of the TILES of every transform: the slice of a per-transform table (Bluestein
+//           chirp / transformed chirp, indexed like the data) that an XCD reads stays in its 4 MiB L2
+__device__ __forceinline__ uint64_t xcd_remap(const PassArgs& a, uint64_t blk, uint64_t nwg) {
+  if (a.nxcd <= 1) return blk;
+  const uint64_t nx = a.nxcd, xcd = blk % nx, slot = blk / nx;
+  if (a.xcd_interleave == 1 && a.tiles > 0 && nwg % (nx * a.tiles) == 0)
+    return ((slot / a.tiles) * nx + xcd) * a.tiles + slot % a.tiles;
+  if (a.xcd_interleave == 2 && a.tiles > 0 && a.tiles % nx == 0) {
+    const uint64_t tpx = a.tiles / nx;
+    return (slot / tpx) * a.tiles + xcd * tpx + slot % tpx;
+  }
+  const uint64_t q = nwg / nx, r = nwg % nx;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
 // ---- in-tile DFT of length L = 16 x R2 x R3 on a register tile (the body of every pass kernel) ----
 // In: thread (th, cg) holds rows th + Q*r of columns cg*VEC + v.  Out: register r holds output index
 // k = th + Q*r; for MODE_FIRST the last exchange also switches the thread mapping from cg-fastest ("A") to
@@ -438,18 +474,7 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
   // contiguous range of tiles (= whole transforms): each 2 MiB page and each DRAM row is then
   // touched by one XCD's L2/TLB instead of all eight (+11..16% on the strided tile pattern, measured
   // with tools/membench.py --xcd).  Bijective for any grid size; affects speed only.
-  uint64_t blk = blockIdx.x;
-  if (a.nxcd > 1) {
-    const uint64_t nwg = gridDim.x, nx = a.nxcd, xcd = blk % nx;
-    if (a.xcd_interleave && a.tiles > 0 && nwg % (nx * a.tiles) == 0) {
-      // XCD x takes transforms x, x + 8, x + 16, ...: the eight XCDs work on eight ADJACENT transforms
-      const uint64_t slot = blk / nx;
-      blk = ((slot / a.tiles) * nx + xcd) * a.tiles + slot % a.tiles;
-    } else {
-      const uint64_t q = nwg / nx, r = nwg % nx;
-      blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + blk / nx;
-    }
-  }
+  const uint64_t blk = xcd_remap(a, blockIdx.x, gridDim.x);
   const cpx<T>* __restrict__ in = (const cpx<T>*)a.in;
   cpx<T>* __restrict__ out = (cpx<T>*)a.out;
   uint64_t b = 0, c0 = 0, g0 = 0;
@@ -565,7 +590,7 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
           if (a.swap_out) y = {y.im, y.re};
           y = {y.re * scale, y.im * scale};
         }
-        p[Q * r] = y;
+        store_elem<T, (FINAL ? FOURIER_NT_STORE != 0 : (FOURIER_NT_STORE == 2 && L <= 1024))>(p + Q * r, y);
       }
     }
   } else if constexpr (IO == IO_BLU_OUT) {
@@ -620,7 +645,7 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
         }
         u.a[2 * v] = y.re; u.a[2 * v + 1] = y.im;
       }
-      store_unit<T, FINAL && FOURIER_NT_STORE>(p + a.s * (uint64_t)(Q * r), u);
+      store_unit<T, (FINAL ? FOURIER_NT_STORE != 0 : (FOURIER_NT_STORE == 2 && L <= 1024))>(p + a.s * (uint64_t)(Q * r), u);
     }
   }
 }
@@ -643,11 +668,7 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16)
   const int tid = (int)threadIdx.x;
   int th = tid / CG, cg = tid % CG;
   const int thB = tid % Q, cgB = tid / Q;
-  uint64_t blk = blockIdx.x;
-  if (a.nxcd > 1) {
-    const uint64_t nwg = gridDim.x, nx = a.nxcd, xcd = blk % nx, q = nwg / nx, r = nwg % nx;
-    blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + blk / nx;
-  }
+  const uint64_t blk = xcd_remap(a, blockIdx.x, gridDim.x);
   const uint64_t b = blk / a.tiles, c0 = (blk % a.tiles) * COLS;
   const cpx<T>* __restrict__ in = (const cpx<T>*)a.in + b * a.n;
   cpx<T>* __restrict__ out = (cpx<T>*)a.out + b * a.n;
@@ -701,7 +722,7 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16)
   for (int v = 0; v < VEC; ++v) {
     cpx<T>* p = out + (c0 + (uint64_t)(cg * VEC + v)) * L + th;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) p[Q * r] = x[v][r];
+    for (int r = 0; r < 16; ++r) p[Q * r] = x[v][r];  // plain stores measured faster here (r01 session 8)
   }
 }
 
@@ -999,7 +1020,7 @@ __global__ void __launch_bounds__(FOURIER_TWOLEVEL_NT(T, L1, L2), FOURIER_MIN_WA
       if (a.swap_out) y = {y.im, y.re};
       u.a[2 * v] = y.re * scale; u.a[2 * v + 1] = y.im * scale;
     }
-    store_unit<T, FOURIER_NT_STORE>(p + (Q2 * r) * L1, u);
+    store_unit<T, FOURIER_NT_STORE != 0>(p + (Q2 * r) * L1, u);
   }
 }
 
@@ -1322,7 +1343,7 @@ __global__ void __launch_bounds__(256) odd_last_kernel(OddArgs a) {
       if (a.swap_out) y = {y.im, y.re};
       v.a[2 * c] = y.re * scale; v.a[2 * c + 1] = y.im * scale;
     }
-    store_unit<T, FOURIER_NT_STORE>(out + (uint64_t)k * a.s, v);
+    store_unit<T, FOURIER_NT_STORE != 0>(out + (uint64_t)k * a.s, v);
   }
 }
 

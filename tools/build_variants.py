@@ -14,12 +14,14 @@ VARIANTS = {
     "slp": ["-fslp-vectorize"],
     "waves1": ["-DFOURIER_MIN_WAVES(NT)=1"],
     "nt_first": ["-DFOURIER_NT_LOAD=1"],
+    "nt_store_all": ["-DFOURIER_NT_STORE=2"],
     "nt_none": ["-DFOURIER_NT_LOAD=0", "-DFOURIER_NT_STORE=0"],
     "conv_1wg": ["-DFOURIER_CONV_MIN_WAVES(NT)=((NT)>=512?2:1)"],
     "nt_load": ["-DFOURIER_NT_LOAD=1"],
     "nt_store": ["-DFOURIER_NT_STORE=1"],
     "nt_both": ["-DFOURIER_NT_LOAD=1", "-DFOURIER_NT_STORE=1"],
     "cg4": ["-DFOURIER_CG_1024=4"],
+    "cg2048_4": ["-DFOURIER_CG_2048=4"],
     "cg16": ["-DFOURIER_CG_1024=16"],
     "split16k": ["-DFOURIER_SPLIT_THRESHOLD=(16*1024)"],
     "split32k": ["-DFOURIER_SPLIT_THRESHOLD=(32*1024)"],

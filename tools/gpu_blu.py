@@ -9,7 +9,8 @@ from fourier_amd import fft as F, _lib
 
 CASES = [("C4 f32 999983x512", 999983, 512, "f32"), ("C4 f64 999983x256", 999983, 256, "f64"),
          ("prime 65537x8192", 65537, 8192, "f32"), ("40000x8192 (512x256)", 40000, 8192, "f32"),
-         ("2200000x128 (3-pass)", 2200000, 128, "f32"), ("10007x16384 f64 (256x128)", 10007, 16384, "f64")]
+         ("2200000x128 (3-pass)", 2200000, 128, "f32"), ("10007x16384 f64 (256x128)", 10007, 16384, "f64"),
+         ("2^20 x2048", 1 << 20, 2048, "f32"), ("2^20 f64 x1024", 1 << 20, 1024, "f64")]
 
 
 def run(lib, tag, n, batch, real, opts):
@@ -43,7 +44,7 @@ if __name__ == "__main__":
     for name, path in libs:
         _lib._lib = base if path is None else _lib.bind(ctypes.CDLL(path))
         for tag, n, batch, real in CASES:
-            for opts in ((), (("bluestein_conv", 0),)):
+            for opts in ((), (("xcd_swizzle", 3),), (("bluestein_conv", 0),)):
                 if path is not None and opts:
                     continue
                 try:
