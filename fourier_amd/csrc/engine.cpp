@@ -79,6 +79,29 @@ struct DevBuf {
   }
 };
 
+// page-locked host staging buffer, mapped into the device address space (legacy host-buffer ABI)
+struct PinnedBuf {
+  void* h = nullptr;  // host address
+  void* d = nullptr;  // the same memory as the device sees it
+  size_t bytes = 0;
+  PinnedBuf() {}
+  PinnedBuf(const PinnedBuf&) = delete;
+  PinnedBuf& operator=(const PinnedBuf&) = delete;
+  ~PinnedBuf() { release(); }
+  void release() {
+    if (h) (void)hipHostFree(h);
+    h = d = nullptr;
+    bytes = 0;
+  }
+  void ensure(size_t n) {
+    if (n <= bytes) return;
+    release();
+    HIP_CHECK(hipHostMalloc(&h, n, hipHostMallocMapped));
+    HIP_CHECK(hipHostGetDevicePointer(&d, h, 0));
+    bytes = n;
+  }
+};
+
 // ---------------------------------------------------------------------------------------------
 // optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg)
 struct Profiler {
@@ -385,8 +408,7 @@ template <typename T> class Pow2Engine {
     } else {
       throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "power-of-two sizes above 2^30 are not supported");
     }
-    // FOURIER_REVERSE_LENS: development switch, swaps which pass gets the longer length (A/B timing only)
-    if (mirror != (getenv("FOURIER_REVERSE_LENS") != nullptr)) std::reverse(lens.begin(), lens.end());
+    if (mirror) std::reverse(lens.begin(), lens.end());  // either order times the same (profiles/r01_s8_nt_and_pass_order.jsonl)
     uint64_t s = 1, size = n;
     for (size_t p = 0; p < lens.size(); ++p) {
       auto pass = std::unique_ptr<Pass>(new Pass());
@@ -706,6 +728,8 @@ template <typename T> class MixedEngine {
       }
     if (tw.empty()) tw.push_back({(T)1, (T)0});
     tw_.upload(tw);
+    // transforms per workgroup: about 1024 points (16 KiB of LDS in f32: several workgroups per CU; larger groups that
+    // fill the 256 threads better lose more in occupancy than they gain, r01 session 9)
     group_ = (uint32_t)std::max<size_t>(1, 1024 / n);
     smem_ = 2 * (size_t)group_ * n * sizeof(cpx<T>);
 #ifndef FOURIER_EMU
@@ -948,12 +972,23 @@ template <typename T> class Plan {
     if (!h_in || !h_out) throw EngineError(::fourier::c::FOURIER_HIP_INVALID_ARGUMENT, "null buffer");
     if (code < 0 || code > 4) return;  // unknown code: silent no-op (lib.rs:10)
     DeviceGuard g(device_);
-    hostio_.ensure(n_ * ELEM);
-    HIP_CHECK(hipMemcpy(hostio_.p, h_in, n_ * ELEM, hipMemcpyHostToDevice));
-    exec(hostio_.p, hostio_.p, 1, code, (hipStream_t)0);
+    const size_t bytes = n_ * ELEM;
+    pinned_.ensure(bytes);
+    std::memcpy(pinned_.h, h_in, bytes);
+    if (bytes <= ZERO_COPY_MAX) {
+      // small transforms are latency-bound: the kernels read and write the mapped host buffer directly over
+      // PCIe (every plan reads its input once and writes its output once) -- one launch chain, one sync
+      exec(pinned_.d, pinned_.d, 1, code, (hipStream_t)0);
+    } else {
+      hostio_.ensure(bytes);
+      HIP_CHECK(hipMemcpyAsync(hostio_.p, pinned_.h, bytes, hipMemcpyHostToDevice, (hipStream_t)0));
+      exec(hostio_.p, hostio_.p, 1, code, (hipStream_t)0);
+      HIP_CHECK(hipMemcpyAsync(pinned_.h, hostio_.p, bytes, hipMemcpyDeviceToHost, (hipStream_t)0));
+    }
     HIP_CHECK(hipStreamSynchronize((hipStream_t)0));
-    HIP_CHECK(hipMemcpy(h_out, hostio_.p, n_ * ELEM, hipMemcpyDeviceToHost));
+    std::memcpy(h_out, pinned_.h, bytes);
   }
+  static constexpr size_t ZERO_COPY_MAX = 256 * 1024;
 
  private:
   struct DeviceGuard {
@@ -1022,6 +1057,7 @@ template <typename T> class Plan {
   std::unique_ptr<MixedEngine<T>> mix_;
   DevBuf xtab_, wtab_;
   mutable DevBuf scratch_, work_, hostio_;
+  mutable PinnedBuf pinned_;
   size_t chunk_bytes_ = 0;
   bool force_scratch_ = false;
   bool fused_ = false;  // Bluestein: chirp steps fused into the inner passes

@@ -590,7 +590,9 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
           if (a.swap_out) y = {y.im, y.re};
           y = {y.re * scale, y.im * scale};
         }
-        store_elem<T, (FINAL ? FOURIER_NT_STORE != 0 : (FOURIER_NT_STORE == 2 && L <= 1024))>(p + Q * r, y);
+        // MODE_ROWS: a wave's element stores only form whole lines for L >= 256; below that they rely on L2
+        // write-combining and a non-temporal hint is a 2-6x loss (N = 16..64, r01 session 9)
+        store_elem<T, (MODE == MODE_ROWS ? (FOURIER_NT_STORE != 0 && L >= 256) : (FOURIER_NT_STORE == 2 && L <= 1024))>(p + Q * r, y);
       }
     }
   } else if constexpr (IO == IO_BLU_OUT) {
@@ -1199,8 +1201,16 @@ __device__ __forceinline__ void mixed_pass(const cpx<T>* __restrict__ src, cpx<T
                                            uint32_t n, uint32_t nb, uint32_t size, uint32_t stride, bool fwd, cpx<T> w3,
                                            cpx<T> w8) {
   const uint32_t m = size / R, nbf = n / R;
+  // q / nbf and e / stride without integer division: operands stay below 2^16 (a workgroup holds <= 9216 points), so
+  // the float quotient is off by at most one and a compare fixes it
+  const float inv_nbf = 1.0f / (float)nbf, inv_stride = 1.0f / (float)stride;
   for (uint32_t q = threadIdx.x; q < nb * nbf; q += blockDim.x) {
-    const uint32_t g = q / nbf, e = q - g * nbf, i = e / stride, j = e - i * stride;
+    uint32_t g = (uint32_t)((float)q * inv_nbf);
+    g -= (g * nbf > q); g += ((g + 1) * nbf <= q);
+    const uint32_t e = q - g * nbf;
+    uint32_t i = (uint32_t)((float)e * inv_stride);
+    i -= (i * stride > e); i += ((i + 1) * stride <= e);
+    const uint32_t j = e - i * stride;
     const cpx<T>* in = src + g * n + j + stride * i;
     cpx<T> x[R];
 #pragma unroll

@@ -339,6 +339,30 @@ def test_runs_on_a_side_stream(torch, fa, oracle):
     assert rel_l2(o.cpu().numpy(), oracle.transform_batch(x, 0)) <= 1e-6
 
 
+def test_batched_transform_is_graph_capturable(torch, fa, oracle):
+    """After a warm-up call (which sizes the plan's scratch), the batched entry point is pure stream-ordered
+    launches: it can be captured into a HIP graph and replayed on new data (pow2 two-pass, one-launch and
+    Bluestein conv plans)."""
+    for n in (1 << 16, 4096, 40000):
+        plan = make(fa, n, np.complex64)
+        x0 = np.stack([hash_uniform(900 + b, n) for b in range(3)]).astype(np.complex64)
+        x1 = np.stack([hash_uniform(950 + b, n) for b in range(3)]).astype(np.complex64)
+        d = torch.from_numpy(x0).cuda()
+        o = torch.empty_like(d)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            plan.transform(d, o, fa.Transform.Fft)  # warm-up on the capture stream
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            plan.transform(d, o, fa.Transform.Fft)
+        d.copy_(torch.from_numpy(x1).cuda())
+        g.replay()
+        torch.cuda.synchronize()
+        ref = oracle.transform_batch(x1, 0, nthreads=2)
+        assert rel_l2(o.cpu().numpy(), ref) <= 2e-6, n
+
+
 @pytest.mark.parametrize("src,cc,std", [("consumer.c", "gcc", "-std=c11"), ("consumer.cpp", "g++", "-std=c++14")])
 def test_c_and_cxx_consumers_relink_unchanged(fa, tmp_path, src, cc, std):
     """existing C / C++ users of fourier.h build against include/fourier.h with
