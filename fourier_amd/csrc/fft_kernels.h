@@ -256,8 +256,17 @@ template <typename T, int L, int CG> struct TileCfg {
   static constexpr size_t SMEM_FIRST = TABU_OFF + TABU_BYTES;
   static constexpr size_t SMEM_MID = TABU_OFF + 16 * sizeof(cpx<T>);
   static constexpr size_t SMEM_PLAIN = EXCH_BYTES;
+  // MODE_ROWS with tiny L: whole transforms are staged through LDS so that global memory only sees coalesced
+  // 16-byte units (a thread's own elements are 8..32 bytes apart in chunks of 8..32 bytes: address-unit bound).
+  // Row pitch LP keeps rows 16-byte aligned and spreads a wave's element reads over the banks.  Pays off while a
+  // transform is at most 256 bytes (f32 16: 28 -> 47 %, 32: 39 -> 47 %, f64 16: 45 -> 55 % of the HBM peak); from
+  // 512 bytes on the direct element accesses are faster (r01 session 9).
+  static constexpr bool STAGED_ROWS = ((size_t)L * 2 * sizeof(T) <= 256);
+  static constexpr int LP = L + (sizeof(T) == 4 ? 2 : 1);
+  static constexpr size_t STAGE_BYTES = (size_t)COLS * LP * 2 * sizeof(T);
+  static constexpr size_t SMEM_ROWS = STAGED_ROWS ? (STAGE_BYTES > EXCH_BYTES ? STAGE_BYTES : EXCH_BYTES) : EXCH_BYTES;
   static __host__ __device__ constexpr size_t smem_bytes(int mode) {
-    return mode == MODE_FIRST ? SMEM_FIRST : (mode == MODE_MID ? SMEM_MID : SMEM_PLAIN);
+    return mode == MODE_FIRST ? SMEM_FIRST : (mode == MODE_MID ? SMEM_MID : (mode == MODE_ROWS ? SMEM_ROWS : SMEM_PLAIN));
   }
   // LAYOUT 0 ("skew"): conflict-free for lanes walking pos at fixed cg (row-contiguous mapping).
   // LAYOUT 1 ("xor"):  for the stage-1 exchange of the split-plane tiles, where a 16-lane ds_write_b64
@@ -501,7 +510,29 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
 
   // ---- load: register r <- row th + Q*r
   cpx<T> x[VEC][16];
-  if constexpr (IN_ROWS) {
+  constexpr bool STAGED = IN_ROWS && C::STAGED_ROWS;
+  if constexpr (STAGED) {
+    // coalesced: unit tid + NT*r of the workgroup's contiguous chunk of COLS transforms -> LDS [transform][pos]
+    cpx<T>* stage = (cpx<T>*)smem;
+    const uint64_t e0 = g0 * L, e_end = a.total_cols * (uint64_t)L;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const uint32_t le = (uint32_t)(tid + C::NT * r) * VEC;  // local element index; units never straddle a row
+      if (e0 + le < e_end) {
+        const Unit16<T> u = load_unit_a8<T>(in + e0 + le);
+        *(Unit16<T>*)(stage + (le / L) * C::LP + (le % L)) = u;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const bool valid = g0 + (uint64_t)(cg * VEC + v) < a.total_cols;
+      const cpx<T>* p = stage + (cg * VEC + v) * C::LP + th;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[v][r] = valid ? p[Q * r] : cpx<T>{0, 0};
+    }
+    __syncthreads();  // the exchange buffer aliases the staging area
+  } else if constexpr (IN_ROWS) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       const uint64_t g = g0 + (uint64_t)(cg * VEC + v);
@@ -576,7 +607,28 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
   // ---- store
   const T scale = (T)a.scale;
   const cpx<T>* __restrict__ mul = (const cpx<T>*)a.mul;
-  if constexpr (OUT_ROWS) {
+  if constexpr (STAGED) {
+    cpx<T>* stage = (cpx<T>*)smem;
+    if constexpr (Q > 1) __syncthreads();  // reads of the last exchange are done
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      cpx<T>* p = stage + (cg * VEC + v) * C::LP + th;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        cpx<T> y = x[v][r];
+        if (mul) y = cmul(y, mul[th + Q * r]);
+        if (a.swap_out) y = {y.im, y.re};
+        p[Q * r] = {y.re * scale, y.im * scale};
+      }
+    }
+    __syncthreads();
+    const uint64_t e0 = g0 * L, e_end = a.total_cols * (uint64_t)L;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const uint32_t le = (uint32_t)(tid + C::NT * r) * VEC;
+      if (e0 + le < e_end) store_unit_a8<T>(out + e0 + le, *(const Unit16<T>*)(stage + (le / L) * C::LP + (le % L)));
+    }
+  } else if constexpr (OUT_ROWS) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       const uint64_t g = g0 + (uint64_t)(cg * VEC + v);

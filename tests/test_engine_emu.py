@@ -177,6 +177,22 @@ def test_bluestein_fusion_matches_unfused(fa):
     assert "fused" in make(fa, 3000, np.complex64).describe()
 
 
+def test_small_row_kernels_with_ragged_batches(fa):
+    """N = 16, 32, 64 stage whole transforms through LDS (coalesced 16-byte global accesses); batches that do
+    not fill the last workgroup, in and out of place, all scalings."""
+    for dtype, tol in ((np.complex64, 3e-7), (np.complex128, 1e-15)):
+        for n in (16, 32, 64):
+            plan = make(fa, n, dtype)
+            for batch in (1, 2, 3, 31, 64, 127, 128, 129, 300):
+                x = np.stack([hash_normal(b * 7 + n, n) for b in range(batch)]).astype(dtype)
+                for code in (0, 1, 4):
+                    x128 = x.astype(np.complex128)
+                    ref = np.fft.fft(x128, axis=1) if code == 0 else np.fft.ifft(x128, axis=1) * (1 if code == 1 else np.sqrt(n))
+                    y = run_batch(plan, x, code)
+                    assert rel_l2(y, ref) <= tol, (n, batch, code, rel_l2(y, ref))
+                    assert np.array_equal(run_batch(plan, x, code, inplace=True), y), (n, batch, code)
+
+
 def test_bluestein_conv_kernel_matches_separate_passes(fa, oracle):
     """Large Bluestein plans run the forward inner FFT's last pass, the multiply by the transformed chirp
     and the inverse inner FFT's first pass as ONE launch (bluesteins.rs:236-239 in a single sweep).
