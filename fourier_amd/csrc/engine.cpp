@@ -525,7 +525,7 @@ template <typename T> class Pow2Engine {
   size_t num_passes() const { return tiny_ ? 1 : passes_.size(); }
   bool needs_scratch(bool in_place) const { return passes_.size() >= 3 || (passes_.size() == 2 && in_place); }
   std::string describe() const {
-    if (tiny_) return "tiny(" + std::to_string(n_) + ")";
+    if (tiny_ || n_ == 16 || (n_ == 32 && sizeof(T) == 4)) return "tiny(" + std::to_string(n_) + ")";
     if (!desc_override_.empty()) return desc_override_;
     std::string d;
     for (size_t p = 0; p < passes_.size(); ++p)
@@ -548,10 +548,17 @@ template <typename T> class Pow2Engine {
            bool force_scratch, hipStream_t stream, Profiler* prof = nullptr, int slot0 = 0, unsigned nxcd = 8,
            BluIO blu = BluIO()) const {
     if (batch == 0) return;
-    if (tiny_) {
+    // N = 16 (and f32 N = 32) also run one lane per transform; their ROWS pass only serves Bluestein M = 16 / 32
+    const bool lane_per_transform = tiny_ || n_ == 16 || (n_ == 32 && sizeof(T) == 4);
+    if (lane_per_transform && blu.io == IO_PLAIN) {
       TinyArgs a{in, out, mul, (uint64_t)batch, (int)n_, inverse, inverse, scale};
       PROF_BEGIN(prof, slot0);
-      FOURIER_LAUNCH(&tiny_dft_kernel<T>, (batch + 255) / 256, 256, 0, stream, a);
+      void (*fn)(TinyArgs) = n_ == 32 ? &tiny_shfl_kernel<T, (sizeof(T) == 4 ? 32 : 16)>
+                             : n_ == 16 ? &tiny_shfl_kernel<T, 16>
+                             : n_ == 8 ? &tiny_shfl_kernel<T, 8>
+                             : n_ == 4 ? &tiny_shfl_kernel<T, 4>
+                             : n_ == 2 ? &tiny_shfl_kernel<T, 2> : &tiny_dft_kernel<T>;
+      FOURIER_LAUNCH(fn, (batch + 255) / 256, 256, 0, stream, a);
       PROF_END(prof);
       return;
     }

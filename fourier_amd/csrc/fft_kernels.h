@@ -230,11 +230,28 @@ template <typename T> __device__ __forceinline__ void dft16(cpx<T>* x) {
     }
 }
 
+// 32 points in registers: two 16-point DFTs over the even and odd inputs, then one radix-2 combine
+template <typename T> __device__ __forceinline__ void dft32(cpx<T>* x) {
+  cpx<T> e[16], o[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { e[i] = x[2 * i]; o[i] = x[2 * i + 1]; }
+  dft16(e);
+  dft16(o);
+  const cpx<T> w[16] = {{(T)1.00000000000000000000, (T)-0.00000000000000000000}, {(T)0.98078528040323043058, (T)-0.19509032201612824808}, {(T)0.92387953251128673848, (T)-0.38268343236508978178}, {(T)0.83146961230254523567, (T)-0.55557023301960217765}, {(T)0.70710678118654757274, (T)-0.70710678118654746172}, {(T)0.55557023301960228867, (T)-0.83146961230254523567}, {(T)0.38268343236508983729, (T)-0.92387953251128673848}, {(T)0.19509032201612833135, (T)-0.98078528040323043058}, {(T)0.00000000000000006123, (T)-1.00000000000000000000}, {(T)-0.19509032201612819257, (T)-0.98078528040323043058}, {(T)-0.38268343236508972627, (T)-0.92387953251128673848}, {(T)-0.55557023301960195560, (T)-0.83146961230254545772}, {(T)-0.70710678118654746172, (T)-0.70710678118654757274}, {(T)-0.83146961230254534669, (T)-0.55557023301960217765}, {(T)-0.92387953251128673848, (T)-0.38268343236508989280}, {(T)-0.98078528040323043058, (T)-0.19509032201612860891}};  // W32^k
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const cpx<T> t = (k == 0) ? o[0] : cmul(o[k], w[k]);
+    x[k] = {e[k].re + t.re, e[k].im + t.im};
+    x[k + 16] = {e[k].re - t.re, e[k].im - t.im};
+  }
+}
+
 template <typename T, int R> __device__ __forceinline__ void dft_r(cpx<T>* x) {
   if constexpr (R == 2) dft2(x);
   else if constexpr (R == 4) dft4(x);
   else if constexpr (R == 8) dft8(x);
   else if constexpr (R == 16) dft16(x);
+  else if constexpr (R == 32) dft32(x);
 }
 
 // ---- tile configuration ----
@@ -256,17 +273,8 @@ template <typename T, int L, int CG> struct TileCfg {
   static constexpr size_t SMEM_FIRST = TABU_OFF + TABU_BYTES;
   static constexpr size_t SMEM_MID = TABU_OFF + 16 * sizeof(cpx<T>);
   static constexpr size_t SMEM_PLAIN = EXCH_BYTES;
-  // MODE_ROWS with tiny L: whole transforms are staged through LDS so that global memory only sees coalesced
-  // 16-byte units (a thread's own elements are 8..32 bytes apart in chunks of 8..32 bytes: address-unit bound).
-  // Row pitch LP keeps rows 16-byte aligned and spreads a wave's element reads over the banks.  Pays off while a
-  // transform is at most 256 bytes (f32 16: 28 -> 47 %, 32: 39 -> 47 %, f64 16: 45 -> 55 % of the HBM peak); from
-  // 512 bytes on the direct element accesses are faster (r01 session 9).
-  static constexpr bool STAGED_ROWS = ((size_t)L * 2 * sizeof(T) <= 256);
-  static constexpr int LP = L + (sizeof(T) == 4 ? 2 : 1);
-  static constexpr size_t STAGE_BYTES = (size_t)COLS * LP * 2 * sizeof(T);
-  static constexpr size_t SMEM_ROWS = STAGED_ROWS ? (STAGE_BYTES > EXCH_BYTES ? STAGE_BYTES : EXCH_BYTES) : EXCH_BYTES;
   static __host__ __device__ constexpr size_t smem_bytes(int mode) {
-    return mode == MODE_FIRST ? SMEM_FIRST : (mode == MODE_MID ? SMEM_MID : (mode == MODE_ROWS ? SMEM_ROWS : SMEM_PLAIN));
+    return mode == MODE_FIRST ? SMEM_FIRST : (mode == MODE_MID ? SMEM_MID : SMEM_PLAIN);
   }
   // LAYOUT 0 ("skew"): conflict-free for lanes walking pos at fixed cg (row-contiguous mapping).
   // LAYOUT 1 ("xor"):  for the stage-1 exchange of the split-plane tiles, where a 16-lane ds_write_b64
@@ -510,29 +518,7 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
 
   // ---- load: register r <- row th + Q*r
   cpx<T> x[VEC][16];
-  constexpr bool STAGED = IN_ROWS && C::STAGED_ROWS;
-  if constexpr (STAGED) {
-    // coalesced: unit tid + NT*r of the workgroup's contiguous chunk of COLS transforms -> LDS [transform][pos]
-    cpx<T>* stage = (cpx<T>*)smem;
-    const uint64_t e0 = g0 * L, e_end = a.total_cols * (uint64_t)L;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const uint32_t le = (uint32_t)(tid + C::NT * r) * VEC;  // local element index; units never straddle a row
-      if (e0 + le < e_end) {
-        const Unit16<T> u = load_unit_a8<T>(in + e0 + le);
-        *(Unit16<T>*)(stage + (le / L) * C::LP + (le % L)) = u;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      const bool valid = g0 + (uint64_t)(cg * VEC + v) < a.total_cols;
-      const cpx<T>* p = stage + (cg * VEC + v) * C::LP + th;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) x[v][r] = valid ? p[Q * r] : cpx<T>{0, 0};
-    }
-    __syncthreads();  // the exchange buffer aliases the staging area
-  } else if constexpr (IN_ROWS) {
+  if constexpr (IN_ROWS) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       const uint64_t g = g0 + (uint64_t)(cg * VEC + v);
@@ -607,28 +593,7 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
   // ---- store
   const T scale = (T)a.scale;
   const cpx<T>* __restrict__ mul = (const cpx<T>*)a.mul;
-  if constexpr (STAGED) {
-    cpx<T>* stage = (cpx<T>*)smem;
-    if constexpr (Q > 1) __syncthreads();  // reads of the last exchange are done
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      cpx<T>* p = stage + (cg * VEC + v) * C::LP + th;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        cpx<T> y = x[v][r];
-        if (mul) y = cmul(y, mul[th + Q * r]);
-        if (a.swap_out) y = {y.im, y.re};
-        p[Q * r] = {y.re * scale, y.im * scale};
-      }
-    }
-    __syncthreads();
-    const uint64_t e0 = g0 * L, e_end = a.total_cols * (uint64_t)L;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const uint32_t le = (uint32_t)(tid + C::NT * r) * VEC;
-      if (e0 + le < e_end) store_unit_a8<T>(out + e0 + le, *(const Unit16<T>*)(stage + (le / L) * C::LP + (le % L)));
-    }
-  } else if constexpr (OUT_ROWS) {
+  if constexpr (OUT_ROWS) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       const uint64_t g = g0 + (uint64_t)(cg * VEC + v);
@@ -1149,11 +1114,90 @@ __global__ void __launch_bounds__(FOURIER_TWOLEVEL_NT(T, L1, L2), FOURIER_MIN_WA
   }
 }
 
-// ---- transforms of length 1, 2, 4, 8: one thread per transform ----
 struct TinyArgs {
   const void* in; void* out; const void* mul;
   uint64_t batch; int n; int swap_in, swap_out; double scale;
 };
+
+// ---- transforms of length 2, 4, 8, 16: one lane per transform, coalesced I/O through wave shuffles ----
+// A transform is U = N * sizeof(complex) / 16 consecutive 16-byte units.  The wave loads its 64 transforms as
+// 64*U consecutive units (lane l takes units l, 64 + l, ...: whole 1 KiB lines per instruction); U adjacent
+// lanes then hold one part each of U transforms, and a U x U transpose over those lanes (log2 U rounds of
+// __shfl_xor with a register select) hands every lane one whole transform for the in-register butterfly.  The
+// transpose is its own inverse, so the same routine restores the unit order for the coalesced store.
+template <int U> __device__ __forceinline__ void transpose_units(int (&reg)[U][4], int lane) {
+#pragma unroll
+  for (int s = 1; s < U; s <<= 1) {
+    const bool hi = (lane & s) != 0;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      if (j & s) continue;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {  // scalar selects: an array-element select would go through scratch memory
+        const int lo_reg = reg[j][d], hi_reg = reg[j ^ s][d];
+        const int recv = __shfl_xor(hi ? lo_reg : hi_reg, s);
+        reg[j][d] = hi ? recv : lo_reg;
+        reg[j ^ s][d] = hi ? hi_reg : recv;
+      }
+    }
+  }
+}
+template <typename T, int N>
+__global__ void __launch_bounds__(256) tiny_shfl_kernel(TinyArgs a) {
+  constexpr int VEC = 16 / (2 * (int)sizeof(T));
+  constexpr int U = N / VEC;
+  static_assert(U >= 1 && U <= 16, "tiny_shfl_kernel: 16..256-byte transforms");
+  const int lane = (int)threadIdx.x & 63;
+  const uint64_t wave = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const uint64_t u0 = wave * 64 * U, total_units = a.batch * (uint64_t)U;
+  const cpx<T>* in = (const cpx<T>*)a.in;
+  cpx<T>* out = (cpx<T>*)a.out;
+  int reg[U][4];
+#pragma unroll
+  for (int j = 0; j < U; ++j) {
+    const uint64_t u = u0 + (uint64_t)(64 * j + lane);
+    Unit16<T> v{};
+    if (u < total_units) v = load_unit_a8<T>(in + u * VEC);
+    __builtin_memcpy(reg[j], &v, 16);
+  }
+  transpose_units<U>(reg, lane);  // lane (g = lane / U, q = lane % U) owns transform (64 / U) * q + g of the wave
+  cpx<T> x[N];
+#pragma unroll
+  for (int j = 0; j < U; ++j) {
+    Unit16<T> v;
+    __builtin_memcpy(&v, reg[j], 16);
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      x[j * VEC + c] = {v.a[2 * c], v.a[2 * c + 1]};
+      if (a.swap_in) x[j * VEC + c] = {x[j * VEC + c].im, x[j * VEC + c].re};
+    }
+  }
+  dft_r<T, N>(x);
+  const T scale = (T)a.scale;
+  const cpx<T>* mul = (const cpx<T>*)a.mul;
+#pragma unroll
+  for (int j = 0; j < U; ++j) {
+    Unit16<T> v;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      cpx<T> y = x[j * VEC + c];
+      if (mul) y = cmul(y, mul[j * VEC + c]);
+      if (a.swap_out) y = {y.im, y.re};
+      v.a[2 * c] = y.re * scale; v.a[2 * c + 1] = y.im * scale;
+    }
+    __builtin_memcpy(reg[j], &v, 16);
+  }
+  transpose_units<U>(reg, lane);
+#pragma unroll
+  for (int j = 0; j < U; ++j) {
+    const uint64_t u = u0 + (uint64_t)(64 * j + lane);
+    Unit16<T> v;
+    __builtin_memcpy(&v, reg[j], 16);
+    if (u < total_units) store_unit_a8<T>(out + u * VEC, v);
+  }
+}
+
+// ---- transforms of length 1 (and the generic fallback form): one thread per transform ----
 template <typename T>
 __global__ void __launch_bounds__(256) tiny_dft_kernel(TinyArgs a) {
   const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;

@@ -48,6 +48,7 @@ namespace hipemu {
 struct Tls {
   dim3 tid, bid, bdim, gdim;
   unsigned char* smem = nullptr;
+  int* shfl = nullptr;  // one slot per thread of the block: cross-lane shuffles
   ucontext_t* sched = nullptr;
   ucontext_t* self = nullptr;
 };
@@ -142,6 +143,7 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, K kernel, A arg) {
     std::vector<ucontext_t> ctx(nthreads);
     std::vector<FiberArg> fargs(nthreads);
     std::vector<unsigned char> smem_buf(smem_bytes + 64);
+    std::vector<int> shfl_buf(nthreads);
     std::vector<size_t> log_mark(nthreads);
     std::vector<std::vector<LdsAccess>> tlog(nthreads);
     ucontext_t sched;
@@ -153,6 +155,7 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, K kernel, A arg) {
       t.bdim = block; t.gdim = grid;
       t.bid = dim3(b % grid.x, (b / grid.x) % grid.y, b / (grid.x * grid.y));
       t.smem = smem_buf.data();
+      t.shfl = shfl_buf.data();
       t.sched = &sched;
       std::memset(smem_buf.data(), 0xCD, smem_buf.size());  // poison: catches reads of unwritten LDS
       for (unsigned i = 0; i < nthreads; ++i) {
@@ -219,6 +222,16 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, K kernel, A arg) {
 #define blockDim (hipemu::tls().bdim)
 #define gridDim (hipemu::tls().gdim)
 inline void __syncthreads() { hipemu::syncthreads(); }
+// wave shuffle: every thread of the block must reach it (publish, barrier, read the partner's slot, barrier)
+inline int __shfl_xor(int v, int lane_mask) {
+  hipemu::Tls& t = hipemu::tls();
+  const unsigned i = t.tid.x + t.bdim.x * (t.tid.y + t.bdim.y * t.tid.z);
+  t.shfl[i] = v;
+  hipemu::syncthreads();
+  const int r = t.shfl[(i & ~63u) | ((i ^ (unsigned)lane_mask) & 63u)];
+  hipemu::syncthreads();
+  return r;
+}
 
 // ---- host API subset ----
 inline hipError_t hipMalloc(void** p, size_t n) { *p = n ? malloc(n) : nullptr; return (*p || !n) ? hipSuccess : hipErrorOutOfMemory; }

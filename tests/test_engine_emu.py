@@ -177,13 +177,14 @@ def test_bluestein_fusion_matches_unfused(fa):
     assert "fused" in make(fa, 3000, np.complex64).describe()
 
 
-def test_small_row_kernels_with_ragged_batches(fa):
-    """N = 16, 32, 64 stage whole transforms through LDS (coalesced 16-byte global accesses); batches that do
-    not fill the last workgroup, in and out of place, all scalings."""
+def test_lane_per_transform_and_small_row_kernels_with_ragged_batches(fa):
+    """N = 2..16 (f32: ..32) run one lane per transform: the wave loads coalesced 16-byte units and transposes
+    them across lanes with __shfl_xor; N = 32 (f64) / 64 are the smallest row kernels.  Batches that do not fill
+    the last wave / workgroup, in and out of place, several scalings."""
     for dtype, tol in ((np.complex64, 3e-7), (np.complex128, 1e-15)):
-        for n in (16, 32, 64):
+        for n in (2, 4, 8, 16, 32, 64):
             plan = make(fa, n, dtype)
-            for batch in (1, 2, 3, 31, 64, 127, 128, 129, 300):
+            for batch in (1, 2, 3, 31, 64, 65, 127, 128, 129, 257, 300):
                 x = np.stack([hash_normal(b * 7 + n, n) for b in range(batch)]).astype(dtype)
                 for code in (0, 1, 4):
                     x128 = x.astype(np.complex128)
