@@ -316,6 +316,45 @@ def test_c5_chunk_of_2p22(torch, fa, oracle):
     _full_size_properties(torch, fa, oracle, 1 << 22, 256, np.complex64, 1e-6)
 
 
+@pytest.mark.parametrize("log2n,dtype,tol", [(27, np.complex64, 1e-6), (26, np.complex128, 5e-14), (30, np.complex64, 1.5e-6)])
+def test_largest_three_pass_sizes_known_answers(torch, fa, log2n, dtype, tol):
+    """2^26 .. 2^30 (three passes, 1..8 GiB per transform): too long for the CPU oracle, so pinned by known answers
+    computed on the device in f64 -- a shifted impulse plus a tone transforms to a pure phase ramp plus a single
+    bin -- and by the in-place round trip."""
+    n = 1 << log2n
+    cdt = torch.complex64 if dtype == np.complex64 else torch.complex128
+    plan = make(fa, n, dtype)
+    p, q, amp = 12345, (n // 3) | 1, 0.5
+    k = torch.arange(n, device="cuda", dtype=torch.int64)
+    ang = (2.0 * np.pi / n) * torch.remainder(k * q, n).double()   # tone at bin q (k*q < 2^63: exact in int64)
+    x = torch.empty(n, dtype=cdt, device="cuda")
+    x.real = (amp * torch.cos(ang)).to(x.real.dtype)
+    x.imag = (amp * torch.sin(ang)).to(x.real.dtype)
+    x[p] += 1.0
+    del ang
+    y = torch.empty_like(x)
+    plan.transform(x.view(1, n), y.view(1, n), fa.Transform.Fft)
+    torch.cuda.synchronize()
+    ang = (-2.0 * np.pi / n) * torch.remainder(k * p, n).double()  # impulse at p -> exp(-2 pi i p k / n)
+    del k
+    err2 = ((y.real.double() - torch.cos(ang)) ** 2).sum()
+    err2 += ((y.imag.double() - torch.sin(ang)) ** 2).sum()
+    del ang
+    # the tone adds amp*n at bin q: remove it from the error sum analytically
+    yq = complex(y[q].item())
+    ph = -2.0 * np.pi * ((p * q) % n) / n
+    model_q = complex(np.cos(ph), np.sin(ph))
+    err2 = float(err2) - abs(yq - model_q) ** 2 + abs(yq - (model_q + amp * n)) ** 2
+    ref2 = float(n) + (amp * n) ** 2
+    assert np.sqrt(err2 / ref2) <= tol, (log2n, np.sqrt(err2 / ref2))
+    plan.transform_in_place(y.view(1, n), fa.Transform.Ifft)
+    torch.cuda.synchronize()
+    d = torch.view_as_real(y - x).double().pow(2).sum().sqrt() / torch.view_as_real(x).double().pow(2).sum().sqrt()
+    assert float(d) <= 2 * tol, (log2n, float(d))
+    del x, y
+    torch.cuda.empty_cache()
+
+
 def test_linearity(torch, fa):
     n = 1 << 20
     plan = make(fa, n, np.complex64)
