@@ -188,12 +188,20 @@ def main():
             plan.transform_batch_ptr(xs.data_ptr(), ys.data_ptr(), sample, int(Transform.Fft), stream)
             torch.cuda.synchronize(dev)
             got = ys.cpu().numpy()
-            ob = O.OracleBatch(n, hx.dtype, nthreads=cores)
+            # one oracle plan per thread (plans are Send, not Sync).  The port is memory-bound well before all
+            # hardware threads are busy, so a few thread counts are timed and the best aggregate is reported,
+            # with the count that produced it.
             ref = np.empty_like(hx)
-            ob.run(hx[: min(sample, cores)], O.FFT, out=ref[: min(sample, cores)])  # warm-up (page faults)
-            t0 = time.perf_counter()
-            ob.run(hx, O.FFT, out=ref)
-            cpu_s = time.perf_counter() - t0
+            tried = {}
+            for nt in sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8)}, reverse=True):
+                ob = O.OracleBatch(n, hx.dtype, nthreads=nt)
+                ob.run(hx[: min(sample, nt)], O.FFT, out=ref[: min(sample, nt)])  # warm-up (page faults)
+                t0 = time.perf_counter()
+                ob.run(hx, O.FFT, out=ref)
+                tried[nt] = time.perf_counter() - t0
+                del ob
+            used = min(tried, key=tried.get)
+            cpu_s = tried[used]
             # the reference itself is single-threaded (one plan, one slice per call): the same port on ONE core
             ob1 = O.OracleBatch(n, hx.dtype, nthreads=1)
             k1 = min(sample, 4)
@@ -206,10 +214,12 @@ def main():
             out["parity"] = {"sample_transforms": sample, "rel_l2_vs_oracle": err,
                              "tolerance": 1e-6 if args.dtype == "f32" else 5e-14}
             out["cpu_baseline"] = {
-                "value": round(sample * flops_per / cpu_s / 1e9, 2), "unit": "GFLOP/s", "cores": cores,
+                "value": round(sample * flops_per / cpu_s / 1e9, 2), "unit": "GFLOP/s", "cores": used,
+                "host_threads_available": cores,
+                "threads_tried_gflops": {str(k): round(sample * flops_per / v / 1e9, 2) for k, v in tried.items()},
                 "kind": "port",
                 "sample": f"{sample} of the same transforms ({args.dtype} N=2^{args.log2n}, out-of-place), "
-                          f"one oracle plan per thread, {cpu_s:.2f} s wall",
+                          f"one oracle plan per thread on {used} threads, {cpu_s:.2f} s wall",
                 "ms_per_transform_aggregate": round(cpu_s / sample * 1e3, 3),
                 "one_core": {"ms_per_transform": round(one_core_s * 1e3, 3), "value": round(flops_per / one_core_s / 1e9, 3),
                              "unit": "GFLOP/s", "sample": f"{k1} transforms on 1 thread"},
