@@ -294,6 +294,17 @@ def test_chunking_and_scratch_options_do_not_change_results(fa):
         assert np.array_equal(run_batch(plan, x, 0, inplace=True), base)
     with pytest.raises(fa.FourierError):
         make(fa, n, np.complex64).set_option("no_such_option", 1)
+    # the workgroup -> tile mappings are bijections: same bits whatever the mapping (two-pass, Bluestein conv and
+    # one-launch plans; batch sizes that do and do not divide by the XCD count)
+    for n2, batch2 in ((1 << 16, 3), (1 << 16, 8), (40000, 2), (4096, 5)):
+        x2 = np.stack([hash_normal(400 + b, n2) for b in range(batch2)]).astype(np.complex64)
+        base2 = run_batch(make(fa, n2, np.complex64), x2, 0)
+        for mode in (0, 1, 2, 3):
+            plan = make(fa, n2, np.complex64)
+            plan.set_option("xcd_swizzle", mode)
+            assert np.array_equal(run_batch(plan, x2, 0), base2), (n2, batch2, mode)
+    with pytest.raises(fa.FourierError):
+        make(fa, n, np.complex64).set_option("xcd_swizzle", 4)
 
 
 def test_linearity_and_roundtrip_properties(fa):
