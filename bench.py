@@ -193,7 +193,7 @@ def main():
             # with the count that produced it.
             ref = np.empty_like(hx)
             tried = {}
-            for nt in sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8)}, reverse=True):
+            for nt in sorted({max(1, cores >> k) for k in range(6)}, reverse=True):  # all, 1/2 ... 1/32 of the host threads
                 ob = O.OracleBatch(n, hx.dtype, nthreads=nt)
                 ob.run(hx[: min(sample, nt)], O.FFT, out=ref[: min(sample, nt)])  # warm-up (page faults)
                 t0 = time.perf_counter()
