@@ -22,6 +22,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "fft_kernels.h"
@@ -997,6 +998,49 @@ template <typename T> class Plan {
   }
   static constexpr size_t ZERO_COPY_MAX = 256 * 1024;
 
+  // Batched transform on HOST memory (extension; the reference's callers hold host slices, fft.rs:48-61): `batch`
+  // contiguous transforms are streamed through the device in chunks.  NSLOTS slots of pinned staging + device buffer;
+  // the H2D copy of chunk i+1, the kernels of chunk i and the D2H copy of chunk i-1 run on three streams, and
+  // the calling thread (helped by a few copy threads) moves pageable user memory in and out of the staging
+  // buffers meanwhile.  Synchronous: returns when `h_out` is complete.  h_in == h_out is allowed.
+  void exec_host_batch(const void* h_in, void* h_out, size_t batch, int code) const {
+    if (!h_in || !h_out) throw EngineError(::fourier::c::FOURIER_HIP_INVALID_ARGUMENT, "null buffer");
+    if (code < 0 || code > 4) throw EngineError(::fourier::c::FOURIER_HIP_INVALID_ARGUMENT, "unknown transform code");
+    if (batch == 0) return;
+    DeviceGuard g(device_);
+    const size_t per = n_ * ELEM;
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(batch, HOST_CHUNK_BYTES / per));
+    const size_t nchunks = (batch + chunk - 1) / chunk;
+    pipe_.ensure(chunk * per);
+    const char* src = (const char*)h_in;
+    char* dst = (char*)h_out;
+    auto chunk_bytes = [&](size_t i) { return std::min(chunk, batch - i * chunk) * per; };
+    for (size_t i = 0; i < nchunks + NSLOTS; ++i) {
+      const int s = (int)(i % NSLOTS);
+      CopyJob jobs[2];
+      int njobs = 0;
+      if (i >= NSLOTS) {  // chunk i-NSLOTS used this slot: its result is in the staging buffer once its D2H has finished
+        HIP_CHECK(hipEventSynchronize(pipe_.d2h_done[s]));
+        jobs[njobs++] = {dst + (i - NSLOTS) * chunk * per, pipe_.pin_out[s].h, chunk_bytes(i - NSLOTS)};
+      }
+      if (i < nchunks) jobs[njobs++] = {pipe_.pin_in[s].h, src + i * chunk * per, chunk_bytes(i)};
+      parallel_copy(jobs, njobs);  // result of chunk i-NSLOTS out of, input of chunk i into the staging buffers, together
+      if (i < nchunks) {
+        const size_t bytes = chunk_bytes(i);
+        HIP_CHECK(hipMemcpyAsync(pipe_.dev[s].p, pipe_.pin_in[s].h, bytes, hipMemcpyHostToDevice, pipe_.s_h2d));
+        HIP_CHECK(hipEventRecord(pipe_.h2d_done[s], pipe_.s_h2d));
+        HIP_CHECK(hipStreamWaitEvent(pipe_.s_comp, pipe_.h2d_done[s], 0));
+        exec(pipe_.dev[s].p, pipe_.dev[s].p, bytes / per, code, pipe_.s_comp);
+        HIP_CHECK(hipEventRecord(pipe_.comp_done[s], pipe_.s_comp));
+        HIP_CHECK(hipStreamWaitEvent(pipe_.s_d2h, pipe_.comp_done[s], 0));
+        HIP_CHECK(hipMemcpyAsync(pipe_.pin_out[s].h, pipe_.dev[s].p, bytes, hipMemcpyDeviceToHost, pipe_.s_d2h));
+        HIP_CHECK(hipEventRecord(pipe_.d2h_done[s], pipe_.s_d2h));
+      }
+    }
+  }
+  static constexpr size_t HOST_CHUNK_BYTES = (size_t)32 << 20;
+  static constexpr size_t NSLOTS = 4;  // chunks in flight: copy-in, H2D, kernels, D2H + copy-out each take about one chunk time
+
  private:
   struct DeviceGuard {
     int prev = -1;
@@ -1056,6 +1100,55 @@ template <typename T> class Plan {
     for (size_t k = 0; k < m_; ++k) w[k] = {(T)(wr[k] * inv_m), (T)(wi[k] * inv_m)};
     wtab_.upload(w);
   }
+
+  // pageable <-> pinned copies of a chunk, split over a few threads (one core moves ~10 GB/s, PCIe wants 50+ each way)
+  struct CopyJob { void* dst; const void* src; size_t bytes; };
+  static void parallel_copy(const CopyJob* jobs, int njobs) {
+    std::vector<std::thread> th;
+    for (int j = 0; j < njobs; ++j) {
+      const CopyJob job = jobs[j];
+      const size_t nt = std::max<size_t>(1, std::min<size_t>(COPY_THREADS, job.bytes / ((size_t)2 << 20)));
+      const size_t piece = ((job.bytes / nt) + 4095) & ~(size_t)4095;
+      for (size_t t = 0; t < nt; ++t) {
+        const size_t off = t * piece;
+        if (off >= job.bytes) break;
+        const size_t len = std::min(piece, job.bytes - off);
+        if (nt == 1 && njobs == 1) { std::memcpy(job.dst, job.src, len); return; }
+        th.emplace_back([=] { std::memcpy((char*)job.dst + off, (const char*)job.src + off, len); });
+      }
+    }
+    for (auto& t : th) t.join();
+  }
+  static constexpr size_t COPY_THREADS = 12;
+  struct HostPipe {  // exec_host_batch: NSLOTS slots, three streams
+    static constexpr int NS = 4;
+    PinnedBuf pin_in[NS], pin_out[NS];
+    DevBuf dev[NS];
+    hipStream_t s_h2d = nullptr, s_comp = nullptr, s_d2h = nullptr;
+    hipEvent_t h2d_done[NS] = {}, comp_done[NS] = {}, d2h_done[NS] = {};
+    void ensure(size_t bytes) {
+      if (!s_h2d) {
+        HIP_CHECK(hipStreamCreateWithFlags(&s_h2d, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&s_comp, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&s_d2h, hipStreamNonBlocking));
+        for (int s = 0; s < NS; ++s) {
+          HIP_CHECK(hipEventCreateWithFlags(&h2d_done[s], hipEventDisableTiming));
+          HIP_CHECK(hipEventCreateWithFlags(&comp_done[s], hipEventDisableTiming));
+          HIP_CHECK(hipEventCreateWithFlags(&d2h_done[s], hipEventDisableTiming));
+        }
+      }
+      for (int s = 0; s < NS; ++s) { pin_in[s].ensure(bytes); pin_out[s].ensure(bytes); dev[s].ensure(bytes); }
+    }
+    ~HostPipe() {
+      for (int s = 0; s < NS; ++s)
+        for (hipEvent_t e : {h2d_done[s], comp_done[s], d2h_done[s]})
+          if (e) (void)hipEventDestroy(e);
+      for (hipStream_t st : {s_h2d, s_comp, s_d2h})
+        if (st) (void)hipStreamDestroy(st);
+    }
+  };
+  static_assert(NSLOTS == HostPipe::NS, "slot count");
+  mutable HostPipe pipe_;
 
   size_t n_, m_ = 0;
   int device_ = 0;
@@ -1134,6 +1227,11 @@ namespace fc = ::fourier::c;
                                                       void* d_out, size_t batch, int code, void* stream) {       \
     const Plan<T>* p = (const Plan<T>*)h;                                                                        \
     return guarded<T>(p, [&] { p->exec(d_in, d_out, batch, code, (hipStream_t)stream); });                       \
+  }                                                                                                              \
+  extern "C" int fourier_hip_transform_batch_host_##SUFFIX(const fc::fourier_fft_##SUFFIX* h, const std::complex<T>* in, \
+                                                           std::complex<T>* out, size_t batch, int code) {      \
+    const Plan<T>* p = (const Plan<T>*)h;                                                                        \
+    return guarded<T>(p, [&] { p->exec_host_batch(in, out, batch, code); });                                     \
   }                                                                                                              \
   extern "C" int fourier_hip_profile_##SUFFIX(const fc::fourier_fft_##SUFFIX* h, const void* d_in, void* d_out,  \
                                               size_t batch, int code, void* stream, int nslots, float* ms_sum,   \

@@ -8,7 +8,8 @@ plus the batched, device-resident entry point the GPU path is measured on (the r
 batch API: fft.rs:48-61 takes one slice per call).
 
 Buffers: numpy complex64/complex128 arrays go through the legacy host ABI (H2D + D2H inside the
-library); torch CUDA tensors go through the device-resident batched ABI on the current stream.
+library; arrays holding several transforms are streamed through the device in chunks); torch CUDA
+tensors go through the device-resident batched ABI on the current stream.
 All compute happens in libfourier.so (HIP); there is no CPU fallback.
 """
 import enum
@@ -90,6 +91,19 @@ class Fft:
         if st != 0:
             raise FourierError(self._L.fourier_hip_status_string(st).decode())
 
+    def transform_batch_host(self, input, output, transform):
+        """`batch` contiguous transforms in host (numpy) memory, streamed through the device in chunks with
+        copies and kernels overlapped; synchronous.  input may be output (in place)."""
+        for a in (input, output):
+            if not (isinstance(a, np.ndarray) and a.dtype == self.np_dtype and a.flags.c_contiguous):
+                raise TypeError(f"expected C-contiguous numpy {self.np_dtype} arrays")
+        if input.size != output.size or input.size % self._n != 0:
+            raise ValueError(f"buffers of {input.size}/{output.size} elements are not the same whole number of transforms")
+        st = getattr(self._L, f"fourier_hip_transform_batch_host_{self._suffix}")(
+            self._h, input.ctypes.data, output.ctypes.data, input.size // self._n, int(transform))
+        if st != 0:
+            raise FourierError(self._L.fourier_hip_status_string(st).decode())
+
     def profile_batch_ptr(self, d_in, d_out, batch, transform, stream=0, nslots=16):
         """One batched transform with a HIP event pair around every kernel launch.
         Returns [(slot_name, total_ms, launches), ...] in launch order."""
@@ -135,10 +149,14 @@ class Fft:
         for a in (input, output):
             if not (isinstance(a, np.ndarray) and a.dtype == self.np_dtype and a.flags.c_contiguous):
                 raise TypeError(f"expected C-contiguous numpy {self.np_dtype} arrays")
-        if input.size != self._n or output.size != self._n:
-            raise ValueError(f"buffer length {input.size}/{output.size} != size {self._n}")  # fft.rs:57-58
         if not output.flags.writeable:
             raise ValueError("output is read-only")
+        if input.size == output.size and input.size > self._n and input.size % self._n == 0:
+            # several whole transforms in host memory: streamed through the device (extension)
+            self.transform_batch_host(input, output, transform)
+            return
+        if input.size != self._n or output.size != self._n:
+            raise ValueError(f"buffer length {input.size}/{output.size} != size {self._n}")  # fft.rs:57-58
         if input is output or input.ctypes.data == output.ctypes.data:
             getattr(self._L, f"fourier_transform_in_place_{self._suffix}")(self._h, output.ctypes.data, code)
         else:

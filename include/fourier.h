@@ -107,6 +107,18 @@ int fourier_hip_transform_batch_double(const FOURIER_STRUCT fourier_fft_double *
                                        void *d_out, FOURIER_SIZE_TYPE batch, int transform,
                                        void *stream);
 
+/* Batched `Fft::transform` on HOST memory -- what a caller of the reference holds (one slice per transform,
+ * fourier-algorithms/src/fft.rs:48-61), `batch` of them contiguously.  The transforms are streamed through the
+ * device in chunks (pinned staging; the host-to-device copy of one chunk, the kernels of the previous one and the
+ * device-to-host copy of the one before overlap), so the rate is PCIe's, not one call's latency.  Synchronous:
+ * `out` is complete on return.  in == out selects in-place; partial overlap is not allowed. */
+int fourier_hip_transform_batch_host_float(const FOURIER_STRUCT fourier_fft_float *,
+                                           const FOURIER_COMPLEX_FLOAT_TYPE *in, FOURIER_COMPLEX_FLOAT_TYPE *out,
+                                           FOURIER_SIZE_TYPE batch, int transform);
+int fourier_hip_transform_batch_host_double(const FOURIER_STRUCT fourier_fft_double *,
+                                            const FOURIER_COMPLEX_DOUBLE_TYPE *in, FOURIER_COMPLEX_DOUBLE_TYPE *out,
+                                            FOURIER_SIZE_TYPE batch, int transform);
+
 /* Sticky status of the last failing call on this handle (FOURIER_HIP_OK if none) and its text. */
 int fourier_hip_last_status_float(const FOURIER_STRUCT fourier_fft_float *);
 int fourier_hip_last_status_double(const FOURIER_STRUCT fourier_fft_double *);

@@ -355,6 +355,27 @@ def test_largest_three_pass_sizes_known_answers(torch, fa, log2n, dtype, tol):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("n,batch,dtype,tol", [(1 << 20, 40, np.complex64, 1e-6), (4096, 70000, np.complex64, 1e-6),
+                                               (999983, 20, np.complex64, 2e-6), (1 << 18, 70, np.complex128, 5e-14)])
+def test_host_batched_entry_point(torch, fa, oracle, n, batch, dtype, tol):
+    """Host arrays of many transforms streamed through the device in chunks (several chunks in every case here):
+    identical to the device-resident batched result, sampled transforms against the oracle, in place too."""
+    rng = np.random.default_rng(n + batch)
+    x = (rng.random((batch, n), dtype=np.float32 if dtype == np.complex64 else np.float64)
+         + 1j * rng.random((batch, n), dtype=np.float32 if dtype == np.complex64 else np.float64)).astype(dtype)
+    plan = make(fa, n, dtype)
+    y = np.empty_like(x)
+    plan.transform_batch_host(x, y, fa.Transform.Fft)
+    for b in (0, batch // 2, batch - 1):
+        ref = oracle.transform_batch(x[b:b + 1], oracle.FFT)
+        assert rel_l2(y[b], ref[0]) <= tol, (n, b, rel_l2(y[b], ref[0]))
+    sl = slice(0, batch, max(1, batch // 16))
+    assert np.array_equal(gpu_batch(torch, fa, plan, x[sl], 0), y[sl])
+    z = x.copy()
+    plan.transform(z, z, fa.Transform.Fft)
+    assert np.array_equal(z, y)
+
+
 def test_linearity(torch, fa):
     n = 1 << 20
     plan = make(fa, n, np.complex64)
