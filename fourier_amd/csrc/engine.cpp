@@ -875,6 +875,7 @@ template <typename T> class Plan {
       return 0;
     }
     if (key == "bluestein_conv" && (v == 0 || v == 1)) { conv_ = (v == 1) && conv_ok_; return 0; }
+    if (key == "host_chunk_bytes" && v > 0) { host_chunk_bytes_ = (size_t)v; return 0; }
     return ::fourier::c::FOURIER_HIP_INVALID_ARGUMENT;
   }
 
@@ -1009,7 +1010,7 @@ template <typename T> class Plan {
     if (batch == 0) return;
     DeviceGuard g(device_);
     const size_t per = n_ * ELEM;
-    const size_t chunk = std::max<size_t>(1, std::min<size_t>(batch, HOST_CHUNK_BYTES / per));
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(batch, host_chunk_bytes_ / per));
     const size_t nchunks = (batch + chunk - 1) / chunk;
     pipe_.ensure(chunk * per);
     const char* src = (const char*)h_in;
@@ -1159,6 +1160,7 @@ template <typename T> class Plan {
   mutable DevBuf scratch_, work_, hostio_;
   mutable PinnedBuf pinned_;
   size_t chunk_bytes_ = 0;
+  size_t host_chunk_bytes_ = HOST_CHUNK_BYTES;  // exec_host_batch: bytes of one streamed chunk
   bool force_scratch_ = false;
   bool fused_ = false;  // Bluestein: chirp steps fused into the inner passes
   bool small_fused_ = false;  // Bluestein with M <= 2^15: everything in one launch

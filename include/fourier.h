@@ -132,6 +132,7 @@ const char *fourier_hip_status_string(int status);
  *   "xcd_swizzle"  1 (default) = XCD-aware workgroup->tile mapping (each XCD owns a contiguous run of transforms),
  *                  2 = XCDs interleaved over adjacent transforms, 0 = plain blockIdx order
  *   "bluestein_fusion" 1 (default where the inner FFT has >= 2 passes) = chirp steps fused into the inner passes
+ *   "host_chunk_bytes" bytes of one chunk of fourier_hip_transform_batch_host_* (default 32 MiB, four in flight)
  *   "bluestein_conv"   1 (default with bluestein_fusion) = the forward inner FFT's last pass, the multiply by the
  *                  transformed chirp and the inverse inner FFT's first pass run as one launch */
 int fourier_hip_set_option_float(FOURIER_STRUCT fourier_fft_float *, const char *key, long long value);
