@@ -983,7 +983,10 @@ template <typename T> class Plan {
     DeviceGuard g(device_);
     const size_t bytes = n_ * ELEM;
     pinned_.ensure(bytes);
-    std::memcpy(pinned_.h, h_in, bytes);
+    {
+      const CopyJob in_job{pinned_.h, h_in, bytes};
+      parallel_copy(&in_job, 1);  // one thread below 4 MiB, a few above (a 2^20-point transform is 8-16 MiB)
+    }
     if (bytes <= ZERO_COPY_MAX) {
       // small transforms are latency-bound: the kernels read and write the mapped host buffer directly over
       // PCIe (every plan reads its input once and writes its output once) -- one launch chain, one sync
@@ -995,7 +998,8 @@ template <typename T> class Plan {
       HIP_CHECK(hipMemcpyAsync(pinned_.h, hostio_.p, bytes, hipMemcpyDeviceToHost, (hipStream_t)0));
     }
     HIP_CHECK(hipStreamSynchronize((hipStream_t)0));
-    std::memcpy(h_out, pinned_.h, bytes);
+    const CopyJob out_job{h_out, pinned_.h, bytes};
+    parallel_copy(&out_job, 1);
   }
   static constexpr size_t ZERO_COPY_MAX = 256 * 1024;
 

@@ -130,7 +130,8 @@ const char *fourier_hip_status_string(int status);
  *   "scratch"      1 = always route the intermediate through the plan's reused scratch buffer,
  *                  0 = use the output buffer as intermediate when out of place (default)
  *   "xcd_swizzle"  1 (default) = XCD-aware workgroup->tile mapping (each XCD owns a contiguous run of transforms),
- *                  2 = XCDs interleaved over adjacent transforms, 0 = plain blockIdx order
+ *                  2 = XCDs interleaved over adjacent transforms, 3 = each XCD owns an eighth of every transform's
+ *                  tiles (both measured slower, kept for experiments), 0 = plain blockIdx order
  *   "bluestein_fusion" 1 (default where the inner FFT has >= 2 passes) = chirp steps fused into the inner passes
  *   "host_chunk_bytes" bytes of one chunk of fourier_hip_transform_batch_host_* (default 32 MiB, four in flight)
  *   "bluestein_conv"   1 (default with bluestein_fusion) = the forward inner FFT's last pass, the multiply by the

@@ -3,8 +3,8 @@
 ranks of one node with no data-path collective.  The input does not fit anywhere at once, so every rank
 walks its contiguous shard (fourier_amd.shard.batch_shard) in fixed chunks, regenerating each chunk on the
 device (in place, seeded by the chunk's first transform index) and transforming it in place; the first
-transform of a few chunks is checked against the CPU oracle.  Launch: `python tools/run_c5.py` (1 GPU) or
-`python -m torch.distributed.run --nproc-per-node N tools/run_c5.py`.  Prints one JSON line on rank 0."""
+transform of a few chunks is checked against the CPU oracle.  Launch: `python tests/harness/run_c5.py` (1 GPU) or
+`python -m torch.distributed.run --nproc-per-node N tests/harness/run_c5.py`.  Prints one JSON line on rank 0."""
 import argparse
 import json
 import math
@@ -12,7 +12,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 
@@ -44,6 +44,10 @@ def main():
     buf = torch.empty((args.chunk, n), dtype=torch.complex64, device=dev)
     gen = torch.Generator(device=dev)
     checks = []
+    # untimed warm-up on one chunk: sizes the plan's 32 GiB in-place scratch (a one-off allocation, like plan creation)
+    buf.zero_()
+    plan.transform_in_place(buf, Transform.Fft)
+    torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
