@@ -198,6 +198,12 @@ template <typename T> struct fft;
       return ::fourier::c::fourier_hip_transform_batch_##SUFFIX(impl.get(), d_in, d_out, batch,    \
                                                                 static_cast<int>(t), stream);      \
     }                                                                                              \
+    /* many transforms in host memory, streamed through the device (extension) */                 \
+    int transform_batch_host(const ::std::complex<T> *in, ::std::complex<T> *out, std::size_t batch, \
+                             ::fourier::transform t) const {                                       \
+      return ::fourier::c::fourier_hip_transform_batch_host_##SUFFIX(impl.get(), in, out, batch,   \
+                                                                     static_cast<int>(t));         \
+    }                                                                                              \
     explicit operator bool() const { return static_cast<bool>(impl); }                             \
                                                                                                    \
   private:                                                                                         \

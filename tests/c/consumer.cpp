@@ -19,7 +19,14 @@ template <typename T> static int check() {
     if (std::abs(out[i] - std::complex<T>(T(0.5), 0)) > T(1e-6)) return 3;
   fourier::fft<T> moved(std::move(fft));
   moved.transform(in, out, fourier::transform::unscaled_ifft);
-  return std::abs(out[0] - std::complex<T>(1, 0)) > T(1e-6) ? 4 : 0;
+  if (std::abs(out[0] - std::complex<T>(1, 0)) > T(1e-6)) return 4;
+  // extension: several transforms held in host memory, one call (impulses at 0, 1, 2 -> 1, -i at bin 1, +1 at bin 2)
+  std::complex<T> many[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}, res[12];
+  if (moved.transform_batch_host(many, res, 3, fourier::transform::fft) != 0) return 5;
+  if (std::abs(res[0] - std::complex<T>(1, 0)) > T(1e-6) || std::abs(res[5] - std::complex<T>(0, -1)) > T(1e-6) ||
+      std::abs(res[10] - std::complex<T>(1, 0)) > T(1e-6))
+    return 6;
+  return 0;
 }
 
 int main() {
