@@ -740,9 +740,29 @@ template <typename T> class MixedEngine {
     // fill the 256 threads better lose more in occupancy than they gain, r01 session 9)
     group_ = (uint32_t)std::max<size_t>(1, 1024 / n);
     smem_ = 2 * (size_t)group_ * n * sizeof(cpx<T>);
+    fn_ = &mixed_radix_kernel<T>;
+    if (!getenv("FOURIER_MIX_GENERIC")) {  // lengths with a compile-time specialisation (same arithmetic, constant index math)
+#define FOURIER_MIX_CT(NN)                                                      \
+  case NN:                                                                      \
+    if constexpr ((size_t)NN <= MAX_N) fn_ = &mixed_radix_kernel_ct<T, NN>;     \
+    break;
+      switch (n) {  // every 2^a * 3^b (b >= 1) the engine runs in LDS: 3 ... 9216 (f32) / 4608 (f64)
+        FOURIER_MIX_CT(3) FOURIER_MIX_CT(6) FOURIER_MIX_CT(9) FOURIER_MIX_CT(12) FOURIER_MIX_CT(18) FOURIER_MIX_CT(24)
+        FOURIER_MIX_CT(27) FOURIER_MIX_CT(36) FOURIER_MIX_CT(48) FOURIER_MIX_CT(54) FOURIER_MIX_CT(72) FOURIER_MIX_CT(81)
+        FOURIER_MIX_CT(96) FOURIER_MIX_CT(108) FOURIER_MIX_CT(144) FOURIER_MIX_CT(162) FOURIER_MIX_CT(192) FOURIER_MIX_CT(216)
+        FOURIER_MIX_CT(243) FOURIER_MIX_CT(288) FOURIER_MIX_CT(324) FOURIER_MIX_CT(384) FOURIER_MIX_CT(432) FOURIER_MIX_CT(486)
+        FOURIER_MIX_CT(576) FOURIER_MIX_CT(648) FOURIER_MIX_CT(729) FOURIER_MIX_CT(768) FOURIER_MIX_CT(864) FOURIER_MIX_CT(972)
+        FOURIER_MIX_CT(1152) FOURIER_MIX_CT(1296) FOURIER_MIX_CT(1458) FOURIER_MIX_CT(1536) FOURIER_MIX_CT(1728) FOURIER_MIX_CT(1944)
+        FOURIER_MIX_CT(2187) FOURIER_MIX_CT(2304) FOURIER_MIX_CT(2592) FOURIER_MIX_CT(2916) FOURIER_MIX_CT(3072) FOURIER_MIX_CT(3456)
+        FOURIER_MIX_CT(3888) FOURIER_MIX_CT(4374) FOURIER_MIX_CT(4608) FOURIER_MIX_CT(5184) FOURIER_MIX_CT(5832) FOURIER_MIX_CT(6144)
+        FOURIER_MIX_CT(6561) FOURIER_MIX_CT(6912) FOURIER_MIX_CT(7776) FOURIER_MIX_CT(8748) FOURIER_MIX_CT(9216)
+        default: break;
+      }
+#undef FOURIER_MIX_CT
+    }
 #ifndef FOURIER_EMU
     if (smem_ > 48 * 1024)
-      HIP_CHECK(hipFuncSetAttribute((const void*)&mixed_radix_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_));
+      HIP_CHECK(hipFuncSetAttribute((const void*)fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_));
 #endif
   }
   std::string describe() const {
@@ -765,13 +785,14 @@ template <typename T> class MixedEngine {
     const uint64_t grid = (batch + group_ - 1) / group_;
     if (grid > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");
     PROF_BEGIN(prof, 0);
-    FOURIER_LAUNCH(&mixed_radix_kernel<T>, grid, 256, smem_, stream, a);
+    FOURIER_LAUNCH(fn_, grid, 256, smem_, stream, a);
     PROF_END(prof);
   }
 
  private:
   size_t n_;
   uint32_t counts_[5];
+  void (*fn_)(MixArgs) = nullptr;
   uint32_t group_ = 1;
   size_t smem_ = 0;
   DevBuf tw_;

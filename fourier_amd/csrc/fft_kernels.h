@@ -1419,6 +1419,74 @@ __device__ __forceinline__ void dft_pow3(cpx<T>* x, const OddArgs& a) {
   }
 }
 
+template <typename T, int R> __device__ __forceinline__ void ref_butterfly(cpx<T>* x, bool fwd, cpx<T> w3, cpx<T> w8) {
+  if constexpr (R == 2) ref_bf2(x[0], x[1]);
+  else if constexpr (R == 3) ref_bf3(x, w3);
+  else if constexpr (R == 4) ref_bf4(x, fwd);
+  else ref_bf8(x, fwd, w8);
+}
+// ---- the same kernel with the transform length fixed at compile time ----
+// For the sizes the reference itself benchmarks (3^5, 3^6, 3^7, fft_bench.rs:153-159) and the common 3*2^k / 9*2^k
+// lengths: schedule, sizes, strides and table offsets are constants, so the per-butterfly index arithmetic
+// (two runtime divisions in mixed_pass) folds into multiply-shifts and the pass loop unrolls.  Same operations in
+// the same order: still bit-identical to the CPU restatement.
+constexpr uint32_t mix_next_radix(uint32_t cur, bool first) {  // autosort/mod.rs:104-116
+  return (first && cur % 4 == 0) ? 4u : (cur % 8 == 0 ? 8u : (cur % 4 == 0 ? 4u : (cur % 3 == 0 ? 3u : 2u)));
+}
+template <typename T, uint32_t N, uint32_t SIZE, uint32_t STRIDE, uint32_t TWOFF, bool FIRST_PASS> struct MixPassesCT {
+  static __device__ __forceinline__ const cpx<T>* run(const cpx<T>* src, cpx<T>* dst, const cpx<T>* tw, uint32_t nb, bool fwd,
+                                                     cpx<T> w3, cpx<T> w8) {
+    constexpr uint32_t R = mix_next_radix(SIZE, FIRST_PASS), M = SIZE / R, NBF = N / R;
+    const cpx<T>* __restrict__ t = tw + TWOFF;
+    for (uint32_t q = threadIdx.x; q < nb * NBF; q += 256) {
+      const uint32_t g = q / NBF, e = q % NBF, i = e / STRIDE, j = e % STRIDE;  // constants: multiply-shift
+      const cpx<T>* in = src + g * N + j + STRIDE * i;
+      cpx<T> x[R];
+#pragma unroll
+      for (uint32_t k = 0; k < R; ++k) x[k] = in[STRIDE * M * k];
+      ref_butterfly<T, (int)R>(x, fwd, w3, w8);
+      if constexpr (SIZE != R) {  // mod.rs:238,272
+#pragma unroll
+        for (uint32_t k = 1; k < R; ++k) {
+          cpx<T> w = t[i * R + k];
+          if (!fwd) w.im = -w.im;
+          x[k] = ref_mul(x[k], w);
+        }
+      }
+      cpx<T>* out = dst + g * N + j + R * STRIDE * i;
+#pragma unroll
+      for (uint32_t k = 0; k < R; ++k) out[STRIDE * k] = x[k];
+    }
+    __syncthreads();
+    if constexpr (SIZE == R) return dst;
+    else return MixPassesCT<T, N, SIZE / R, STRIDE * R, TWOFF + SIZE, false>::run(dst, const_cast<cpx<T>*>(src), tw, nb, fwd, w3, w8);
+  }
+};
+template <typename T, uint32_t N>
+__global__ void __launch_bounds__(256) mixed_radix_kernel_ct(MixArgs a) {
+  FOURIER_DYN_SMEM(smem);
+  constexpr uint32_t GROUP = (1024 / N) ? (1024 / N) : 1;
+  cpx<T>* buf0 = (cpx<T>*)smem;
+  cpx<T>* buf1 = buf0 + (size_t)GROUP * N;
+  const uint64_t b0 = (uint64_t)blockIdx.x * GROUP;
+  const uint32_t nb = (uint32_t)((a.batch - b0) < GROUP ? (a.batch - b0) : GROUP);
+  const uint32_t total = nb * N;
+  const cpx<T>* in = (const cpx<T>*)a.in + b0 * N;
+  cpx<T>* out = (cpx<T>*)a.out + b0 * N;
+  for (uint32_t idx = threadIdx.x; idx < total; idx += 256) buf0[idx] = in[idx];
+  __syncthreads();
+  const bool fwd = a.forward != 0;
+  cpx<T> w3{(T)a.w3re, (T)a.w3im}, w8{(T)a.w8re, (T)a.w8im};
+  if (!fwd) { w3.im = -w3.im; w8.im = -w8.im; }
+  const cpx<T>* res = MixPassesCT<T, N, N, 1, 0, true>::run(buf0, buf1, (const cpx<T>*)a.tw, nb, fwd, w3, w8);
+  const T scale = (T)a.scale;
+  for (uint32_t idx = threadIdx.x; idx < total; idx += 256) {
+    cpx<T> y = res[idx];
+    if (a.scaled) y = {y.re * scale, y.im * scale};  // mod.rs:387-393
+    out[idx] = y;
+  }
+}
+
 template <typename T, int R>
 __global__ void __launch_bounds__(256) odd_last_kernel(OddArgs a) {
   constexpr int VEC = 16 / (2 * (int)sizeof(T));

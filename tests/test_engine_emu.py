@@ -146,6 +146,19 @@ def test_mixed_radix_sizes_are_bit_identical_to_the_oracle(fa, oracle):
         assert np.array_equal(run_batch(make(fa, n, dtype), xb, 0), oracle.transform_batch(xb, 0)), n
 
 
+def test_length_specialised_mixed_kernels_equal_the_generic_one(fa, monkeypatch):
+    """Every LDS-resident 2^a*3^b length has a kernel instantiation with the schedule, strides and table offsets as
+    compile-time constants; the runtime-parameterised kernel (FOURIER_MIX_GENERIC) must give the same bits."""
+    for n in (3, 54, 243, 768, 2187, 4374, 6561):
+        x = np.stack([hash_normal(31 + b, n) for b in range(5)]).astype(np.complex64)
+        fast = make(fa, n, np.complex64)
+        monkeypatch.setenv("FOURIER_MIX_GENERIC", "1")
+        slow = make(fa, n, np.complex64)
+        monkeypatch.delenv("FOURIER_MIX_GENERIC")
+        for code in (0, 1, 4):
+            assert np.array_equal(run_batch(fast, x, code), run_batch(slow, x, code)), (n, code)
+
+
 def test_large_mixed_radix_sizes_run_natively(fa, oracle):
     """N = 2^a*3^b (a >= 12, b <= 3): big-radix passes over the 2^a part + one final radix-3^b Stockham pass
     (the reference's order, RADICES = [4,8,4,3,2]); every code, in and out of place, against the oracle."""
