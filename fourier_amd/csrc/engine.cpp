@@ -739,12 +739,11 @@ template <typename T> class MixedEngine {
     // transforms per workgroup: about 1024 points (16 KiB of LDS in f32: several workgroups per CU; larger groups that
     // fill the 256 threads better lose more in occupancy than they gain, r01 session 9)
     group_ = (uint32_t)std::max<size_t>(1, 1024 / n);
-    smem_ = 2 * (size_t)group_ * n * sizeof(cpx<T>);
     fn_ = &mixed_radix_kernel<T>;
     if (!getenv("FOURIER_MIX_GENERIC")) {  // lengths with a compile-time specialisation (same arithmetic, constant index math)
 #define FOURIER_MIX_CT(NN)                                                      \
   case NN:                                                                      \
-    if constexpr ((size_t)NN <= MAX_N) fn_ = &mixed_radix_kernel_ct<T, NN>;     \
+    if constexpr ((size_t)NN <= MAX_N) { fn_ = &mixed_radix_kernel_ct<T, NN>; group_ = mix_group<T>(NN); } \
     break;
       switch (n) {  // every 2^a * 3^b (b >= 1) the engine runs in LDS: 3 ... 9216 (f32) / 4608 (f64)
         FOURIER_MIX_CT(3) FOURIER_MIX_CT(6) FOURIER_MIX_CT(9) FOURIER_MIX_CT(12) FOURIER_MIX_CT(18) FOURIER_MIX_CT(24)
@@ -760,6 +759,7 @@ template <typename T> class MixedEngine {
       }
 #undef FOURIER_MIX_CT
     }
+    smem_ = 2 * (size_t)group_ * n * sizeof(cpx<T>);
 #ifndef FOURIER_EMU
     if (smem_ > 48 * 1024)
       HIP_CHECK(hipFuncSetAttribute((const void*)fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_));

@@ -1430,6 +1430,13 @@ template <typename T, int R> __device__ __forceinline__ void ref_butterfly(cpx<T
 // lengths: schedule, sizes, strides and table offsets are constants, so the per-butterfly index arithmetic
 // (two runtime divisions in mixed_pass) folds into multiply-shifts and the pass loop unrolls.  Same operations in
 // the same order: still bit-identical to the CPU restatement.
+// fused (3,3) pass pairs: for lengths with a factor 9; in f64 only from 1024 points on (below, the 18 extra VGPRs and
+// the idle threads cost more than the saved LDS round trip: 729 f64 53 % without, 42 % with; 2187 30 % / 33 %)
+template <typename T> constexpr bool mix_pairs(uint32_t n) { return n % 9 == 0 && (sizeof(T) == 4 || n >= 1024); }
+// transforms per workgroup: about 1024 points (16 KiB of LDS in f32).  More points per workgroup fill the 256
+// threads better but lose more in resident workgroups than they gain (N=243 f32: 49 % at 1152 points, 40 % at
+// 2304, 27 % at 4608; r01 session 13)
+template <typename T> constexpr uint32_t mix_group(uint32_t n) { return 1024 / n ? 1024 / n : 1; }
 constexpr uint32_t mix_next_radix(uint32_t cur, bool first) {  // autosort/mod.rs:104-116
   return (first && cur % 4 == 0) ? 4u : (cur % 8 == 0 ? 8u : (cur % 4 == 0 ? 4u : (cur % 3 == 0 ? 3u : 2u)));
 }
@@ -1438,6 +1445,52 @@ template <typename T, uint32_t N, uint32_t SIZE, uint32_t STRIDE, uint32_t TWOFF
                                                      cpx<T> w3, cpx<T> w8) {
     constexpr uint32_t R = mix_next_radix(SIZE, FIRST_PASS), M = SIZE / R, NBF = N / R;
     const cpx<T>* __restrict__ t = tw + TWOFF;
+    if constexpr (R == 3 && SIZE >= 9 && (SIZE / 3) % 3 == 0 && mix_pairs<T>(N)) {
+      // two consecutive radix-3 passes on one LDS round trip: the three butterflies (i + M2*k2, j), k2 < 3, of this
+      // pass write exactly the inputs of the three butterflies (i, j + STRIDE*k), k < 3, of the next one, so a thread
+      // that loads those nine points keeps them in registers in between -- same operations in the same order as
+      // two single passes (mod.rs:203-284 twice), half the LDS traffic, barriers and index arithmetic
+      constexpr uint32_t SIZE2 = SIZE / 3, M2 = SIZE2 / 3, NBF2 = N / 9;
+      const cpx<T>* __restrict__ t2 = tw + TWOFF + SIZE;
+      for (uint32_t q = threadIdx.x; q < nb * NBF2; q += 256) {
+        const uint32_t g = q / NBF2, e = q % NBF2, i = e / STRIDE, j = e % STRIDE;  // i < M2
+        const cpx<T>* in = src + g * N + j + STRIDE * i;
+        cpx<T> x[3][3];
+#pragma unroll
+        for (uint32_t k2 = 0; k2 < 3; ++k2)
+#pragma unroll
+          for (uint32_t k1 = 0; k1 < 3; ++k1) x[k2][k1] = in[STRIDE * (M2 * k2 + M * k1)];
+#pragma unroll
+        for (uint32_t k2 = 0; k2 < 3; ++k2) {
+          ref_bf3(x[k2], w3);
+#pragma unroll
+          for (uint32_t k = 1; k < 3; ++k) {
+            cpx<T> w = t[(i + M2 * k2) * 3 + k];
+            if (!fwd) w.im = -w.im;
+            x[k2][k] = ref_mul(x[k2][k], w);
+          }
+        }
+        cpx<T>* out = dst + g * N + j + 9 * STRIDE * i;
+#pragma unroll
+        for (uint32_t k = 0; k < 3; ++k) {
+          cpx<T> y[3] = {x[0][k], x[1][k], x[2][k]};
+          ref_bf3(y, w3);
+          if constexpr (SIZE2 != 3) {
+#pragma unroll
+            for (uint32_t k2 = 1; k2 < 3; ++k2) {
+              cpx<T> w = t2[i * 3 + k2];
+              if (!fwd) w.im = -w.im;
+              y[k2] = ref_mul(y[k2], w);
+            }
+          }
+#pragma unroll
+          for (uint32_t k2 = 0; k2 < 3; ++k2) out[STRIDE * (k + 3 * k2)] = y[k2];
+        }
+      }
+      __syncthreads();
+      if constexpr (SIZE2 == 3) return dst;
+      else return MixPassesCT<T, N, SIZE2 / 3, STRIDE * 9, TWOFF + SIZE + SIZE2, false>::run(dst, const_cast<cpx<T>*>(src), tw, nb, fwd, w3, w8);
+    } else {
     for (uint32_t q = threadIdx.x; q < nb * NBF; q += 256) {
       const uint32_t g = q / NBF, e = q % NBF, i = e / STRIDE, j = e % STRIDE;  // constants: multiply-shift
       const cpx<T>* in = src + g * N + j + STRIDE * i;
@@ -1460,12 +1513,13 @@ template <typename T, uint32_t N, uint32_t SIZE, uint32_t STRIDE, uint32_t TWOFF
     __syncthreads();
     if constexpr (SIZE == R) return dst;
     else return MixPassesCT<T, N, SIZE / R, STRIDE * R, TWOFF + SIZE, false>::run(dst, const_cast<cpx<T>*>(src), tw, nb, fwd, w3, w8);
+    }
   }
 };
 template <typename T, uint32_t N>
 __global__ void __launch_bounds__(256) mixed_radix_kernel_ct(MixArgs a) {
   FOURIER_DYN_SMEM(smem);
-  constexpr uint32_t GROUP = (1024 / N) ? (1024 / N) : 1;
+  constexpr uint32_t GROUP = mix_group<T>(N);
   cpx<T>* buf0 = (cpx<T>*)smem;
   cpx<T>* buf1 = buf0 + (size_t)GROUP * N;
   const uint64_t b0 = (uint64_t)blockIdx.x * GROUP;
