@@ -13,6 +13,9 @@ VARIANTS = {
     "base": [],
     "slp": ["-fslp-vectorize"],
     "waves1": ["-DFOURIER_MIN_WAVES(NT)=1"],
+    "small_mw4": ["-DFOURIER_MIN_WAVES(NT)=((NT)>=1024?4:((NT)>=256?(NT)/128:4))"],
+    "small_mw5": ["-DFOURIER_MIN_WAVES(NT)=((NT)>=1024?4:((NT)>=256?(NT)/128:5))"],
+    "mid_mw3": ["-DFOURIER_MIN_WAVES(NT)=((NT)>=1024?4:((NT)>=512?4:((NT)>=256?3:1)))"],
     "nt_first": ["-DFOURIER_NT_LOAD=1"],
     "nt_store_all": ["-DFOURIER_NT_STORE=2"],
     "nt_none": ["-DFOURIER_NT_LOAD=0", "-DFOURIER_NT_STORE=0"],
