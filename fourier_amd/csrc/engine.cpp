@@ -695,7 +695,9 @@ template <typename T> class Pow2Engine {
 template <typename T> class MixedEngine {
  public:
   // both LDS ping-pong buffers of one transform must fit a workgroup: 2 * N * sizeof(complex) <= 144 KiB
-  static constexpr size_t MAX_N = (144 * 1024) / (2 * sizeof(cpx<T>));  // 9216 (f32), 4608 (f64)
+  // one LDS buffer of one transform must fit a workgroup (the per-length kernels run their passes in place):
+  // N * sizeof(complex) <= 144 KiB
+  static constexpr size_t MAX_N = (144 * 1024) / sizeof(cpx<T>);  // 18432 (f32), 9216 (f64)
   // autosort/mod.rs:104-116: one radix-4 first when divisible, then greedily 8, 4, 3, 2
   static bool factor(size_t size, uint32_t counts[5]) {
     static const size_t radices[5] = {4, 8, 4, 3, 2};
@@ -709,7 +711,8 @@ template <typename T> class MixedEngine {
   }
   static bool handles(size_t n) {
     uint32_t c[5];
-    return n <= MAX_N && !is_pow2(n) && factor(n, c);
+    const char* cap = getenv("FOURIER_MIX_MAX_N");  // development switch: A/B against the Bluestein / odd-pass routes
+    return n <= (cap ? std::min<size_t>(MAX_N, (size_t)atoll(cap)) : MAX_N) && !is_pow2(n) && factor(n, c);
   }
   // twiddle.rs:7-19 verbatim: theta = (index*2) as f64 * PI / size as f64; (cos, -sin) cast to T.
   // cos and sin stay two separate libm calls, as in Rust (a merged sincos() differs in the last bit).
@@ -743,9 +746,9 @@ template <typename T> class MixedEngine {
     if (!getenv("FOURIER_MIX_GENERIC")) {  // lengths with a compile-time specialisation (same arithmetic, constant index math)
 #define FOURIER_MIX_CT(NN)                                                      \
   case NN:                                                                      \
-    if constexpr ((size_t)NN <= MAX_N) { fn_ = &mixed_radix_kernel_ct<T, NN>; group_ = mix_group<T>(NN); } \
+    if constexpr ((size_t)NN <= MAX_N) { fn_ = &mixed_radix_kernel_ct<T, NN>; group_ = mix_group<T>(NN); nbuf_ = mix_inplace<T>(NN) ? 1 : 2; } \
     break;
-      switch (n) {  // every 2^a * 3^b (b >= 1) the engine runs in LDS: 3 ... 9216 (f32) / 4608 (f64)
+      switch (n) {  // every 2^a * 3^b (b >= 1) the engine runs in LDS: 3 ... 18432 (f32) / 9216 (f64)
         FOURIER_MIX_CT(3) FOURIER_MIX_CT(6) FOURIER_MIX_CT(9) FOURIER_MIX_CT(12) FOURIER_MIX_CT(18) FOURIER_MIX_CT(24)
         FOURIER_MIX_CT(27) FOURIER_MIX_CT(36) FOURIER_MIX_CT(48) FOURIER_MIX_CT(54) FOURIER_MIX_CT(72) FOURIER_MIX_CT(81)
         FOURIER_MIX_CT(96) FOURIER_MIX_CT(108) FOURIER_MIX_CT(144) FOURIER_MIX_CT(162) FOURIER_MIX_CT(192) FOURIER_MIX_CT(216)
@@ -754,12 +757,15 @@ template <typename T> class MixedEngine {
         FOURIER_MIX_CT(1152) FOURIER_MIX_CT(1296) FOURIER_MIX_CT(1458) FOURIER_MIX_CT(1536) FOURIER_MIX_CT(1728) FOURIER_MIX_CT(1944)
         FOURIER_MIX_CT(2187) FOURIER_MIX_CT(2304) FOURIER_MIX_CT(2592) FOURIER_MIX_CT(2916) FOURIER_MIX_CT(3072) FOURIER_MIX_CT(3456)
         FOURIER_MIX_CT(3888) FOURIER_MIX_CT(4374) FOURIER_MIX_CT(4608) FOURIER_MIX_CT(5184) FOURIER_MIX_CT(5832) FOURIER_MIX_CT(6144)
-        FOURIER_MIX_CT(6561) FOURIER_MIX_CT(6912) FOURIER_MIX_CT(7776) FOURIER_MIX_CT(8748) FOURIER_MIX_CT(9216)
+        FOURIER_MIX_CT(6561) FOURIER_MIX_CT(6912) FOURIER_MIX_CT(7776) FOURIER_MIX_CT(8748) FOURIER_MIX_CT(9216) FOURIER_MIX_CT(10368)
+        FOURIER_MIX_CT(11664) FOURIER_MIX_CT(12288) FOURIER_MIX_CT(13122) FOURIER_MIX_CT(13824) FOURIER_MIX_CT(15552) FOURIER_MIX_CT(17496)
+        FOURIER_MIX_CT(18432)
         default: break;
       }
 #undef FOURIER_MIX_CT
     }
-    smem_ = 2 * (size_t)group_ * n * sizeof(cpx<T>);
+    smem_ = nbuf_ * (size_t)group_ * n * sizeof(cpx<T>);
+    if (smem_ > 144 * 1024) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "mixed-radix length needs the per-length kernel");
 #ifndef FOURIER_EMU
     if (smem_ > 48 * 1024)
       HIP_CHECK(hipFuncSetAttribute((const void*)fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_));
@@ -793,6 +799,7 @@ template <typename T> class MixedEngine {
   size_t n_;
   uint32_t counts_[5];
   void (*fn_)(MixArgs) = nullptr;
+  size_t nbuf_ = 2;  // LDS buffers of `group_` transforms: 2 = ping-pong, 1 = in-place passes
   uint32_t group_ = 1;
   size_t smem_ = 0;
   DevBuf tw_;
@@ -840,12 +847,14 @@ template <typename T> class Plan {
     if (is_pow2(n)) {
       eng_.reset(new Pow2Engine<T>(n));
       desc_ = "stockham " + eng_->describe();
+    } else if (Pow2Engine<T>::handles_mixed(n)) {
+      // big-radix passes over the 2^a part (a >= 12), then a radix-3^b pass: three HBM round trips at full tile
+      // efficiency beat the one-workgroup-per-CU LDS kernel where both apply (3*2^12 f32: 23 % vs 14 %)
+      eng_.reset(new Pow2Engine<T>(n));
+      desc_ = "stockham " + eng_->describe();
     } else if (MixedEngine<T>::handles(n)) {
       mix_.reset(new MixedEngine<T>(n));
       desc_ = "stockham mixed-radix " + mix_->describe();
-    } else if (Pow2Engine<T>::handles_mixed(n)) {
-      eng_.reset(new Pow2Engine<T>(n));  // big-radix passes over the 2^a part, then a radix-3^b pass
-      desc_ = "stockham " + eng_->describe();
     } else {
       init_bluestein();
       desc_ = "bluestein M=" + std::to_string(m_) + " inner " + eng_->describe() + (small_fused_ ? " fused" : "");

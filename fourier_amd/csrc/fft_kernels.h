@@ -1440,79 +1440,121 @@ template <typename T> constexpr uint32_t mix_group(uint32_t n) { return 1024 / n
 constexpr uint32_t mix_next_radix(uint32_t cur, bool first) {  // autosort/mod.rs:104-116
   return (first && cur % 4 == 0) ? 4u : (cur % 8 == 0 ? 8u : (cur % 4 == 0 ? 4u : (cur % 3 == 0 ? 3u : 2u)));
 }
+// Every pass runs IN PLACE on one LDS buffer: a thread keeps the outputs of all its butterflies of a pass in
+// registers across a barrier, then writes them back to the buffer it read from.  Same arithmetic as the ping-pong
+// form; half the LDS, so twice the resident workgroups where LDS was the limit (N=6561 f32 16 -> 32 % of the HBM
+// peak, 2304 37 -> 51 %, f64 1152 46 -> 61 %) and no loss elsewhere (A/B over the threshold,
+// profiles/r01_s15_mixed_inplace_ab.txt).  FOURIER_MIX_INPLACE_BYTES > 0 restores ping-pong below that footprint.
+#ifndef FOURIER_MIX_INPLACE_BYTES
+#define FOURIER_MIX_INPLACE_BYTES 0u
+#endif
+template <typename T> constexpr bool mix_inplace(uint32_t n) {
+  return FOURIER_MIX_INPLACE_BYTES == 0u || 2u * mix_group<T>(n) * n * 2u * sizeof(T) > FOURIER_MIX_INPLACE_BYTES;
+}
+
 template <typename T, uint32_t N, uint32_t SIZE, uint32_t STRIDE, uint32_t TWOFF, bool FIRST_PASS> struct MixPassesCT {
-  static __device__ __forceinline__ const cpx<T>* run(const cpx<T>* src, cpx<T>* dst, const cpx<T>* tw, uint32_t nb, bool fwd,
-                                                     cpx<T> w3, cpx<T> w8) {
-    constexpr uint32_t R = mix_next_radix(SIZE, FIRST_PASS), M = SIZE / R, NBF = N / R;
+  static constexpr uint32_t R = mix_next_radix(SIZE, FIRST_PASS), M = SIZE / R;
+  static constexpr bool PAIR = (R == 3 && SIZE >= 9 && (SIZE / 3) % 3 == 0 && mix_pairs<T>(N));
+  // two consecutive radix-3 passes on one LDS round trip: the three butterflies (i + M2*k2, j), k2 < 3, of this pass
+  // write exactly the inputs of the three butterflies (i, j + STRIDE*k), k < 3, of the next one, so a thread that
+  // loads those nine points keeps them in registers in between -- same operations in the same order as two single
+  // passes (mod.rs:203-284 twice), half the LDS traffic, barriers and index arithmetic
+  static constexpr uint32_t SIZE2 = SIZE / 3, M2 = SIZE2 / 3;
+  static constexpr uint32_t PTS = PAIR ? 9 : R;          // points one work item reads and writes
+  static constexpr uint32_t NBF = N / PTS;               // work items per transform
+  static constexpr uint32_t OUT_SIZE = PAIR ? SIZE2 / 3 : SIZE / R, OUT_STRIDE = STRIDE * PTS;
+  static constexpr uint32_t OUT_TWOFF = PAIR ? TWOFF + SIZE + SIZE2 : TWOFF + SIZE;
+  static constexpr bool LAST = (OUT_SIZE == 1);
+
+  // work item q: load, butterfly (+ twiddle), results in y[PTS] in the order of the output slots
+  static __device__ __forceinline__ void compute(const cpx<T>* src, const cpx<T>* tw, uint32_t q, bool fwd, cpx<T> w3, cpx<T> w8,
+                                                 cpx<T> (&y)[PTS], uint32_t& out_off) {
+    const uint32_t g = q / NBF, e = q % NBF, i = e / STRIDE, j = e % STRIDE;  // constants: multiply-shift
+    const cpx<T>* in = src + g * N + j + STRIDE * i;
     const cpx<T>* __restrict__ t = tw + TWOFF;
-    if constexpr (R == 3 && SIZE >= 9 && (SIZE / 3) % 3 == 0 && mix_pairs<T>(N)) {
-      // two consecutive radix-3 passes on one LDS round trip: the three butterflies (i + M2*k2, j), k2 < 3, of this
-      // pass write exactly the inputs of the three butterflies (i, j + STRIDE*k), k < 3, of the next one, so a thread
-      // that loads those nine points keeps them in registers in between -- same operations in the same order as
-      // two single passes (mod.rs:203-284 twice), half the LDS traffic, barriers and index arithmetic
-      constexpr uint32_t SIZE2 = SIZE / 3, M2 = SIZE2 / 3, NBF2 = N / 9;
+    out_off = g * N + j + PTS * STRIDE * i;
+    if constexpr (PAIR) {
       const cpx<T>* __restrict__ t2 = tw + TWOFF + SIZE;
-      for (uint32_t q = threadIdx.x; q < nb * NBF2; q += 256) {
-        const uint32_t g = q / NBF2, e = q % NBF2, i = e / STRIDE, j = e % STRIDE;  // i < M2
-        const cpx<T>* in = src + g * N + j + STRIDE * i;
-        cpx<T> x[3][3];
+      cpx<T> x[3][3];
 #pragma unroll
-        for (uint32_t k2 = 0; k2 < 3; ++k2)
+      for (uint32_t k2 = 0; k2 < 3; ++k2)
 #pragma unroll
-          for (uint32_t k1 = 0; k1 < 3; ++k1) x[k2][k1] = in[STRIDE * (M2 * k2 + M * k1)];
+        for (uint32_t k1 = 0; k1 < 3; ++k1) x[k2][k1] = in[STRIDE * (M2 * k2 + M * k1)];
 #pragma unroll
-        for (uint32_t k2 = 0; k2 < 3; ++k2) {
-          ref_bf3(x[k2], w3);
+      for (uint32_t k2 = 0; k2 < 3; ++k2) {
+        ref_bf3(x[k2], w3);
 #pragma unroll
-          for (uint32_t k = 1; k < 3; ++k) {
-            cpx<T> w = t[(i + M2 * k2) * 3 + k];
-            if (!fwd) w.im = -w.im;
-            x[k2][k] = ref_mul(x[k2][k], w);
-          }
-        }
-        cpx<T>* out = dst + g * N + j + 9 * STRIDE * i;
-#pragma unroll
-        for (uint32_t k = 0; k < 3; ++k) {
-          cpx<T> y[3] = {x[0][k], x[1][k], x[2][k]};
-          ref_bf3(y, w3);
-          if constexpr (SIZE2 != 3) {
-#pragma unroll
-            for (uint32_t k2 = 1; k2 < 3; ++k2) {
-              cpx<T> w = t2[i * 3 + k2];
-              if (!fwd) w.im = -w.im;
-              y[k2] = ref_mul(y[k2], w);
-            }
-          }
-#pragma unroll
-          for (uint32_t k2 = 0; k2 < 3; ++k2) out[STRIDE * (k + 3 * k2)] = y[k2];
+        for (uint32_t k = 1; k < 3; ++k) {
+          cpx<T> w = t[(i + M2 * k2) * 3 + k];
+          if (!fwd) w.im = -w.im;
+          x[k2][k] = ref_mul(x[k2][k], w);
         }
       }
-      __syncthreads();
-      if constexpr (SIZE2 == 3) return dst;
-      else return MixPassesCT<T, N, SIZE2 / 3, STRIDE * 9, TWOFF + SIZE + SIZE2, false>::run(dst, const_cast<cpx<T>*>(src), tw, nb, fwd, w3, w8);
-    } else {
-    for (uint32_t q = threadIdx.x; q < nb * NBF; q += 256) {
-      const uint32_t g = q / NBF, e = q % NBF, i = e / STRIDE, j = e % STRIDE;  // constants: multiply-shift
-      const cpx<T>* in = src + g * N + j + STRIDE * i;
-      cpx<T> x[R];
 #pragma unroll
-      for (uint32_t k = 0; k < R; ++k) x[k] = in[STRIDE * M * k];
-      ref_butterfly<T, (int)R>(x, fwd, w3, w8);
+      for (uint32_t k = 0; k < 3; ++k) {
+        cpx<T> z[3] = {x[0][k], x[1][k], x[2][k]};
+        ref_bf3(z, w3);
+        if constexpr (SIZE2 != 3) {
+#pragma unroll
+          for (uint32_t k2 = 1; k2 < 3; ++k2) {
+            cpx<T> w = t2[i * 3 + k2];
+            if (!fwd) w.im = -w.im;
+            z[k2] = ref_mul(z[k2], w);
+          }
+        }
+#pragma unroll
+        for (uint32_t k2 = 0; k2 < 3; ++k2) y[k + 3 * k2] = z[k2];  // output slot STRIDE * (k + 3*k2)
+      }
+    } else {
+#pragma unroll
+      for (uint32_t k = 0; k < R; ++k) y[k] = in[STRIDE * M * k];
+      ref_butterfly<T, (int)R>(y, fwd, w3, w8);
       if constexpr (SIZE != R) {  // mod.rs:238,272
 #pragma unroll
         for (uint32_t k = 1; k < R; ++k) {
           cpx<T> w = t[i * R + k];
           if (!fwd) w.im = -w.im;
-          x[k] = ref_mul(x[k], w);
+          y[k] = ref_mul(y[k], w);
         }
       }
-      cpx<T>* out = dst + g * N + j + R * STRIDE * i;
-#pragma unroll
-      for (uint32_t k = 0; k < R; ++k) out[STRIDE * k] = x[k];
     }
-    __syncthreads();
-    if constexpr (SIZE == R) return dst;
-    else return MixPassesCT<T, N, SIZE / R, STRIDE * R, TWOFF + SIZE, false>::run(dst, const_cast<cpx<T>*>(src), tw, nb, fwd, w3, w8);
+  }
+
+  static __device__ __forceinline__ const cpx<T>* run(const cpx<T>* src, cpx<T>* dst, const cpx<T>* tw, uint32_t nb, bool fwd,
+                                                     cpx<T> w3, cpx<T> w8) {
+    if constexpr (mix_inplace<T>(N)) {
+      constexpr uint32_t ROUNDS = (mix_group<T>(N) * NBF + 255) / 256;
+      cpx<T> y[ROUNDS][PTS];
+      uint32_t off[ROUNDS];
+#pragma unroll
+      for (uint32_t rd = 0; rd < ROUNDS; ++rd) {
+        const uint32_t q = threadIdx.x + 256 * rd;
+        if (q < nb * NBF) compute(src, tw, q, fwd, w3, w8, y[rd], off[rd]);
+      }
+      __syncthreads();  // every input of the pass has been read
+      cpx<T>* buf = const_cast<cpx<T>*>(src);
+#pragma unroll
+      for (uint32_t rd = 0; rd < ROUNDS; ++rd) {
+        const uint32_t q = threadIdx.x + 256 * rd;
+        if (q < nb * NBF) {
+#pragma unroll
+          for (uint32_t k = 0; k < PTS; ++k) buf[off[rd] + STRIDE * k] = y[rd][k];
+        }
+      }
+      __syncthreads();
+      if constexpr (LAST) return src;
+      else return MixPassesCT<T, N, OUT_SIZE, OUT_STRIDE, OUT_TWOFF, false>::run(src, dst, tw, nb, fwd, w3, w8);
+    } else {
+      for (uint32_t q = threadIdx.x; q < nb * NBF; q += 256) {
+        cpx<T> y[PTS];
+        uint32_t off;
+        compute(src, tw, q, fwd, w3, w8, y, off);
+#pragma unroll
+        for (uint32_t k = 0; k < PTS; ++k) dst[off + STRIDE * k] = y[k];
+      }
+      __syncthreads();
+      if constexpr (LAST) return dst;
+      else return MixPassesCT<T, N, OUT_SIZE, OUT_STRIDE, OUT_TWOFF, false>::run(dst, const_cast<cpx<T>*>(src), tw, nb, fwd, w3, w8);
     }
   }
 };

@@ -127,7 +127,7 @@ MIXED_SIZES = sorted({(2 ** a) * (3 ** b) for a in range(13) for b in range(1, 8
 
 
 def test_mixed_radix_sizes_are_bit_identical_to_the_oracle(fa, oracle):
-    """N = 2^a*3^b <= 4096 runs the reference's own radix schedule [4,8,4,3,2], tables and operation order
+    """N = 2^a*3^b <= 18432 (f64: 9216) runs the reference's own radix schedule [4,8,4,3,2], tables and operation order
     (autosort/mod.rs:20-46,203-284, butterfly.rs:3-65) natively: every transform code, both precisions,
     in and out of place must equal the CPU restatement bit for bit."""
     for n in MIXED_SIZES[::3] + [3, 243, 3072, 3888]:
@@ -139,9 +139,12 @@ def test_mixed_radix_sizes_are_bit_identical_to_the_oracle(fa, oracle):
                 ref = oracle.transform_batch(x.astype(dtype), code)
                 assert np.array_equal(run_batch(plan, x.astype(dtype), code), ref), (n, dtype, code)
                 assert np.array_equal(run_batch(plan, x.astype(dtype), code, inplace=True), ref), (n, dtype, code)
-    assert "mixed-radix" in make(fa, 6144, np.complex64).describe()  # 2 x 48 KiB of LDS
-    assert "bluestein" in make(fa, 6144, np.complex128).describe()   # f64: above the LDS-resident limit (4608)
-    for n, dtype in ((6144, np.complex64), (9216, np.complex64), (4608, np.complex128)):
+    assert "mixed-radix" in make(fa, 18432, np.complex64).describe()  # one in-place LDS buffer of 144 KiB
+    assert "mixed-radix" in make(fa, 9216, np.complex128).describe()
+    assert "bluestein" in make(fa, 10368, np.complex128).describe()   # f64: above the LDS-resident limit (9216)
+    assert "x3" in make(fa, 12288, np.complex64).describe()           # 3*2^12: tiled passes + odd pass, not the LDS kernel
+    for n, dtype in ((6144, np.complex64), (9216, np.complex64), (18432, np.complex64), (13122, np.complex64),
+                     (4608, np.complex128), (9216, np.complex128), (6561, np.complex128)):
         xb = np.stack([hash_normal(21 + b, n) for b in range(2)]).astype(dtype)
         assert np.array_equal(run_batch(make(fa, n, dtype), xb, 0), oracle.transform_batch(xb, 0)), n
 
@@ -172,7 +175,8 @@ def test_large_mixed_radix_sizes_run_natively(fa, oracle):
                 assert rel_l2(run_batch(plan, x.astype(dtype), code), ref) <= tl2, (n, code)
                 assert rel_l2(run_batch(plan, x.astype(dtype), code, inplace=True), ref) <= tl2, (n, code)
     assert "bluestein" in make(fa, 81 * 4096, np.complex64).describe()  # 3^4: beyond the odd pass's radices
-    assert "bluestein" in make(fa, 3 * 2048, np.complex128).describe()  # too little 2^a for two tiled passes
+    assert "mixed-radix" in make(fa, 3 * 2048, np.complex128).describe()  # too little 2^a for two tiled passes: LDS kernel
+    assert "bluestein" in make(fa, 9 * 2048, np.complex128).describe()   # f64 18432: beyond both native routes
 
 
 def test_bluestein_fusion_matches_unfused(fa):

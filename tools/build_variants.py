@@ -25,6 +25,7 @@ VARIANTS = {
     "nt_both": ["-DFOURIER_NT_LOAD=1", "-DFOURIER_NT_STORE=1"],
     "cg4": ["-DFOURIER_CG_1024=4"],
     "cg2048_4": ["-DFOURIER_CG_2048=4"],
+    "mix_pingpong_40k": ["-DFOURIER_MIX_INPLACE_BYTES=(40u*1024u)"],
     "cg16": ["-DFOURIER_CG_1024=16"],
     "split16k": ["-DFOURIER_SPLIT_THRESHOLD=(16*1024)"],
     "split32k": ["-DFOURIER_SPLIT_THRESHOLD=(32*1024)"],
