@@ -1569,17 +1569,42 @@ __global__ void __launch_bounds__(256) mixed_radix_kernel_ct(MixArgs a) {
   const uint32_t total = nb * N;
   const cpx<T>* in = (const cpx<T>*)a.in + b0 * N;
   cpx<T>* out = (cpx<T>*)a.out + b0 * N;
-  for (uint32_t idx = threadIdx.x; idx < total; idx += 256) buf0[idx] = in[idx];
+  // global <-> LDS in 16-byte units (two f32 points / one f64 point per lane and instruction; the user rows of an
+  // odd-length f32 batch are only 8-byte aligned, which global_load/store_dwordx4 tolerate), one odd point by itself
+  constexpr uint32_t VEC = 16 / (2 * (uint32_t)sizeof(T));
+  const uint32_t units = total / VEC;
+  if constexpr (VEC == 1) {
+    for (uint32_t idx = threadIdx.x; idx < total; idx += 256) buf0[idx] = in[idx];
+  } else {
+    for (uint32_t u = threadIdx.x; u < units; u += 256) *(Unit16<T>*)(buf0 + u * VEC) = load_unit_a8<T>(in + u * VEC);
+    if ((total % VEC) && threadIdx.x == 0) buf0[total - 1] = in[total - 1];
+  }
   __syncthreads();
   const bool fwd = a.forward != 0;
   cpx<T> w3{(T)a.w3re, (T)a.w3im}, w8{(T)a.w8re, (T)a.w8im};
   if (!fwd) { w3.im = -w3.im; w8.im = -w8.im; }
   const cpx<T>* res = MixPassesCT<T, N, N, 1, 0, true>::run(buf0, buf1, (const cpx<T>*)a.tw, nb, fwd, w3, w8);
-  const T scale = (T)a.scale;
-  for (uint32_t idx = threadIdx.x; idx < total; idx += 256) {
-    cpx<T> y = res[idx];
-    if (a.scaled) y = {y.re * scale, y.im * scale};  // mod.rs:387-393
-    out[idx] = y;
+  const T scale = a.scaled ? (T)a.scale : (T)1;  // mod.rs:387-393 (the unscaled codes skip the multiply: x * 1 is exact)
+  if constexpr (VEC == 1) {
+    for (uint32_t idx = threadIdx.x; idx < total; idx += 256) {
+      cpx<T> y = res[idx];
+      if (a.scaled) y = {y.re * scale, y.im * scale};
+      out[idx] = y;
+    }
+  } else {
+    for (uint32_t u = threadIdx.x; u < units; u += 256) {
+      Unit16<T> v = *(const Unit16<T>*)(res + u * VEC);
+      if (a.scaled) {
+#pragma unroll
+        for (uint32_t c = 0; c < 2 * VEC; ++c) v.a[c] = v.a[c] * scale;
+      }
+      store_unit_a8<T>(out + u * VEC, v);
+    }
+    if ((total % VEC) && threadIdx.x == 0) {
+      cpx<T> y = res[total - 1];
+      if (a.scaled) y = {y.re * scale, y.im * scale};
+      out[total - 1] = y;
+    }
   }
 }
 
