@@ -16,6 +16,17 @@
 //
 // Inverse transforms use IDFT(x) = swap(DFT(swap(x))) with swap = exchange re<->im, applied at the
 // first load / last store, so all twiddle tables are forward-only.
+//
+// Kernel families in this file (DESIGN.md section 2 says which sizes take which):
+//   fft_pass_kernel<T, L, CG, MODE, IO>   one big-radix pass over column tiles (FIRST / MID / LAST) or whole rows (ROWS)
+//   fft_conv_kernel<T, L, CG>             Bluestein middle: last forward pass, (.) w, first inverse pass in one launch
+//   fft_twolevel_kernel<T, L1, L2>        2^11..2^15: both passes inside one workgroup
+//   bluestein_small_kernel / bluestein_rows_kernel   whole chirp-z in one launch for M <= 2^15
+//   tiny_shfl_kernel<T, N>                N <= 16 (f32: 32): one lane per transform, wave-shuffle unit transpose
+//   mixed_radix_kernel_ct<T, N>           2^a*3^b in LDS with the reference's schedule, one instantiation per length
+//   mixed_radix_kernel<T>                 the same, runtime-parameterised (A/B reference)
+//   odd_last_kernel<T, R>                 final radix-3/9/27 pass of the large 2^a*3^b sizes
+//   blu_pre_kernel / blu_post_kernel      unfused chirp sweeps (option bluestein_fusion = 0)
 #pragma once
 #include <stdint.h>
 
