@@ -1443,7 +1443,10 @@ template <typename T, int R> __device__ __forceinline__ void ref_butterfly(cpx<T
 // the same order: still bit-identical to the CPU restatement.
 // fused (3,3) pass pairs: for lengths with a factor 9; in f64 only from 1024 points on (below, the 18 extra VGPRs and
 // the idle threads cost more than the saved LDS round trip: 729 f64 53 % without, 42 % with; 2187 30 % / 33 %)
-template <typename T> constexpr bool mix_pairs(uint32_t n) { return n % 9 == 0 && (sizeof(T) == 4 || n >= 1024); }
+#ifndef FOURIER_MIX_PAIR_MIN_N_F64
+#define FOURIER_MIX_PAIR_MIN_N_F64 1024u
+#endif
+template <typename T> constexpr bool mix_pairs(uint32_t n) { return n % 9 == 0 && (sizeof(T) == 4 || n >= FOURIER_MIX_PAIR_MIN_N_F64); }
 // transforms per workgroup: about 1024 points (16 KiB of LDS in f32).  More points per workgroup fill the 256
 // threads better but lose more in resident workgroups than they gain (N=243 f32: 49 % at 1152 points, 40 % at
 // 2304, 27 % at 4608; r01 session 13)

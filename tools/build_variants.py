@@ -26,6 +26,8 @@ VARIANTS = {
     "cg4": ["-DFOURIER_CG_1024=4"],
     "cg2048_4": ["-DFOURIER_CG_2048=4"],
     "mix_pingpong_40k": ["-DFOURIER_MIX_INPLACE_BYTES=(40u*1024u)"],
+    "mix64_pairs_all": ["-DFOURIER_MIX_PAIR_MIN_N_F64=0u"],
+    "mix64_pairs_none": ["-DFOURIER_MIX_PAIR_MIN_N_F64=100000u"],
     "cg16": ["-DFOURIER_CG_1024=16"],
     "split16k": ["-DFOURIER_SPLIT_THRESHOLD=(16*1024)"],
     "split32k": ["-DFOURIER_SPLIT_THRESHOLD=(32*1024)"],

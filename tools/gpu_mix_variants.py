@@ -8,8 +8,8 @@ from fourier_amd import fft as F, _lib
 from gpu_sweep import time_plan
 libs = [("product", None)] + [(os.path.basename(p)[len("libfourier_"):-3], p) for p in sorted(glob.glob(os.path.join(ROOT, "fourier_amd", "lib", "variants", "libfourier_*.so")))]
 base = _lib.lib()
-for real, esz, cdt in (("f32", 8, torch.complex64), ("f64", 16, torch.complex128)):
-    for n in (96, 243, 384, 729, 768, 1152, 1536, 2187, 2304, 3072):
+for real, esz, cdt in (("f64", 16, torch.complex128),):
+    for n in (27, 81, 243, 729, 1152, 2187, 2304, 4374, 6561, 144, 576, 9216):
         bb = (1 << 30) // (n * esz)
         xs = torch.empty((bb, n), dtype=cdt, device="cuda"); torch.view_as_real(xs).uniform_(0, 1); ys = torch.empty_like(xs)
         row = {}
