@@ -937,9 +937,23 @@ template <typename T> class Plan {
     // keep every launch's grid below 2^31 blocks
     while (chunk > 1 && (double)chunk * (double)(blu_ ? m_ : n_) / 16.0 > 2.0e9) chunk = (chunk + 1) / 2;
 
+    // The plan's scratch (and the Bluestein work array) hold one chunk.  If the device cannot give that much -- an
+    // in-place call on a batch that fills most of the HBM -- fall back to smaller chunks instead of failing: chunks
+    // run back to back on the stream and the results are the same.
+    auto reserve = [&](auto&& alloc) {
+      for (;;) {
+        try { alloc(chunk); return; }
+        catch (const EngineError& e) {
+          if (e.status != ::fourier::c::FOURIER_HIP_OUT_OF_MEMORY || chunk <= 1) throw;
+          (void)hipGetLastError();  // the allocation failure is handled here
+          chunk = (chunk + 1) / 2;
+        }
+      }
+    };
+
     if (!blu_) {
       const bool need = eng_->needs_scratch(in_place) || (force_scratch_ && eng_->num_passes() >= 2);
-      if (need) scratch_.ensure(chunk * n_ * ELEM);
+      if (need) reserve([&](size_t c) { scratch_.ensure(c * n_ * ELEM); });
       for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const size_t nb = std::min(chunk, batch - b0);
         eng_->run(in + b0 * n_, out + b0 * n_, (cpx<T>*)scratch_.p, nb, inverse, scale, nullptr, force_scratch_, stream, prof, 0, nxcd_);
@@ -951,8 +965,10 @@ template <typename T> class Plan {
       eng_->run_bluestein_small(in, out, batch, xtab_.p, wtab_.p, n_, inverse, scale, stream, prof, nxcd_);
       return;
     }
-    work_.ensure(chunk * m_ * ELEM);
-    if (eng_->needs_scratch(true) || fused_) scratch_.ensure(chunk * m_ * ELEM);
+    reserve([&](size_t c) {
+      work_.ensure(c * m_ * ELEM);
+      if (eng_->needs_scratch(true) || fused_) scratch_.ensure(c * m_ * ELEM);
+    });
     cpx<T>* work = (cpx<T>*)work_.p;
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
       const size_t nb = std::min(chunk, batch - b0);

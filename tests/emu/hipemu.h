@@ -234,7 +234,12 @@ inline int __shfl_xor(int v, int lane_mask) {
 }
 
 // ---- host API subset ----
-inline hipError_t hipMalloc(void** p, size_t n) { *p = n ? malloc(n) : nullptr; return (*p || !n) ? hipSuccess : hipErrorOutOfMemory; }
+inline hipError_t hipMalloc(void** p, size_t n) {
+  if (const char* cap = getenv("HIPEMU_MAX_ALLOC"))  // tests: pretend the device is out of memory above this size
+    if (n > (size_t)atoll(cap)) { *p = nullptr; return hipErrorOutOfMemory; }
+  *p = n ? malloc(n) : nullptr;
+  return (*p || !n) ? hipSuccess : hipErrorOutOfMemory;
+}
 inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 enum { hipHostMallocMapped = 2 };
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }

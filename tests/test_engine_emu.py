@@ -324,6 +324,19 @@ def test_chunking_and_scratch_options_do_not_change_results(fa):
         make(fa, n, np.complex64).set_option("xcd_swizzle", 4)
 
 
+def test_out_of_memory_for_the_scratch_falls_back_to_smaller_chunks(fa, monkeypatch):
+    """An in-place call needs a scratch of one chunk (default: the whole batch).  When the device cannot give that
+    much the engine halves the chunk until the allocation fits instead of failing; same bits as the unchunked run."""
+    for n, batch in ((1 << 16, 6), (40000, 5)):  # two-pass in place; Bluestein work + scratch
+        x = np.stack([hash_normal(600 + b, n) for b in range(batch)]).astype(np.complex64)
+        ref = run_batch(make(fa, n, np.complex64), x, 0, inplace=True)
+        plan = make(fa, n, np.complex64)
+        monkeypatch.setenv("HIPEMU_MAX_ALLOC", str(2 * (1 << 17 if n == 40000 else n) * 8 + 4096))  # room for two transforms
+        got = run_batch(plan, x, 0, inplace=True)
+        monkeypatch.delenv("HIPEMU_MAX_ALLOC")
+        assert np.array_equal(got, ref), n
+
+
 def test_linearity_and_roundtrip_properties(fa):
     n = 1 << 14
     plan = make(fa, n, np.complex64)
