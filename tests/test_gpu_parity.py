@@ -376,6 +376,27 @@ def test_host_batched_entry_point(torch, fa, oracle, n, batch, dtype, tol):
     assert np.array_equal(z, y)
 
 
+def test_host_batched_entry_point_with_pinned_buffers(torch, fa):
+    """Page-locked user buffers (torch pinned tensors) behave like pageable ones: pinned input only, pinned output
+    only, both, in place.  (DMA straight from / to a large pinned user buffer was measured slower than staging
+    through the four reused 32 MiB buffers -- 28.8 vs 35-40 GB/s each way -- so every buffer takes the staged route.)"""
+    n, batch = 1 << 16, 300  # 150 MiB: five chunks, every slot reused
+    plan = make(fa, n, np.complex64)
+    rng = np.random.default_rng(5)
+    x = (rng.random((batch, n), dtype=np.float32) + 1j * rng.random((batch, n), dtype=np.float32)).astype(np.complex64)
+    ref = np.empty_like(x)
+    plan.transform_batch_host(x, ref, fa.Transform.Fft)
+    xp = torch.empty((batch, n), dtype=torch.complex64, pin_memory=True)
+    yp = torch.empty((batch, n), dtype=torch.complex64, pin_memory=True)
+    xp.copy_(torch.from_numpy(x))
+    for xin, yout in ((xp.numpy(), np.empty_like(x)), (x, yp.numpy()), (xp.numpy(), yp.numpy())):
+        yout[...] = 0
+        plan.transform_batch_host(xin, yout, fa.Transform.Fft)
+        assert np.array_equal(yout, ref)
+    plan.transform_batch_host(xp.numpy(), xp.numpy(), fa.Transform.Fft)  # in place on pinned memory
+    assert np.array_equal(xp.numpy(), ref)
+
+
 def test_linearity(torch, fa):
     n = 1 << 20
     plan = make(fa, n, np.complex64)
