@@ -29,6 +29,8 @@ VARIANTS = {
     "mix64_pairs_all": ["-DFOURIER_MIX_PAIR_MIN_N_F64=0u"],
     "mix64_pairs_none": ["-DFOURIER_MIX_PAIR_MIN_N_F64=100000u"],
     "cg16": ["-DFOURIER_CG_1024=16"],
+    "split8k": ["-DFOURIER_SPLIT_THRESHOLD=(8*1024)"],
+    "split4k": ["-DFOURIER_SPLIT_THRESHOLD=(4*1024)"],
     "split16k": ["-DFOURIER_SPLIT_THRESHOLD=(16*1024)"],
     "split32k": ["-DFOURIER_SPLIT_THRESHOLD=(32*1024)"],
     "split0": ["-DFOURIER_SPLIT_THRESHOLD=0"],
