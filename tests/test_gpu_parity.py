@@ -397,6 +397,40 @@ def test_host_batched_entry_point_with_pinned_buffers(torch, fa):
     assert np.array_equal(xp.numpy(), ref)
 
 
+def test_independent_plans_on_concurrent_host_threads(torch, fa, oracle):
+    """Handles are Send, not Sync (autosort/mod.rs:54): one thread at a time per handle, but distinct handles are fully
+    independent.  Four host threads, each with its own plan and its own stream, hammer the library concurrently
+    (ctypes drops the GIL around the calls); every result must match the single-threaded one."""
+    import threading
+
+    sizes = [1 << 16, 40000, 4096, 729]
+    xs = {n: np.stack([hash_uniform(300 + b, n) for b in range(4)]).astype(np.complex64) for n in sizes}
+    refs = {n: gpu_batch(torch, fa, make(fa, n, np.complex64), xs[n], 0) for n in sizes}
+    errors = []
+
+    def worker(n):
+        try:
+            plan = make(fa, n, np.complex64)
+            stream = torch.cuda.Stream()
+            d = torch.from_numpy(xs[n]).cuda()
+            o = torch.empty_like(d)
+            for _ in range(40):
+                with torch.cuda.stream(stream):
+                    plan.transform(d, o, fa.Transform.Fft)
+            stream.synchronize()
+            if not np.array_equal(o.cpu().numpy(), refs[n]):
+                errors.append(("mismatch", n))
+        except Exception as e:  # surfaced in the main thread below
+            errors.append((repr(e), n))
+
+    threads = [threading.Thread(target=worker, args=(n,)) for n in sizes]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_linearity(torch, fa):
     n = 1 << 20
     plan = make(fa, n, np.complex64)
