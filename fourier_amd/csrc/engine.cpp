@@ -468,6 +468,7 @@ template <typename T> class Pow2Engine {
   // one-launch two-level plan: it additionally needs the inter-pass table of the role-swapped L2 x L1 problem.
   bool enable_bluestein_small() {
     if (tiny_ || passes_.size() != 1) return false;
+    if (blu_small_.fn) return true;  // tables already uploaded (set_option may be called repeatedly)
     if (passes_[0]->mode == MODE_ROWS) {  // M <= 1024: row core twice, COLS transforms per workgroup
       if (!get_blu_small_kernel<T>(ilog2(n_), blu_small_)) return false;
       set_smem_attribute(blu_small_);
@@ -758,7 +759,7 @@ template <typename T> class MixedEngine {
         FOURIER_MIX_CT(2187) FOURIER_MIX_CT(2304) FOURIER_MIX_CT(2592) FOURIER_MIX_CT(2916) FOURIER_MIX_CT(3072) FOURIER_MIX_CT(3456)
         FOURIER_MIX_CT(3888) FOURIER_MIX_CT(4374) FOURIER_MIX_CT(4608) FOURIER_MIX_CT(5184) FOURIER_MIX_CT(5832) FOURIER_MIX_CT(6144)
         FOURIER_MIX_CT(6561) FOURIER_MIX_CT(6912) FOURIER_MIX_CT(7776) FOURIER_MIX_CT(8748) FOURIER_MIX_CT(9216) FOURIER_MIX_CT(10368)
-        FOURIER_MIX_CT(11664) FOURIER_MIX_CT(12288) FOURIER_MIX_CT(13122) FOURIER_MIX_CT(13824) FOURIER_MIX_CT(15552) FOURIER_MIX_CT(17496)
+        FOURIER_MIX_CT(11664) FOURIER_MIX_CT(13122) FOURIER_MIX_CT(13824) FOURIER_MIX_CT(15552) FOURIER_MIX_CT(17496)
         FOURIER_MIX_CT(18432)
         default: break;
       }
@@ -862,7 +863,17 @@ template <typename T> class Plan {
     desc_ += sizeof(T) == 4 ? " f32" : " f64";
   }
 
+  ~Plan() {
+    if (legacy_stream_) {
+      DeviceGuard g(device_);
+      (void)hipStreamDestroy(legacy_stream_);
+    }
+  }
+  Plan(const Plan&) = delete;
+  Plan& operator=(const Plan&) = delete;
+
   size_t size() const { return n_; }
+  int device() const { return device_; }
   const char* describe() const { return desc_.c_str(); }
   int last_status() const { return status_; }
   void set_status(int s) const { status_ = s; }
@@ -896,6 +907,7 @@ template <typename T> class Plan {
   }
 
   int set_option(const std::string& key, long long v) {
+    DeviceGuard g(device_);  // bluestein_fusion may allocate tables: they must land on the plan's device
     if (key == "chunk_bytes" && v >= 0) { chunk_bytes_ = (size_t)v; return 0; }
     if (key == "scratch" && (v == 0 || v == 1)) { force_scratch_ = (v == 1); return 0; }
     if (key == "xcd_swizzle" && v >= 0 && v <= 3) { nxcd_ = v == 0 ? 1 : (8 | ((unsigned)(v - 1) << 8)); return 0; }
@@ -907,6 +919,48 @@ template <typename T> class Plan {
     if (key == "bluestein_conv" && (v == 0 || v == 1)) { conv_ = (v == 1) && conv_ok_; return 0; }
     if (key == "host_chunk_bytes" && v > 0) { host_chunk_bytes_ = (size_t)v; return 0; }
     return ::fourier::c::FOURIER_HIP_INVALID_ARGUMENT;
+  }
+
+  // Chunk size for a call of `batch` transforms and the plan-owned device buffers it needs (scratch of the in-place /
+  // three-pass plans, the Bluestein work array).  exec() calls this on every call -- it allocates only when the batch
+  // is larger than anything seen before -- and fourier_hip_reserve_* calls it ahead of time, so that a later
+  // transform_batch of at most that batch never allocates (hipMalloc / hipFree synchronise the device) and can be
+  // captured into a HIP graph.  Returns the number of transforms per chunk.
+  size_t prepare(size_t batch, bool in_place) const {
+    if (mix_ || batch == 0) return batch;
+    const size_t per = (blu_ ? m_ : n_) * ELEM;
+    size_t chunk = batch;
+    if (chunk_bytes_) chunk = std::max<size_t>(1, std::min<size_t>(batch, chunk_bytes_ / per));
+    // keep every launch's grid below 2^31 blocks
+    while (chunk > 1 && (double)chunk * (double)(blu_ ? m_ : n_) / 16.0 > 2.0e9) chunk = (chunk + 1) / 2;
+    // The plan's scratch (and the Bluestein work array) hold one chunk.  If the device cannot give that much -- an
+    // in-place call on a batch that fills most of the HBM -- fall back to smaller chunks instead of failing: chunks
+    // run back to back on the stream and the results are the same.
+    auto reserve = [&](auto&& alloc) {
+      for (;;) {
+        try { alloc(chunk); return; }
+        catch (const EngineError& e) {
+          if (e.status != ::fourier::c::FOURIER_HIP_OUT_OF_MEMORY || chunk <= 1) throw;
+          (void)hipGetLastError();  // the allocation failure is handled here
+          chunk = (chunk + 1) / 2;
+        }
+      }
+    };
+    if (!blu_) {
+      const bool need = eng_->needs_scratch(in_place) || (force_scratch_ && eng_->num_passes() >= 2);
+      if (need) reserve([&](size_t c) { scratch_.ensure(c * n_ * ELEM); });
+      return chunk;
+    }
+    if (small_fused_) return batch;  // whole chirp-z in one launch: no work array
+    reserve([&](size_t c) {
+      work_.ensure(c * m_ * ELEM);
+      if (eng_->needs_scratch(true) || fused_) scratch_.ensure(c * m_ * ELEM);
+    });
+    return chunk;
+  }
+  void reserve_for(size_t batch, bool in_place) const {
+    DeviceGuard g(device_);
+    (void)prepare(batch, in_place);
   }
 
   // Batched transform on device memory (the operator behind Fft::transform / transform_in_place).
@@ -931,29 +985,9 @@ template <typename T> class Plan {
                 scale, stream, prof);
       return;
     }
-    const size_t per = (blu_ ? m_ : n_) * ELEM;
-    size_t chunk = batch;
-    if (chunk_bytes_) chunk = std::max<size_t>(1, std::min<size_t>(batch, chunk_bytes_ / per));
-    // keep every launch's grid below 2^31 blocks
-    while (chunk > 1 && (double)chunk * (double)(blu_ ? m_ : n_) / 16.0 > 2.0e9) chunk = (chunk + 1) / 2;
-
-    // The plan's scratch (and the Bluestein work array) hold one chunk.  If the device cannot give that much -- an
-    // in-place call on a batch that fills most of the HBM -- fall back to smaller chunks instead of failing: chunks
-    // run back to back on the stream and the results are the same.
-    auto reserve = [&](auto&& alloc) {
-      for (;;) {
-        try { alloc(chunk); return; }
-        catch (const EngineError& e) {
-          if (e.status != ::fourier::c::FOURIER_HIP_OUT_OF_MEMORY || chunk <= 1) throw;
-          (void)hipGetLastError();  // the allocation failure is handled here
-          chunk = (chunk + 1) / 2;
-        }
-      }
-    };
+    const size_t chunk = prepare(batch, in_place);
 
     if (!blu_) {
-      const bool need = eng_->needs_scratch(in_place) || (force_scratch_ && eng_->num_passes() >= 2);
-      if (need) reserve([&](size_t c) { scratch_.ensure(c * n_ * ELEM); });
       for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const size_t nb = std::min(chunk, batch - b0);
         eng_->run(in + b0 * n_, out + b0 * n_, (cpx<T>*)scratch_.p, nb, inverse, scale, nullptr, force_scratch_, stream, prof, 0, nxcd_);
@@ -965,10 +999,6 @@ template <typename T> class Plan {
       eng_->run_bluestein_small(in, out, batch, xtab_.p, wtab_.p, n_, inverse, scale, stream, prof, nxcd_);
       return;
     }
-    reserve([&](size_t c) {
-      work_.ensure(c * m_ * ELEM);
-      if (eng_->needs_scratch(true) || fused_) scratch_.ensure(c * m_ * ELEM);
-    });
     cpx<T>* work = (cpx<T>*)work_.p;
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
       const size_t nb = std::min(chunk, batch - b0);
@@ -1029,6 +1059,10 @@ template <typename T> class Plan {
     DeviceGuard g(device_);
     const size_t bytes = n_ * ELEM;
     pinned_.ensure(bytes);
+    // the plan's own non-blocking stream: a legacy call never serialises against the NULL stream or any other
+    // stream of the process (a relinked, threaded C/C++ program keeps its concurrency; one thread per handle)
+    if (!legacy_stream_) HIP_CHECK(hipStreamCreateWithFlags(&legacy_stream_, hipStreamNonBlocking));
+    const hipStream_t st = legacy_stream_;
     {
       const CopyJob in_job{pinned_.h, h_in, bytes};
       parallel_copy(&in_job, 1);  // one thread below 4 MiB, a few above (a 2^20-point transform is 8-16 MiB)
@@ -1036,14 +1070,14 @@ template <typename T> class Plan {
     if (bytes <= ZERO_COPY_MAX) {
       // small transforms are latency-bound: the kernels read and write the mapped host buffer directly over
       // PCIe (every plan reads its input once and writes its output once) -- one launch chain, one sync
-      exec(pinned_.d, pinned_.d, 1, code, (hipStream_t)0);
+      exec(pinned_.d, pinned_.d, 1, code, st);
     } else {
       hostio_.ensure(bytes);
-      HIP_CHECK(hipMemcpyAsync(hostio_.p, pinned_.h, bytes, hipMemcpyHostToDevice, (hipStream_t)0));
-      exec(hostio_.p, hostio_.p, 1, code, (hipStream_t)0);
-      HIP_CHECK(hipMemcpyAsync(pinned_.h, hostio_.p, bytes, hipMemcpyDeviceToHost, (hipStream_t)0));
+      HIP_CHECK(hipMemcpyAsync(hostio_.p, pinned_.h, bytes, hipMemcpyHostToDevice, st));
+      exec(hostio_.p, hostio_.p, 1, code, st);
+      HIP_CHECK(hipMemcpyAsync(pinned_.h, hostio_.p, bytes, hipMemcpyDeviceToHost, st));
     }
-    HIP_CHECK(hipStreamSynchronize((hipStream_t)0));
+    HIP_CHECK(hipStreamSynchronize(st));
     const CopyJob out_job{h_out, pinned_.h, bytes};
     parallel_copy(&out_job, 1);
   }
@@ -1159,7 +1193,9 @@ template <typename T> class Plan {
     for (int j = 0; j < njobs; ++j) {
       const CopyJob job = jobs[j];
       const size_t nt = std::max<size_t>(1, std::min<size_t>(COPY_THREADS, job.bytes / ((size_t)2 << 20)));
-      const size_t piece = ((job.bytes / nt) + 4095) & ~(size_t)4095;
+      // ceil(bytes / nt) rounded up to a page: nt * piece >= bytes for every byte count (floor division dropped
+      // the last r < nt bytes of jobs of the form nt*4096*k + r)
+      const size_t piece = (((job.bytes + nt - 1) / nt) + 4095) & ~(size_t)4095;
       for (size_t t = 0; t < nt; ++t) {
         const size_t off = t * piece;
         if (off >= job.bytes) break;
@@ -1209,6 +1245,7 @@ template <typename T> class Plan {
   DevBuf xtab_, wtab_;
   mutable DevBuf scratch_, work_, hostio_;
   mutable PinnedBuf pinned_;
+  mutable hipStream_t legacy_stream_ = nullptr;  // legacy host-buffer calls (exec_host)
   size_t chunk_bytes_ = 0;
   size_t host_chunk_bytes_ = HOST_CHUNK_BYTES;  // exec_host_batch: bytes of one streamed chunk
   bool force_scratch_ = false;
@@ -1230,6 +1267,7 @@ template <typename T> static Plan<T>* create_plan(size_t n, int device) {
 
 template <typename T, typename F> static int guarded(const Plan<T>* p, F&& f) {
   if (!p) return ::fourier::c::FOURIER_HIP_INVALID_ARGUMENT;
+  p->set_status(::fourier::c::FOURIER_HIP_OK);  // last_status = status of the LAST call on this handle
   try {
     f();
     return ::fourier::c::FOURIER_HIP_OK;
@@ -1279,6 +1317,13 @@ namespace fc = ::fourier::c;
                                                       void* d_out, size_t batch, int code, void* stream) {       \
     const Plan<T>* p = (const Plan<T>*)h;                                                                        \
     return guarded<T>(p, [&] { p->exec(d_in, d_out, batch, code, (hipStream_t)stream); });                       \
+  }                                                                                                              \
+  extern "C" int fourier_hip_reserve_##SUFFIX(const fc::fourier_fft_##SUFFIX* h, size_t batch, int in_place) {   \
+    const Plan<T>* p = (const Plan<T>*)h;                                                                        \
+    return guarded<T>(p, [&] { p->reserve_for(batch, in_place != 0); });                                         \
+  }                                                                                                              \
+  extern "C" int fourier_hip_device_##SUFFIX(const fc::fourier_fft_##SUFFIX* h) {                                \
+    return h ? ((const Plan<T>*)h)->device() : -1;                                                               \
   }                                                                                                              \
   extern "C" int fourier_hip_transform_batch_host_##SUFFIX(const fc::fourier_fft_##SUFFIX* h, const std::complex<T>* in, \
                                                            std::complex<T>* out, size_t batch, int code) {      \
@@ -1336,4 +1381,6 @@ extern "C" void fourier_emu_lds_stats(uint64_t* instr, uint64_t* cycles, uint64_
   *instr = s.instr; *cycles = s.cycles; *ideal = s.ideal;
   if (reset) { s.instr = 0; s.cycles = 0; s.ideal = 0; }
 }
+// test-only: number of device allocations so far (tests/test_engine_emu.py: reserve makes calls allocation-free)
+extern "C" uint64_t fourier_emu_alloc_count() { return hipemu::alloc_count(); }
 #endif

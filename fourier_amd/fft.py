@@ -58,6 +58,7 @@ class Fft:
             # the reference's create panics -> NULL through the FFI (fourier-ffi/src/lib.rs:18-19)
             raise FourierError(f"cannot create FFT plan of size {size}")
         self._n = int(size)
+        self.device = int(getattr(self._L, f"fourier_hip_device_{self._suffix}")(self._h))  # device=-1 binds the current one
 
     # -- trait surface ---------------------------------------------------------------------
     def size(self):
@@ -104,6 +105,13 @@ class Fft:
         if st != 0:
             raise FourierError(self._L.fourier_hip_status_string(st).decode())
 
+    def reserve(self, batch, in_place=False):
+        """Pre-size the plan-owned device buffers so that later batched calls of up to `batch` transforms never
+        allocate (hipMalloc synchronises the device; needed before HIP-graph capture)."""
+        st = getattr(self._L, f"fourier_hip_reserve_{self._suffix}")(self._h, int(batch), int(bool(in_place)))
+        if st != 0:
+            raise FourierError(self._L.fourier_hip_status_string(st).decode())
+
     def profile_batch_ptr(self, d_in, d_out, batch, transform, stream=0, nslots=16):
         """One batched transform with a HIP event pair around every kernel launch.
         Returns [(slot_name, total_ms, launches), ...] in launch order."""
@@ -143,6 +151,15 @@ class Fft:
             # extension accepts any whole number of transforms
             if input.numel() != output.numel() or input.numel() % self._n != 0 or input.numel() == 0:
                 raise ValueError(f"buffer of {input.numel()} elements is not a multiple of size {self._n}")
+            # the plan's tables, scratch and kernels live on ONE device (fixed at creation)
+            for t in (input, output):
+                if t.device.index != self.device:
+                    raise ValueError(f"tensor on cuda:{t.device.index}, plan on cuda:{self.device}")
+            # same buffer = in place; anything else must not overlap (include/fourier.h)
+            a0, b0 = input.data_ptr(), output.data_ptr()
+            nbytes = input.numel() * input.element_size()
+            if a0 != b0 and a0 < b0 + nbytes and b0 < a0 + nbytes:
+                raise ValueError("input and output overlap partially")
             stream = torch.cuda.current_stream(input.device).cuda_stream
             self.transform_batch_ptr(input.data_ptr(), output.data_ptr(), input.numel() // self._n, code, stream)
             return

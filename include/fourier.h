@@ -98,14 +98,29 @@ FOURIER_SIZE_TYPE fourier_hip_size_double(const FOURIER_STRUCT fourier_fft_doubl
 
 /* Batched `Fft::transform` on DEVICE memory: `batch` contiguous transforms, transform b at element
  * offset b*size, interleaved complex.  d_in == d_out selects in-place (`transform_in_place`).
- * Enqueued on `stream` (a hipStream_t, NULL = default stream); returns without synchronising.
- * Partial overlap of d_in and d_out is not allowed. */
+ * Enqueued on `stream` (a hipStream_t, NULL = default stream); the kernels are only enqueued, the call
+ * does not wait for them.  Plans that need a plan-owned device buffer (in-place calls of the two-pass
+ * plans, three-pass plans, the Bluestein work array) allocate it on the first call whose batch is larger
+ * than any before -- hipMalloc / hipFree synchronise the device -- unless fourier_hip_reserve_* was
+ * called for at least that batch first; after a reserve the call never allocates and can be captured
+ * into a HIP graph.  Partial overlap of d_in and d_out is not allowed. */
 int fourier_hip_transform_batch_float(const FOURIER_STRUCT fourier_fft_float *, const void *d_in,
                                       void *d_out, FOURIER_SIZE_TYPE batch, int transform,
                                       void *stream);
 int fourier_hip_transform_batch_double(const FOURIER_STRUCT fourier_fft_double *, const void *d_in,
                                        void *d_out, FOURIER_SIZE_TYPE batch, int transform,
                                        void *stream);
+
+/* Pre-size the plan-owned device buffers (scratch / Bluestein work array) for calls of up to `batch`
+ * transforms, in place (in_place != 0) or out of place.  May synchronise the device; a later
+ * fourier_hip_transform_batch_* with batch <= `batch` and the same placement does not allocate. */
+int fourier_hip_reserve_float(const FOURIER_STRUCT fourier_fft_float *, FOURIER_SIZE_TYPE batch, int in_place);
+int fourier_hip_reserve_double(const FOURIER_STRUCT fourier_fft_double *, FOURIER_SIZE_TYPE batch, int in_place);
+
+/* Device index the plan lives on (its tables, scratch and kernels); -1 for a NULL handle.  Buffers
+ * passed to fourier_hip_transform_batch_* must be resident on (or mapped into) that device. */
+int fourier_hip_device_float(const FOURIER_STRUCT fourier_fft_float *);
+int fourier_hip_device_double(const FOURIER_STRUCT fourier_fft_double *);
 
 /* Batched `Fft::transform` on HOST memory -- what a caller of the reference holds (one slice per transform,
  * fourier-algorithms/src/fft.rs:48-61), `batch` of them contiguously.  The transforms are streamed through the
@@ -119,7 +134,10 @@ int fourier_hip_transform_batch_host_double(const FOURIER_STRUCT fourier_fft_dou
                                             const FOURIER_COMPLEX_DOUBLE_TYPE *in, FOURIER_COMPLEX_DOUBLE_TYPE *out,
                                             FOURIER_SIZE_TYPE batch, int transform);
 
-/* Sticky status of the last failing call on this handle (FOURIER_HIP_OK if none) and its text. */
+/* Status of the LAST call made on this handle (every entry point that takes a handle resets it to
+ * FOURIER_HIP_OK on entry and records its own failure, if any) and the text of a status.  The legacy
+ * `void` entry points of Part 1 report through this query; a successful call after a failed one reads
+ * FOURIER_HIP_OK again. */
 int fourier_hip_last_status_float(const FOURIER_STRUCT fourier_fft_float *);
 int fourier_hip_last_status_double(const FOURIER_STRUCT fourier_fft_double *);
 const char *fourier_hip_status_string(int status);

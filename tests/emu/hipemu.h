@@ -234,7 +234,9 @@ inline int __shfl_xor(int v, int lane_mask) {
 }
 
 // ---- host API subset ----
+namespace hipemu { inline uint64_t& alloc_count() { static uint64_t c = 0; return c; } }
 inline hipError_t hipMalloc(void** p, size_t n) {
+  hipemu::alloc_count()++;
   if (const char* cap = getenv("HIPEMU_MAX_ALLOC"))  // tests: pretend the device is out of memory above this size
     if (n > (size_t)atoll(cap)) { *p = nullptr; return hipErrorOutOfMemory; }
   *p = n ? malloc(n) : nullptr;

@@ -452,3 +452,65 @@ def test_lds_layouts_are_bank_conflict_light(fa):
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     assert float(out.stdout.strip().splitlines()[-1]) <= 1.1
+
+
+def test_host_staging_copies_cover_byte_counts_that_do_not_divide_over_the_copy_threads(fa):
+    """Regression (round-1 advisor, high): parallel_copy split a job with floor(bytes / nt) and dropped the last
+    r < nt bytes of jobs of the form nt*4096*k + r -- the last element of a large host batch was never staged in
+    nor copied back.  n = 7, batch = 452023 is 12*4096*515 + 8 bytes when it is one chunk."""
+    n, batch = 7, 452023
+    assert (n * batch * 8) % (12 * 4096) == 8
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(np.complex64)
+    plan = make(fa, n, np.complex64)
+    plan.set_option("host_chunk_bytes", x.nbytes)  # the whole batch is one chunk, i.e. one copy job each way
+    y = np.full_like(x, np.nan)
+    plan.transform_batch_host(x, y, fa.Transform.Fft)
+    ref = run_batch(plan, x[-3:], 0)
+    assert not np.isnan(y.view(np.float32)).any()          # every output byte was written back
+    assert np.array_equal(y[-3:], ref)                      # and the last transform saw its whole input
+    # the legacy one-transform ABI stages through the same routine: a transform of 12*4096*k + 8 bytes
+    n2 = (12 * 4096 * 40 + 8) // 8
+    x2 = hash_normal(9, n2).astype(np.complex64)
+    p2 = make(fa, n2, np.complex64)
+    y2 = np.full_like(x2, np.nan)
+    p2.transform(x2, y2, fa.Transform.Fft)
+    ref2 = run_batch(p2, x2[None, :], 0)[0]
+    assert np.array_equal(y2, ref2)
+
+
+def test_last_status_is_the_status_of_the_last_call(fa):
+    """Regression (round-1 advisor, medium): a failing call left the handle's status set for ever, so every later
+    successful numpy transform raised.  Now every entry point resets it on entry (include/fourier.h)."""
+    plan = make(fa, 64, np.complex64)
+    x = hash_normal(2, 64).astype(np.complex64)
+    y = np.empty_like(x)
+    with pytest.raises(fa.FourierError):
+        plan.transform_batch_ptr(x.ctypes.data, y.ctypes.data, 1, 9)  # unknown transform code
+    plan.transform(x, y, fa.Transform.Fft)  # must not raise
+    assert rel_l2(y, np.fft.fft(x.astype(np.complex128))) < 1e-6
+    from fourier_amd import _lib
+
+    L = _lib.lib()
+    assert L.fourier_hip_last_status_float(plan._h) == 0
+
+
+def test_reserve_presizes_the_scratch_so_that_calls_do_not_allocate(fa):
+    """fourier_hip_reserve_*: after reserve(batch, in_place) a batched call of at most that batch performs no
+    device allocation (hipMalloc synchronises; needed for graph capture).  The emulator counts allocations."""
+    from fourier_amd import _lib
+
+    L = _lib.lib()
+    L.fourier_emu_alloc_count.restype = ctypes.c_uint64
+    for n in (1 << 16, 1000003 // 11, 3 << 12):  # two-pass in place, Bluestein with a work array, three launches
+        plan = make(fa, n, np.complex64)
+        x = hash_normal(4, 3 * n).astype(np.complex64).reshape(3, n)
+        ref = run_batch(plan, x, 0, inplace=True)
+        plan2 = make(fa, n, np.complex64)
+        plan2.reserve(3, in_place=True)
+        before = L.fourier_emu_alloc_count()
+        got = run_batch(plan2, x, 0, inplace=True)
+        got1 = run_batch(plan2, x[:2], 0, inplace=True)
+        assert L.fourier_emu_alloc_count() == before, n
+        assert np.array_equal(got, ref) and np.array_equal(got1, ref[:2])
+    assert plan2.device == 0
