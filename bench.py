@@ -2,17 +2,30 @@
 """bench.py -- headline benchmark of the batched 1D c2c FFT hot path on MI355X.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched under
-torch.distributed.run, one rank per GPU.  A "step" is one pass of the hot path over one batch of
-synthetic input: BASELINE.json configs[1], batched 1D c2c f32, N=2^20, batch=4096 per GPU,
-forward `Transform::Fft`, out of place, inputs resident in HBM before the timed region.
-Rank 0 prints ONE JSON line.  metric = nominal 5*N*log2(N) GFLOP/s, whole job (all ranks).
+torch.distributed.run, one rank per GPU.  Rank 0 prints ONE JSON line.
+metric = nominal 5*N*log2(N) GFLOP/s, whole job (all ranks).
+
+Workloads (`--config`, default `auto`):
+  c2    BASELINE.json configs[1]: f32 N=2^20, batch 4096 per GPU, forward, out of place, inputs resident in
+        HBM before the timed region.  A "step" = one pass of the hot path over the batch.  THE DEFAULT AT N=1.
+  c5    BASELINE.json configs[4]: f32 N=2^22, GLOBAL batch 65536 (2 TiB of input) split contiguously over the
+        ranks (fourier_amd.shard.batch_shard; no data-path collective) -- "scaling": "strong".  The shard does
+        not fit in HBM, so a rank walks it in fixed chunks of 1024 transforms (32 GiB), each regenerated on the
+        device (seeded by its global chunk index) right before it is transformed.  A "step" = one pass over the
+        whole 65536-transform job; the step time is the FFT time (chunk generation is bracketed out with
+        device syncs and reported separately as wall_ms_per_step_incl_regen).  THE DEFAULT AT N>1: this is the
+        configuration BASELINE.json names for the 1/2/4/8-GPU scaling curve.
+  c3 / c4   configs[2] (f64 N=2^20 x 4096) and configs[3] (Bluestein N=999983 f32 x 512), same form as c2.
+`auto` = c2 on one GPU, c5 under torch.distributed.run with more than one rank.
 
 Extra objects in the JSON line:
-  roofline     -- dominant kernel, algorithmic bytes per launch / HIP-event duration (events on the
-                  launch stream, inside this process), peak 8 TB/s; `traffic` from the committed
-                  rocprofv3 PMC pass (profiles/traffic_latest.json) or null.
-  cpu_baseline -- the oracle (CPU restatement of the reference, kind "port") timed on this box's host
-                  cores on a bounded sample of the same workload (rank 0, N=1 only).
+  roofline      -- dominant kernel, algorithmic bytes per launch / HIP-event duration (events on the
+                   launch stream, inside this process), peak 8 TB/s; `traffic` from the committed
+                   rocprofv3 PMC pass (profiles/traffic_latest.json) or null.
+  cpu_baseline  -- the oracle (CPU restatement of the reference, kind "port") timed on this box's host
+                   cores on a bounded sample of the same workload (rank 0, N=1 only).
+  other_configs -- (N=1, default config only) a few seconds each on C3, C4 and one C5 chunk after the
+                   headline timing: ms, algorithmic fraction, dominant-kernel fraction.
 """
 import argparse
 import json
@@ -26,21 +39,190 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
+CONFIGS = {
+    "c2": dict(n=1 << 20, batch=4096, dtype="f32", name="BASELINE configs[1]"),
+    "c3": dict(n=1 << 20, batch=4096, dtype="f64", name="BASELINE configs[2]"),
+    "c4": dict(n=999983, batch=512, dtype="f32", name="BASELINE configs[3]"),
+    "c5": dict(n=1 << 22, global_batch=65536, chunk=1024, dtype="f32", name="BASELINE configs[4]"),
+}
+
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--log2n", type=int, default=20)
-    p.add_argument("--batch", type=int, default=4096, help="transforms per GPU per step")
-    p.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    p.add_argument("--config", default="auto", choices=["auto", "c2", "c3", "c4", "c5"])
+    p.add_argument("--log2n", type=int, default=None, help="override the transform length (c2/c3 form)")
+    p.add_argument("--batch", type=int, default=None, help="transforms per GPU per step (c2/c3/c4) or global batch (c5)")
+    p.add_argument("--chunk", type=int, default=None, help="c5: transforms per resident chunk")
+    p.add_argument("--dtype", default=None, choices=["f32", "f64"])
     p.add_argument("--chunk-bytes", type=int, default=None, help="override the plan's chunk_bytes option")
     p.add_argument("--scratch", type=int, default=None, help="override the plan's scratch option (0/1)")
     p.add_argument("--inplace", action="store_true")
     p.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    p.add_argument("--no-other", action="store_true", help="skip the other_configs leg")
     p.add_argument("--cpu-sample", type=int, default=0, help="transforms in the CPU sample (0 = auto)")
     return p.parse_args()
+
+
+def nominal_flops(n):
+    return 5.0 * n * math.log2(n)
+
+
+def make_plan(fourier_amd, n, dtype, device, args=None):
+    plan = (fourier_amd.create_fft_f32 if dtype == "f32" else fourier_amd.create_fft_f64)(n, device)
+    if args is not None:
+        if args.chunk_bytes is not None:
+            plan.set_option("chunk_bytes", args.chunk_bytes)
+        if args.scratch is not None:
+            plan.set_option("scratch", args.scratch)
+    return plan
+
+
+def kernel_profile(plan, x_ptr, y_ptr, batch, stream, reps=3):
+    """Per-kernel ms of one batched transform: HIP events on the launch stream (fourier_hip_profile_*)."""
+    from fourier_amd import Transform
+
+    acc = {}
+    for _ in range(reps):
+        for name, ms, cnt in plan.profile_batch_ptr(x_ptr, y_ptr, batch, int(Transform.Fft), stream):
+            if cnt:
+                a = acc.setdefault(name, [0.0, 0])
+                a[0] += ms
+                a[1] += cnt
+    return {k: {"ms_per_step": v[0] / reps, "launches_per_step": v[1] // reps} for k, v in acc.items()}
+
+
+def roofline_of(plan, kernels, batch, alg_bytes_per, dtype, whole_path_frac, traffic_ok=False):
+    dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+    dom_ms = kernels[dom]["ms_per_step"]
+    achieved = batch * alg_bytes_per / (dom_ms * 1e-3) / 1e9  # all launches of that kernel in a step cover the batch
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if traffic_ok and os.path.exists(tpath):  # the committed PMC pass was taken on the default workload only
+        try:
+            with open(tpath) as f:
+                tj = json.load(f)
+            traffic = tj.get("per_launch_bytes", {}).get(dom)
+        except Exception:
+            traffic = None
+    return {
+        "bound": "hbm", "kernel": dom,
+        "rocprof_name": f"fourier_hip kernel behind slot '{dom}' of plan {plan.describe()} "
+                        f"({'float' if dtype == 'f32' else 'double'})",
+        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+        "algorithmic_bytes_per_launch": batch * alg_bytes_per / max(kernels[dom]["launches_per_step"], 1),
+        "kernels": {k: {"ms_per_step": round(v["ms_per_step"], 4), "launches_per_step": v["launches_per_step"]}
+                    for k, v in kernels.items()},
+        "whole_path_frac": round(whole_path_frac, 4),
+    }
+
+
+def quick_config(fourier_amd, torch, dev, key, reps=3):
+    """A few seconds on another BASELINE config (N=1 only): median of `reps` timed steps + kernel profile."""
+    from fourier_amd import Transform
+
+    c = CONFIGS[key]
+    n, dtype = c["n"], c["dtype"]
+    batch = c.get("batch", c.get("chunk"))
+    esz = 8 if dtype == "f32" else 16
+    cdt = torch.complex64 if dtype == "f32" else torch.complex128
+    plan = make_plan(fourier_amd, n, dtype, dev.index)
+    x = torch.empty((batch, n), dtype=cdt, device=dev)
+    torch.view_as_real(x).uniform_(0.0, 1.0)
+    y = torch.empty_like(x)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    plan.transform_batch_ptr(x.data_ptr(), y.data_ptr(), batch, int(Transform.Fft), stream)
+    torch.cuda.synchronize(dev)
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        plan.transform_batch_ptr(x.data_ptr(), y.data_ptr(), batch, int(Transform.Fft), stream)
+        torch.cuda.synchronize(dev)
+        ts.append(time.perf_counter() - t0)
+    t = sorted(ts)[len(ts) // 2]
+    kernels = kernel_profile(plan, x.data_ptr(), y.data_ptr(), batch, stream, reps=1)
+    alg = 2.0 * n * esz
+    dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+    out = {
+        "workload": f"{c['name']}: {dtype} N={n} batch={batch}" + (" (one chunk of the 65536-transform job)" if key == "c5" else ""),
+        "plan": plan.describe(), "ms_per_step": round(t * 1e3, 3),
+        "gflops": round(batch * nominal_flops(n) / t / 1e9, 1),
+        "hbm_frac_algorithmic": round(batch * alg / t / 1e9 / HBM_PEAK_GBPS, 4),
+        "dominant_kernel": dom,
+        "dominant_kernel_frac": round(batch * alg / (kernels[dom]["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+        "kernels_ms": {k: round(v["ms_per_step"], 3) for k, v in kernels.items()},
+    }
+    del x, y, plan
+    torch.cuda.empty_cache()
+    return out
+
+
+def cpu_baseline(torch, plan, hx, n, dtype, dev, stream, cores):
+    """Parity sample + cpu_baseline: the oracle on this box's host cores (bounded sample)."""
+    import numpy as np
+    from fourier_amd import Transform
+    from oracle import oracle as O
+
+    O.build()
+    flops_per = nominal_flops(n)
+    sample = hx.shape[0]
+    xs = torch.from_numpy(hx).to(dev)
+    ys = torch.empty_like(xs)
+    plan.transform_batch_ptr(xs.data_ptr(), ys.data_ptr(), sample, int(Transform.Fft), stream)
+    torch.cuda.synchronize(dev)
+    got = ys.cpu().numpy()
+    # one oracle plan per thread (plans are Send, not Sync).  The port is memory-bound well before all
+    # hardware threads are busy, so a few thread counts are timed and the best aggregate is reported,
+    # with the count that produced it.
+    ref = np.empty_like(hx)
+    tried = {}
+    for nt in sorted({max(1, cores >> k) for k in range(6)}, reverse=True):  # all, 1/2 ... 1/32 of the host threads
+        ob = O.OracleBatch(n, hx.dtype, nthreads=nt)
+        ob.run(hx[: min(sample, nt)], O.FFT, out=ref[: min(sample, nt)])  # warm-up (page faults)
+        t0 = time.perf_counter()
+        ob.run(hx, O.FFT, out=ref)
+        tried[nt] = time.perf_counter() - t0
+        del ob
+    used = min(tried, key=tried.get)
+    cpu_s = tried[used]
+    # the reference itself is single-threaded (one plan, one slice per call): the same port on ONE core, with the
+    # reference's AVX first pass (radix_4_stride_1_avx_f32, avx_optimization.rs:4-92) and without it
+    k1 = min(sample, 4)
+    one = {}
+    for label, avx in (("avx_first_pass", True), ("scalar_first_pass", False)):
+        if not hasattr(O, "set_avx_first_pass"):
+            if not avx:
+                continue
+        else:
+            O.set_avx_first_pass(avx)
+        ob1 = O.OracleBatch(n, hx.dtype, nthreads=1)
+        ref1 = np.empty_like(hx[:k1])
+        ob1.run(hx[:1], O.FFT, out=ref1[:1])
+        t0 = time.perf_counter()
+        ob1.run(hx[:k1], O.FFT, out=ref1)
+        one[label] = (time.perf_counter() - t0) / k1
+        del ob1
+    if hasattr(O, "set_avx_first_pass"):
+        O.set_avx_first_pass(True)
+    one_core_s = one["avx_first_pass"]
+    err = float(np.linalg.norm(got.astype(np.complex128) - ref) / np.linalg.norm(ref))
+    parity = {"sample_transforms": sample, "rel_l2_vs_oracle": err, "tolerance": 1e-6 if dtype == "f32" else 5e-14}
+    base = {
+        "value": round(sample * flops_per / cpu_s / 1e9, 2), "unit": "GFLOP/s", "cores": used,
+        "host_threads_available": cores,
+        "threads_tried_gflops": {str(k): round(sample * flops_per / v / 1e9, 2) for k, v in tried.items()},
+        "kind": "port",
+        "sample": f"{sample} of the same transforms ({dtype} N={n}, out-of-place), "
+                  f"one oracle plan per thread on {used} threads, {cpu_s:.2f} s wall",
+        "ms_per_transform_aggregate": round(cpu_s / sample * 1e3, 3),
+        "one_core": {"ms_per_transform": round(one_core_s * 1e3, 3), "value": round(flops_per / one_core_s / 1e9, 3),
+                     "unit": "GFLOP/s", "sample": f"{k1} transforms on 1 thread",
+                     "ms_per_transform_by_first_pass": {k: round(v * 1e3, 3) for k, v in one.items()}},
+    }
+    return parity, base
 
 
 def main():
@@ -63,64 +245,121 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import fourier_amd
-    from fourier_amd import Transform
+    from fourier_amd import Transform, shard
 
-    n = 1 << args.log2n
-    batch = args.batch
-    cdt = torch.complex64 if args.dtype == "f32" else torch.complex128
-    esz = 8 if args.dtype == "f32" else 16
-    plan = (fourier_amd.create_fft_f32 if args.dtype == "f32" else fourier_amd.create_fft_f64)(n, local_rank)
-    if args.chunk_bytes is not None:
-        plan.set_option("chunk_bytes", args.chunk_bytes)
-    if args.scratch is not None:
-        plan.set_option("scratch", args.scratch)
-
-    # synthetic input: re, im i.i.d. uniform [0,1) (the reference bench recipe, fft_bench.rs:18-23)
-    torch.manual_seed(0x5EED0001 + rank)
-    x = torch.empty((batch, n), dtype=cdt, device=dev)
-    torch.view_as_real(x).uniform_(0.0, 1.0)
-    y = x if args.inplace else torch.empty_like(x)
+    key = args.config if args.config != "auto" else ("c5" if world > 1 else "c2")
+    cfg = dict(CONFIGS[key])
+    if args.dtype:
+        cfg["dtype"] = args.dtype
+    if args.log2n is not None:
+        cfg["n"] = 1 << args.log2n
+    dtype, n = cfg["dtype"], cfg["n"]
+    cdt = torch.complex64 if dtype == "f32" else torch.complex128
+    esz = 8 if dtype == "f32" else 16
+    flops_per = nominal_flops(n)
+    alg_bytes_per = 2.0 * n * esz  # SURVEY.md 8(d): each point read once + written once
+    plan = make_plan(fourier_amd, n, dtype, local_rank, args)
     stream = torch.cuda.current_stream(dev).cuda_stream
-
-    def step():
-        plan.transform_batch_ptr(x.data_ptr(), y.data_ptr(), batch, int(Transform.Fft), stream)
-
-    # host copy of the parity / CPU-baseline sample, taken before anything can overwrite the input
-    hx = None
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    if rank == 0 and world == 1 and not args.no_cpu:
-        sample = min(batch, args.cpu_sample or max(8, min(256, 2 * cores)))
-        hx = x[:sample].cpu().numpy()
 
     def sync_all():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(dev)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    hx = None
+    extra = {}
+    if key == "c5":
+        # ---- strong scaling: the global batch is split over the ranks, a rank walks its shard in resident chunks
+        gbatch = args.batch or cfg["global_batch"]
+        chunk = args.chunk or cfg["chunk"]
+        lo, hi = shard.batch_shard(gbatch, world, rank)
+        chunk = max(1, min(chunk, hi - lo))
+        x = torch.empty((chunk, n), dtype=cdt, device=dev)
+        y = x if args.inplace else torch.empty_like(x)
+        if args.inplace:
+            plan.reserve(chunk, in_place=True)
+        gen = torch.Generator(device=dev)
+        batch = chunk  # per launch (roofline leg)
+        units_per_step = gbatch
 
-    flops_per = 5.0 * n * math.log2(n)
-    alg_bytes_per = 2.0 * n * esz  # SURVEY.md 8(d): each point read once + written once
-    total_units = world * batch * args.steps
+        def step(step_index):
+            """One pass over this rank's shard; returns the FFT-only seconds (generation bracketed out)."""
+            t_fft = 0.0
+            for b0 in range(lo, hi, chunk):
+                nb = min(chunk, hi - b0)
+                gen.manual_seed(0x5EED0C50 + 7919 * step_index + b0)  # every chunk of every step is new data
+                torch.view_as_real(x[:nb]).uniform_(0.0, 1.0, generator=gen)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                plan.transform_batch_ptr(x.data_ptr(), y.data_ptr(), nb, int(Transform.Fft), stream)
+                torch.cuda.synchronize(dev)
+                t_fft += time.perf_counter() - t1
+            return t_fft
+
+        for w in range(args.warmup):
+            step(-1 - w)
+        sync_all()
+        t0 = time.perf_counter()
+        fft_s = 0.0
+        for k in range(args.steps):
+            fft_s += step(k)
+        torch.cuda.synchronize(dev)
+        sync_all()
+        wall = time.perf_counter() - t0
+        elapsed = shard.reduce_max_seconds(fft_s, dist, dev)
+        wall = shard.reduce_max_seconds(wall, dist, dev)
+        extra["wall_ms_per_step_incl_regen"] = round(wall / args.steps * 1e3, 3)
+        workload = (f"batched 1D c2c {dtype} N={n} GLOBAL batch={gbatch} batch-sharded over {world} GPU(s) "
+                    f"({hi - lo} per GPU as resident chunks of {chunk}, regenerated on the device), forward "
+                    f"{'in-place' if args.inplace else 'out-of-place'} ({cfg['name']})")
+        config = {"workload": workload, "n": n, "global_batch": gbatch, "batch_per_gpu": hi - lo, "chunk": chunk,
+                  "parallelism": f"batch-shard x{world}", "plan": plan.describe()}
+        scaling = "strong"
+        if rank == 0 and not args.no_cpu:
+            hx = None  # parity for c5: two transforms of the resident chunk, below
+    else:
+        batch = args.batch or cfg["batch"]
+        units_per_step = world * batch
+        # synthetic input: re, im i.i.d. uniform [0,1) (the reference bench recipe, fft_bench.rs:18-23)
+        torch.manual_seed(0x5EED0001 + rank)
+        x = torch.empty((batch, n), dtype=cdt, device=dev)
+        torch.view_as_real(x).uniform_(0.0, 1.0)
+        y = x if args.inplace else torch.empty_like(x)
+        if args.inplace:
+            plan.reserve(batch, in_place=True)
+
+        def step():
+            plan.transform_batch_ptr(x.data_ptr(), y.data_ptr(), batch, int(Transform.Fft), stream)
+
+        # host copy of the parity / CPU-baseline sample, taken before anything can overwrite the input
+        if rank == 0 and world == 1 and not args.no_cpu:
+            sample = min(batch, args.cpu_sample or max(8, min(256, 2 * cores)))
+            hx = x[:sample].cpu().numpy()
+        for _ in range(args.warmup):
+            step()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize(dev)
+        sync_all()
+        elapsed = shard.reduce_max_seconds(time.perf_counter() - t0, dist, dev)
+        workload = (f"batched 1D c2c {dtype} N={n} batch={batch}/GPU forward "
+                    f"{'in-place' if args.inplace else 'out-of-place'} ({cfg['name']})")
+        config = {"workload": workload, "n": n, "batch_per_gpu": batch, "global_batch": world * batch,
+                  "parallelism": f"batch-shard x{world}", "plan": plan.describe()}
+        scaling = "weak"
+
+    total_units = units_per_step * args.steps
     gflops = total_units * flops_per / elapsed / 1e9
     alg_gbps = total_units * alg_bytes_per / elapsed / 1e9
     ms_per_step = elapsed / args.steps * 1e3
+    log2n = math.log2(n)
+    nlabel = f"2^{int(log2n)}" if log2n == int(log2n) else str(n)
 
     out = {
-        "metric": "batched 1D c2c FFT GFLOP/s (5N*log2N), f32 N=2^20" if (args.dtype == "f32" and args.log2n == 20)
-        else f"batched 1D c2c FFT GFLOP/s (5N*log2N), {args.dtype} N=2^{args.log2n}",
+        "metric": f"batched 1D c2c FFT GFLOP/s (5N*log2N), {dtype} N={nlabel}",
         "value": round(gflops, 1),
         "unit": "GFLOP/s",
         "n_gpus": world,
@@ -128,102 +367,57 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
-        "dtype": args.dtype,
+        "dtype": dtype,
         "data": "synthetic",
-        "config": {
-            "workload": f"batched 1D c2c {args.dtype} N=2^{args.log2n} batch={batch}/GPU forward "
-                        f"{'in-place' if args.inplace else 'out-of-place'} (BASELINE configs[1])",
-            "n": n, "batch_per_gpu": batch, "global_batch": world * batch, "parallelism": f"batch-shard x{world}",
-            "plan": plan.describe(),
-        },
+        "config": config,
         "hbm_gbps_algorithmic": round(alg_gbps, 1),
         "hbm_frac_algorithmic": round(alg_gbps / (HBM_PEAK_GBPS * world), 4),
     }
+    out.update(extra)
 
     if rank == 0:
         # ---- roofline of the dominant kernel: HIP events on the launch stream, live
-        reps = 3
-        acc = {}
-        for _ in range(reps):
-            for name, ms, cnt in plan.profile_batch_ptr(x.data_ptr(), y.data_ptr(), batch, int(Transform.Fft), stream):
-                a = acc.setdefault(name, [0.0, 0])
-                a[0] += ms
-                a[1] += cnt
-        kernels = {k: {"ms_per_step": v[0] / reps, "launches_per_step": v[1] // reps} for k, v in acc.items()}
-        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
-        dom_ms = kernels[dom]["ms_per_step"]
-        achieved = batch * alg_bytes_per / (dom_ms * 1e-3) / 1e9  # all launches of that kernel in a step cover the batch
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                with open(tpath) as f:
-                    tj = json.load(f)
-                traffic = tj.get("per_launch_bytes", {}).get(dom)
-            except Exception:
-                traffic = None
-        out["roofline"] = {
-            "bound": "hbm", "kernel": dom,
-            "rocprof_name": f"fourier_hip::fft_pass_kernel<{'float' if args.dtype == 'f32' else 'double'}, ...> "
-                            f"({'first' if dom == 'pass0' else 'last'} pass of plan {plan.describe()})",
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-            "algorithmic_bytes_per_launch": batch * alg_bytes_per / max(kernels[dom]["launches_per_step"], 1),
-            "kernels": {k: {"ms_per_step": round(v["ms_per_step"], 4), "launches_per_step": v["launches_per_step"]}
-                        for k, v in kernels.items()},
-            "whole_path_frac": round(alg_gbps / world / HBM_PEAK_GBPS, 4),
-        }
+        kernels = kernel_profile(plan, x.data_ptr(), y.data_ptr(), batch, stream)
+        out["roofline"] = roofline_of(plan, kernels, batch, alg_bytes_per, dtype, alg_gbps / world / HBM_PEAK_GBPS,
+                                      traffic_ok=(key == "c2" and n == 1 << 20 and dtype == "f32" and batch == 4096))
 
-        # ---- parity sample + cpu_baseline: the oracle on this box's host cores (bounded sample)
-        if hx is not None:
+        if key == "c5" and not args.no_cpu:
+            # parity on the resident chunk: its first and last transform against the oracle (bounded: 2 transforms)
             import numpy as np
             from oracle import oracle as O
 
             O.build()
-            sample = hx.shape[0]
-            xs = torch.from_numpy(hx).to(dev)
-            ys = torch.empty_like(xs)
-            plan.transform_batch_ptr(xs.data_ptr(), ys.data_ptr(), sample, int(Transform.Fft), stream)
+            torch.view_as_real(x).uniform_(0.0, 1.0)
+            keep = [x[0].cpu().numpy(), x[batch - 1].cpu().numpy()]
+            plan.transform_batch_ptr(x.data_ptr(), y.data_ptr(), batch, int(Transform.Fft), stream)
             torch.cuda.synchronize(dev)
-            got = ys.cpu().numpy()
-            # one oracle plan per thread (plans are Send, not Sync).  The port is memory-bound well before all
-            # hardware threads are busy, so a few thread counts are timed and the best aggregate is reported,
-            # with the count that produced it.
-            ref = np.empty_like(hx)
-            tried = {}
-            for nt in sorted({max(1, cores >> k) for k in range(6)}, reverse=True):  # all, 1/2 ... 1/32 of the host threads
-                ob = O.OracleBatch(n, hx.dtype, nthreads=nt)
-                ob.run(hx[: min(sample, nt)], O.FFT, out=ref[: min(sample, nt)])  # warm-up (page faults)
-                t0 = time.perf_counter()
-                ob.run(hx, O.FFT, out=ref)
-                tried[nt] = time.perf_counter() - t0
-                del ob
-            used = min(tried, key=tried.get)
-            cpu_s = tried[used]
-            # the reference itself is single-threaded (one plan, one slice per call): the same port on ONE core
-            ob1 = O.OracleBatch(n, hx.dtype, nthreads=1)
-            k1 = min(sample, 4)
-            ref1 = np.empty_like(hx[:k1])
-            ob1.run(hx[:1], O.FFT, out=ref1[:1])
+            got = [y[0].cpu().numpy(), y[batch - 1].cpu().numpy()]
+            orc = O.OracleFft(n, np.complex64 if dtype == "f32" else np.complex128)
             t0 = time.perf_counter()
-            ob1.run(hx[:k1], O.FFT, out=ref1)
-            one_core_s = (time.perf_counter() - t0) / k1
-            err = float(np.linalg.norm(got.astype(np.complex128) - ref) / np.linalg.norm(ref))
-            out["parity"] = {"sample_transforms": sample, "rel_l2_vs_oracle": err,
-                             "tolerance": 1e-6 if args.dtype == "f32" else 5e-14}
-            out["cpu_baseline"] = {
-                "value": round(sample * flops_per / cpu_s / 1e9, 2), "unit": "GFLOP/s", "cores": used,
-                "host_threads_available": cores,
-                "threads_tried_gflops": {str(k): round(sample * flops_per / v / 1e9, 2) for k, v in tried.items()},
-                "kind": "port",
-                "sample": f"{sample} of the same transforms ({args.dtype} N=2^{args.log2n}, out-of-place), "
-                          f"one oracle plan per thread on {used} threads, {cpu_s:.2f} s wall",
-                "ms_per_transform_aggregate": round(cpu_s / sample * 1e3, 3),
-                "one_core": {"ms_per_transform": round(one_core_s * 1e3, 3), "value": round(flops_per / one_core_s / 1e9, 3),
-                             "unit": "GFLOP/s", "sample": f"{k1} transforms on 1 thread"},
-            }
+            refs = [orc.transform(k, O.FFT) for k in keep]
+            one_core_s = (time.perf_counter() - t0) / len(keep)
+            errs = [float(np.linalg.norm(g.astype(np.complex128) - r) / np.linalg.norm(r)) for g, r in zip(got, refs)]
+            out["parity"] = {"sample_transforms": 2, "rel_l2_vs_oracle": max(errs), "tolerance": 1e-6 if dtype == "f32" else 5e-14}
+            if world == 1:
+                out["cpu_baseline"] = {"value": round(flops_per / one_core_s / 1e9, 3), "unit": "GFLOP/s", "cores": 1, "kind": "port",
+                                       "sample": f"2 of the same transforms ({dtype} N={n}) on one core, {one_core_s * 1e3:.1f} ms each"}
+        elif hx is not None:
+            out["parity"], out["cpu_baseline"] = cpu_baseline(torch, plan, hx, n, dtype, dev, stream, cores)
+
+        if world == 1 and dist is None and args.config == "auto" and not args.no_other and args.batch is None and args.log2n is None:
+            # ---- the other BASELINE configs, a few seconds each, so that a driver-run record holds them too
+            del x, y
+            torch.cuda.empty_cache()
+            others = {}
+            for k in ("c3", "c4", "c5"):
+                try:
+                    others[k] = quick_config(fourier_amd, torch, dev, k)
+                except Exception as e:  # never lose the headline line to a secondary config
+                    others[k] = {"error": repr(e)}
+                    torch.cuda.empty_cache()
+            out["other_configs"] = others
         print(json.dumps(out), flush=True)
 
     if dist is not None:

@@ -514,3 +514,23 @@ def test_reserve_presizes_the_scratch_so_that_calls_do_not_allocate(fa):
         assert L.fourier_emu_alloc_count() == before, n
         assert np.array_equal(got, ref) and np.array_equal(got1, ref[:2])
     assert plan2.device == 0
+
+
+def test_device_sharded_driver_runs_every_shard_on_its_own_thread(fa, oracle):
+    """fourier_amd.shard.DeviceShardedFft (in-process form): one plan + one host thread per shard, the
+    global batch split with batch_shard.  The emulator has one device, so both shards name device 0."""
+    from fourier_amd import shard
+
+    n, gbatch = 1000, 11
+    x = hash_normal(31, gbatch * n).astype(np.complex64).reshape(gbatch, n)
+    y = np.empty_like(x)
+    drv = shard.DeviceShardedFft(n, "f32", [0, 0, 0])
+    ins, outs = [], []
+    for g in range(3):
+        lo, hi = shard.batch_shard(gbatch, 3, g)
+        ins.append((x[lo:hi].ctypes.data, hi - lo))
+        outs.append((y[lo:hi].ctypes.data, hi - lo))
+    drv.transform(ins, outs, fa.Transform.Fft)
+    assert rel_l2(y, oracle.transform_batch(x, oracle.FFT)) <= 2e-6
+    with pytest.raises(ValueError):
+        drv.transform(ins[:2], outs, fa.Transform.Fft)

@@ -371,3 +371,62 @@ extern "C" int mb_tile(const void* src, void* dst, uint64_t bytes, int transpose
   k_tile<<<blocks, 512, 0, (hipStream_t)stream>>>((const v4u*)src, (v4u*)dst, rowunits, transposed);
   return (int)hipGetLastError();
 }
+
+// ---- XCD-local exchange model: is an intermediate that round-trips through the XCD's OWN L2 free? ----
+// Persistent workgroups (512 threads, LDS-padded to 2 per CU like the pass kernels).  Per 128 KiB tile: stream the
+// tile in from A (nt), park it in a slot of THIS XCD's private ring (fp_bytes per XCD, so the eight rings together
+// are 8*fp), read back another slot of the SAME ring that a neighbouring workgroup of this XCD wrote a moment ago,
+// stream the tile out to B (nt).  No synchronisation (throughput model; the values read back are whatever is
+// there).  xshift != 0 reads the ring of XCD (x + xshift) % 8 instead: the cross-XCD control.
+// store_fl: 0 plain, 1 sc1 (write-through), 2 nt;  load_fl: 0 plain, 1 sc1 (L1 bypass), 2 nt
+__device__ __forceinline__ void st_fl(v4u* p, v4u v, int fl) {
+  if (fl == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  else if (fl == 2) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+__global__ void __launch_bounds__(512, 4) k_l2x(const v4u* __restrict__ A, v4u* __restrict__ B, v4u* __restrict__ S, unsigned* xcc_out,
+                                                uint64_t tiles, uint64_t fp_units, int mode, int store_fl, int load_fl, int xshift) {
+  extern __shared__ unsigned char pad_lds[];
+  const int tid = threadIdx.x;
+  const unsigned xcd = blockIdx.x % 8, slot = blockIdx.x / 8, wpx = gridDim.x / 8;
+  if (tid == 0) xcc_out[blockIdx.x] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID[3:0]
+  const uint64_t nslots = fp_units / 8192;  // 128 KiB slots in one XCD's ring
+  v4u* ring_w = S + (uint64_t)xcd * fp_units;
+  const v4u* ring_r = S + (uint64_t)((xcd + xshift) % 8) * fp_units;
+  uint64_t it = 0;
+  for (uint64_t t = blockIdx.x; t < tiles; t += gridDim.x, ++it) {
+    const v4u* a = A + t * 8192 + tid;
+    v4u v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = __builtin_nontemporal_load(a + r * 512);
+    const uint64_t sw = (it * wpx + slot) % nslots;
+    if (mode >= 1) {
+      v4u* s = ring_w + sw * 8192 + tid;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st_fl(s + r * 512, v[r], store_fl);
+    }
+    if (mode >= 2) {
+      // transposed read-back (the real kernel reads columns of what the team wrote): slot written ~nslots/2 tiles ago
+      const v4u* s2 = ring_r + ((sw + nslots / 2 + 1) % nslots) * 8192;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const v4u* p = s2 + ((tid & 7) + 8 * (((tid >> 3) + 64 * r) % 1024));
+        if (load_fl == 1) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[r]) : "v"(p) : "memory");
+        else if (load_fl == 2) v[r] = __builtin_nontemporal_load(p);
+        else v[r] = *p;
+      }
+      if (load_fl == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    v4u* b = B + t * 8192 + tid;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(v[r], b + r * 512);
+  }
+  (void)pad_lds;
+}
+extern "C" int mb_l2x(const void* A, void* B, void* S, void* xcc, uint64_t bytes, uint64_t fp_bytes_per_xcd, int mode, int store_fl,
+                      int load_fl, int xshift, int wgs_per_xcd, int lds_bytes, void* stream) {
+  hipFuncSetAttribute((const void*)k_l2x, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  k_l2x<<<8 * wgs_per_xcd, 512, lds_bytes, (hipStream_t)stream>>>((const v4u*)A, (v4u*)B, (v4u*)S, (unsigned*)xcc, bytes / (128 << 10),
+                                                                 fp_bytes_per_xcd / 16, mode, store_fl, load_fl, xshift);
+  return (int)hipGetLastError();
+}

@@ -59,6 +59,27 @@ def main():
     L.mb_fused_sync.argtypes = [vp, vp, vp, vp, u64, ci, ci, ci, vp]
     L.mb_fused_pipe.argtypes = [vp, vp, vp, vp, u64, ci, ci, ci, ci, vp]
     L.mb_tile_s.argtypes = [vp, vp, u64, u64, u64, ci, vp]
+    L.mb_l2x.argtypes = [vp, vp, vp, vp, u64, u64, ci, ci, ci, ci, ci, ci, vp]
+    if "--l2x" in sys.argv:
+        # XCD-local exchange model (round 2): does an intermediate that round-trips through the XCD's own L2 cost HBM time?
+        S = torch.empty(8 * (64 << 20), dtype=torch.uint8, device=dev)
+        xcc = torch.zeros(8 * 64 * 2, dtype=torch.int32, device=dev)
+        wpx = 64  # 2 workgroups per CU
+        t = timeit(lambda: L.mb_l2x(a.data_ptr(), b.data_ptr(), S.data_ptr(), xcc.data_ptr(), big, 1 << 20, 0, 0, 0, 0, wpx, 69632, st), reps=3, warm=1)
+        xs = xcc[:8 * wpx].cpu().numpy()
+        import numpy as _np
+        emit(tag="l2x", mode="copy_only", wgs_per_xcd=wpx, ms=round(t * 1e3, 3), alg_tbps=round(2 * big / t / 1e12, 3),
+             xcc_mismatch=int((xs != (_np.arange(len(xs)) % 8)).sum()))
+        for fp_kib in (256, 512, 1024, 2048, 3072, 4096, 8192, 16384, 65536):
+            for mode, mname in ((1, "copy+ring_write"), (2, "copy+ring_write+ring_read")):
+                for sfl, lfl, xshift in ((0, 0, 0), (0, 1, 0), (2, 1, 0), (1, 1, 0), (0, 1, 3), (1, 1, 3)):
+                    if mode == 1 and (lfl, xshift) != (0, 0) and not (sfl, lfl, xshift) in ((1, 1, 0), (2, 1, 0)):
+                        continue
+                    t = timeit(lambda: L.mb_l2x(a.data_ptr(), b.data_ptr(), S.data_ptr(), xcc.data_ptr(), big, fp_kib << 10, mode, sfl, lfl, xshift, wpx, 69632, st),
+                               reps=3, warm=1)
+                    emit(tag="l2x", mode=mname, ring_kib_per_xcd=fp_kib, store=("plain", "sc1", "nt")[sfl], load=("plain", "sc1", "nt")[lfl],
+                         read_from_xcd_plus=xshift, ms=round(t * 1e3, 3), alg_tbps=round(2 * big / t / 1e12, 3), us_per_8MiB=round(t / (big / (8 << 20)) * 1e6, 3))
+        return
     if "--stride" in sys.argv:
         nt = 1024  # transforms of 8 MiB payload
         for sru, dru in ((512, 512), (520, 512), (512, 520), (520, 520), (528, 528), (576, 576), (1024, 1024), (1032, 1032), (2048, 2048), (640, 640)):
