@@ -51,6 +51,13 @@ def lib():
             getattr(L, f"oracle_fourier_batch_run_{s}").argtypes = [vp, vp, vp, sz, ci]
         L.oracle_fourier_counts.restype = ci
         L.oracle_fourier_counts.argtypes = [sz, ctypes.POINTER(sz)]
+        L.oracle_fourier_table_len.restype = sz
+        L.oracle_fourier_table_len.argtypes = [sz]
+        L.oracle_fourier_radix_pass_double.restype = ci
+        L.oracle_fourier_radix_pass_double.argtypes = [ci, vp, vp, ci, sz, sz, ci]
+        L.oracle_fourier_set_clone.restype = ci
+        L.oracle_fourier_set_clone.argtypes = [ci]
+        L.oracle_fourier_have_avx.restype = ci
         _lib = L
     return _lib
 
@@ -136,3 +143,40 @@ def radix_counts(size):
     c = (ctypes.c_size_t * 5)()
     ok = lib().oracle_fourier_counts(size, c)
     return list(c) if ok else None
+
+
+def table_len(size):
+    """Entries of one direction's twiddle table (autosort/mod.rs:24-46), None if the size does not factor."""
+    if radix_counts(size) is None:
+        return None
+    return int(lib().oracle_fourier_table_len(size))
+
+
+# which clone of the reference's pass functions the oracle runs (process-wide):
+GENERIC, AVX_NO_FIRST_PASS, AVX = 0, 1, 2
+
+
+def set_clone(clone):
+    """0 = generic (scalar) functions, 1 = AVX clone without the hand-scheduled f32 first pass, 2 = AVX clone as the
+    reference runs it on an AVX host (default).  Results are bit-identical; only the speed differs.  Returns the clone
+    in effect (0 when the oracle was built without AVX)."""
+    return int(lib().oracle_fourier_set_clone(int(clone)))
+
+
+def have_avx():
+    return bool(lib().oracle_fourier_have_avx())
+
+
+def set_avx_first_pass(on):
+    """bench.py: time the port with (True: clone 2) and without (False: clone 0, scalar) the AVX clone."""
+    return set_clone(AVX if on else GENERIC)
+
+
+def radix_pass(radix, x, forward, size, stride, clone=GENERIC):
+    """One Stockham pass (autosort/mod.rs:203-284) of the restatement on a complex128 array of size*stride points."""
+    x = np.ascontiguousarray(x, dtype=np.complex128)
+    assert x.shape == (size * stride,)
+    out = np.empty_like(x)
+    ok = lib().oracle_fourier_radix_pass_double(radix, x.ctypes.data, out.ctypes.data, int(forward), size, stride, int(clone))
+    assert ok
+    return out

@@ -148,3 +148,89 @@ def test_batch_threads_match_single(oracle):
     assert np.array_equal(a, b)
     f = oracle.OracleFft(96, np.complex64)
     assert np.array_equal(a[4], f.transform(x[4], oracle.FFT))
+
+
+def test_twiddle_table_lengths_match_the_reference_layout(oracle):
+    """autosort/mod.rs:24-46: one direction's table holds size_cur entries per pass (m rows of `radix`).  SURVEY.md
+    section 3.2 derives 5 266 / 1 348 168 / 2 696 338 / 5 392 676 entries for N = 4096 / 2^20 / 2^21 / 2^22."""
+    assert oracle.table_len(4096) == 5266
+    assert oracle.table_len(1 << 20) == 1348168
+    assert oracle.table_len(1 << 21) == 2696338
+    assert oracle.table_len(1 << 22) == 5392676
+    assert oracle.table_len(1) == 0 and oracle.table_len(2) == 2 and oracle.table_len(6) == 6 + 2
+    assert oracle.table_len(999983) is None
+    for n in (12, 96, 243, 1000 * 0 + 972, 4096, 18432):  # independent count: sum of size_cur over the schedule
+        counts, cur, total = oracle.radix_counts(n), n, 0
+        for radix, c in zip((4, 8, 4, 3, 2), counts):
+            for _ in range(c):
+                total += cur
+                cur //= radix
+        assert oracle.table_len(n) == total and cur == 1, n
+
+
+def _numpy_stockham_pass(x, radix, size, stride, forward):
+    """Independent restatement of ONE pass, autosort/mod.rs:203-284, from its index formula:
+    out[j + R*s*i + s*k] = W_size^{i*k} * sum_k' omega_R^{k*k'} * in[j + s*i + s*m*k'],  i < m = size/R, j < s."""
+    m = size // radix
+    sgn = -1.0 if forward else 1.0
+    X = x.reshape(radix, m, stride)                                    # [k'][i][j]
+    kk = np.arange(radix)
+    omega = np.exp(sgn * 2j * np.pi * np.outer(kk, kk) / radix)        # DFT_R
+    Y = np.einsum("kq,qij->ikj", omega, X)                             # [i][k][j]
+    if size != radix:                                                  # mod.rs:238,272: no twiddle on the last pass
+        W = np.exp(sgn * 2j * np.pi * np.outer(np.arange(m), kk) / size)
+        Y = Y * W[:, :, None]
+    return Y.reshape(-1)
+
+
+@pytest.mark.parametrize("radix,size,stride", [(2, 2, 96), (2, 16, 3), (3, 9, 4), (3, 3, 32), (4, 64, 1), (4, 4, 8),
+                                               (8, 512, 1), (8, 64, 4), (8, 8, 16), (4, 16, 3), (8, 24 * 0 + 8, 5)])
+def test_one_pass_against_an_independent_numpy_restatement(oracle, radix, size, stride):
+    """Pass-by-pass pin of radix_pass (generic AND AVX clone, narrow and wide forms) against numpy in f64."""
+    x = hash_normal(1000 + radix * size + stride, size * stride)
+    for forward in (True, False):
+        want = _numpy_stockham_pass(x, radix, size, stride, forward)
+        for clone in (oracle.GENERIC, oracle.AVX):
+            got = oracle.radix_pass(radix, x, forward, size, stride, clone)
+            assert rel_l2(got, want) < 1e-14, (radix, size, stride, forward, clone)
+
+
+def test_avx_clone_is_bit_identical_to_the_generic_functions(oracle):
+    """vector/avx.rs + autosort/avx_optimization.rs:4-92 restated with intrinsics: same operations, same roundings.
+    Values must be equal for every size class (pure pow2 with the f32 radix-4 stride-1 first pass, odd first
+    passes, 2^a*3^b, Bluestein) in both precisions and directions."""
+    if not oracle.have_avx():
+        pytest.skip("oracle built without AVX")
+    sizes = [4, 8, 16, 32, 64, 128, 256, 1024, 4096, 1 << 15, 6, 12, 24, 48, 96, 243, 768, 972, 7, 100, 1000]
+    try:
+        for dtype in (np.complex64, np.complex128):
+            for n in sizes:
+                x = hash_normal(n, n).astype(dtype)
+                outs = []
+                for clone in (oracle.GENERIC, oracle.AVX_NO_FIRST_PASS, oracle.AVX):
+                    assert oracle.set_clone(clone) == clone
+                    f = oracle.OracleFft(n, dtype)
+                    outs.append((f.transform(x, oracle.FFT), f.transform(x, oracle.IFFT)))
+                for o in outs[1:]:
+                    assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]), (n, dtype)
+    finally:
+        oracle.set_clone(oracle.AVX)
+
+
+REF = "/root/reference"
+
+
+@pytest.mark.parametrize("src,cc,std", [("test.c", "gcc", "-std=c11"), ("test.cpp", "g++", "-std=c++14")])
+def test_reference_consumers_compile_unchanged_against_our_header(tmp_path, src, cc, std):
+    """The reference's own C and C++ consumers (fourier-ffi/test.c:7-46, test.cpp) must compile UNCHANGED against
+    include/fourier.h with the reference's warning flags as errors.  Compile-only (no GPU here); the files are read
+    where they lie -- nothing is copied into the repo.  Skipped where the reference tree does not exist (GPU box)."""
+    import subprocess
+
+    path = os.path.join(REF, "fourier-ffi", src)
+    if not os.path.exists(path):
+        pytest.skip("reference tree not present")
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    r = subprocess.run([cc, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, path],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
