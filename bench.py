@@ -188,16 +188,14 @@ def cpu_baseline(torch, plan, hx, n, dtype, dev, stream, cores):
         del ob
     used = min(tried, key=tried.get)
     cpu_s = tried[used]
-    # the reference itself is single-threaded (one plan, one slice per call): the same port on ONE core, with the
-    # reference's AVX first pass (radix_4_stride_1_avx_f32, avx_optimization.rs:4-92) and without it
+    # the reference itself is single-threaded (one plan, one slice per call): the same port on ONE core, as the
+    # reference's AVX clone (vector/avx.rs wide passes + radix_4_stride_1_avx_f32, what an AVX host runs; the
+    # multi-thread legs above use it too) and as the generic scalar functions (what round 1 timed)
     k1 = min(sample, 4)
     one = {}
-    for label, avx in (("avx_first_pass", True), ("scalar_first_pass", False)):
-        if not hasattr(O, "set_avx_first_pass"):
-            if not avx:
-                continue
-        else:
-            O.set_avx_first_pass(avx)
+    for label, clone in (("avx_clone", O.AVX), ("generic_scalar", O.GENERIC)):
+        if O.set_clone(clone) != clone:
+            continue
         ob1 = O.OracleBatch(n, hx.dtype, nthreads=1)
         ref1 = np.empty_like(hx[:k1])
         ob1.run(hx[:1], O.FFT, out=ref1[:1])
@@ -205,22 +203,21 @@ def cpu_baseline(torch, plan, hx, n, dtype, dev, stream, cores):
         ob1.run(hx[:k1], O.FFT, out=ref1)
         one[label] = (time.perf_counter() - t0) / k1
         del ob1
-    if hasattr(O, "set_avx_first_pass"):
-        O.set_avx_first_pass(True)
-    one_core_s = one["avx_first_pass"]
+    O.set_clone(O.AVX)
+    one_core_s = one.get("avx_clone", one["generic_scalar"])
     err = float(np.linalg.norm(got.astype(np.complex128) - ref) / np.linalg.norm(ref))
     parity = {"sample_transforms": sample, "rel_l2_vs_oracle": err, "tolerance": 1e-6 if dtype == "f32" else 5e-14}
     base = {
         "value": round(sample * flops_per / cpu_s / 1e9, 2), "unit": "GFLOP/s", "cores": used,
         "host_threads_available": cores,
         "threads_tried_gflops": {str(k): round(sample * flops_per / v / 1e9, 2) for k, v in tried.items()},
-        "kind": "port",
+        "kind": "port", "clone": "avx" if O.have_avx() else "generic",
         "sample": f"{sample} of the same transforms ({dtype} N={n}, out-of-place), "
                   f"one oracle plan per thread on {used} threads, {cpu_s:.2f} s wall",
         "ms_per_transform_aggregate": round(cpu_s / sample * 1e3, 3),
         "one_core": {"ms_per_transform": round(one_core_s * 1e3, 3), "value": round(flops_per / one_core_s / 1e9, 3),
                      "unit": "GFLOP/s", "sample": f"{k1} transforms on 1 thread",
-                     "ms_per_transform_by_first_pass": {k: round(v * 1e3, 3) for k, v in one.items()}},
+                     "ms_per_transform_by_clone": {k: round(v * 1e3, 3) for k, v in one.items()}},
     }
     return parity, base
 

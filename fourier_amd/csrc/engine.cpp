@@ -138,6 +138,7 @@ typedef void (*PassKernel)(PassArgs);
 struct KernelInfo {
   PassKernel fn = nullptr;
   int L = 0, CG = 0, NT = 0, COLS = 0, R3 = 0;
+  int split = 0;  // 1: two workgroups per tile (fft_last_split_kernel), grid = 2 x tiles
   size_t smem = 0;
 };
 
@@ -147,6 +148,16 @@ template <typename T, int L, int CG, int MODE, int IO = IO_PLAIN> static KernelI
   k.fn = &fft_pass_kernel<T, L, CG, MODE, IO>;
   k.L = L; k.CG = CG; k.NT = C::NT; k.COLS = C::COLS; k.R3 = C::R3;
   k.smem = C::smem_bytes(MODE);
+  return k;
+}
+
+// last pass of length L on half tiles: the register tile (and the thread count) of a length-L/2 pass
+template <typename T, int L, int CG, int IO = IO_PLAIN> static KernelInfo make_split_info() {
+  using C = TileCfg<T, L / 2, CG>;
+  KernelInfo k;
+  k.fn = &fft_last_split_kernel<T, L / 2, CG, IO>;
+  k.L = L; k.CG = CG; k.NT = C::NT; k.COLS = C::COLS; k.R3 = C::R3; k.split = 1;
+  k.smem = C::smem_bytes(MODE_LAST);
   return k;
 }
 
@@ -160,8 +171,22 @@ template <typename T, int L, int CG, int MODE, int IO = IO_PLAIN> static KernelI
 #ifndef FOURIER_CG_2048
 #define FOURIER_CG_2048 8
 #endif
+// L = 2048 holds a 256 KiB tile per workgroup at 16 columns -- one workgroup per CU, no overlap of its load and
+// compute phases.  Default plans therefore run the FIRST pass on 64-byte-wide tiles (8 columns, 128 KiB, two
+// workgroups per CU; the transposed store does not care about the tile width) and the LAST pass on half tiles
+// (fft_last_split_kernel).  FOURIER_WIDE_2048=1 in the environment at plan creation brings the 16-column kernels back (A/B).
+#ifndef FOURIER_CG_2048_FIRST
+#define FOURIER_CG_2048_FIRST 4
+#endif
 
 template <typename T> static KernelInfo get_kernel(int L, int mode, int io = IO_PLAIN) {
+  if (L == 2048 && !getenv("FOURIER_WIDE_2048")) {
+    if (mode == MODE_FIRST)
+      return io == IO_BLU_IN ? make_info<T, 2048, FOURIER_CG_2048_FIRST, MODE_FIRST, IO_BLU_IN>()
+                             : make_info<T, 2048, FOURIER_CG_2048_FIRST, MODE_FIRST>();
+    if (mode == MODE_LAST)
+      return io == IO_BLU_OUT ? make_split_info<T, 2048, FOURIER_CG_1024, IO_BLU_OUT>() : make_split_info<T, 2048, FOURIER_CG_1024>();
+  }
 #define FK(LL, CGG)                                                                              \
   case LL:                                                                                       \
     switch (mode) {                                                                              \
@@ -275,6 +300,42 @@ template <typename T> static bool get_blu_small_kernel(int k, KernelInfo& info) 
   }
 }
 
+// fft_l2fused_kernel: both passes of an N = L1 x L2 plan in one launch, intermediate in the XCD's L2
+typedef void (*FusedKernel)(FusedArgs);
+struct FusedInfo {
+  FusedKernel fn = nullptr;
+  int L1 = 0, L2 = 0, NT = 0, COLS_A = 0, COLS_B = 0;
+  size_t smem = 0;
+};
+template <typename T, int L1, int CG1, int L2, int CG2> static FusedInfo make_fused_info() {
+  using CA = TileCfg<T, L1, CG1>;
+  using CB = TileCfg<T, L2, CG2>;
+  FusedInfo k;
+  k.fn = &fft_l2fused_kernel<T, L1, CG1, L2, CG2>;
+  k.L1 = L1; k.L2 = L2; k.NT = CA::NT; k.COLS_A = CA::COLS; k.COLS_B = CB::COLS;
+  const size_t sa = CA::smem_bytes(MODE_FIRST), sb = CB::smem_bytes(MODE_LAST);
+  k.smem = (((sa > sb ? sa : sb) + 15) & ~(size_t)15) + 16;  // + the broadcast slot
+  return k;
+}
+// N * sizeof(complex) <= 2 MiB and two passes: f32 2^16 .. 2^18, f64 2^15 .. 2^17 (64 KiB tiles, 256 threads)
+template <typename T> static bool get_fused_kernel(int k, FusedInfo& info) {
+  if constexpr (sizeof(T) == 4) {
+    switch (k) {
+      case 16: info = make_fused_info<T, 256, 16, 256, 16>(); return true;
+      case 17: info = make_fused_info<T, 512, 8, 256, 16>(); return true;
+      case 18: info = make_fused_info<T, 512, 8, 512, 8>(); return true;
+      default: return false;
+    }
+  } else {
+    switch (k) {
+      case 15: info = make_fused_info<T, 256, 16, 128, 32>(); return true;
+      case 16: info = make_fused_info<T, 256, 16, 256, 16>(); return true;
+      case 17: info = make_fused_info<T, 512, 8, 256, 16>(); return true;
+      default: return false;
+    }
+  }
+}
+
 enum { MODE_ODD_LAST = 5 };  // host-side tag for odd_last_kernel (final radix-3^b pass of a 2^a*3^b plan)
 typedef void (*OddKernel)(OddArgs);
 template <typename T> static OddKernel get_odd_kernel(int r) {
@@ -342,7 +403,7 @@ template <typename T> class Pow2Engine {
     int odd_r = 0;
     uint64_t s, size, cn;
     uint32_t lo_bits = 0;
-    DevBuf tw_lo, tw_hi;
+    DevBuf tw_lo, tw_hi, tw_half;  // tw_half: split last pass, W_L^{n} for n < L/2, laid out [Q*r + th]
     StageTables<T>* st = nullptr;
   };
 
@@ -422,19 +483,26 @@ template <typename T> class Pow2Engine {
         if (extent % (uint64_t)pass->k.COLS != 0)
           throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "tile does not divide pass extent");
       }
-      auto it = stage_.find(L);
+      const int Lt = pass->k.split ? L / 2 : L;  // length of the in-tile FFT (a split pass runs a half-length tile)
+      auto it = stage_.find(Lt);
       if (it == stage_.end()) {
         auto st = std::unique_ptr<StageTables<T>>(new StageTables<T>());
-        make_stage_tables<T>(L, *st);
-        it = stage_.emplace(L, std::move(st)).first;
+        make_stage_tables<T>(Lt, *st);
+        it = stage_.emplace(Lt, std::move(st)).first;
       }
       pass->st = it->second.get();
+      if (pass->k.split) {
+        std::vector<cpx<T>> wh((size_t)Lt);
+        for (int nn = 0; nn < Lt; ++nn) { double re, im; unit_root((uint64_t)nn, (uint64_t)L, re, im); wh[(size_t)nn] = {(T)re, (T)im}; }
+        pass->tw_half.upload(wh);
+      }
       if (pass->mode == MODE_FIRST || pass->mode == MODE_MID) make_two_level(*pass, size);
       set_smem_attribute(pass->k);
       passes_.push_back(std::move(pass));
       s *= (uint64_t)L;
       size /= (uint64_t)L;
     }
+    if (p3 == 1 && lens.size() == 2 && !mirror) init_l2fused(k);
     if (p3 > 1) {  // final odd-radix pass: size == R == p3, stride s == 2^a
       auto pass = std::unique_ptr<Pass>(new Pass());
       pass->mode = MODE_ODD_LAST;
@@ -507,6 +575,71 @@ template <typename T> class Pow2Engine {
     PROF_END(prof);
   }
 
+  // ---- XCD-fused two-pass plan (fft_l2fused_kernel): opt-in via the plan option "l2_fused"
+  void init_l2fused(int k) {
+    FusedInfo fi;
+    if (!get_fused_kernel<T>(k, fi)) return;
+    if (passes_.size() != 2 || passes_[0]->k.L != fi.L1 || passes_[1]->k.L != fi.L2) return;
+    if ((n_ / fi.L1) % (size_t)fi.COLS_A != 0 || (size_t)fi.L1 % (size_t)fi.COLS_B != 0) return;
+    fused_ = fi;
+#ifndef FOURIER_EMU
+    if (fused_.smem > 48 * 1024)
+      HIP_CHECK(hipFuncSetAttribute((const void*)fused_.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_.smem));
+#endif
+    int per_cu = 0, cus = 0, dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_.fn, fused_.NT, fused_.smem));
+    HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    fused_grid_ = (unsigned)std::max(1, per_cu) * (unsigned)std::max(1, cus);  // persistent: every workgroup resident
+    const size_t bytes = n_ * sizeof(cpx<T>);
+    fused_depth_ = bytes <= (512u << 10) ? 3 : 2;  // windows per XCD: <= 2 MiB of the 4 MiB L2 (profiles/r02_membench.jsonl, l2x)
+    if (const char* e = getenv("FOURIER_L2_FUSED")) fused_on_ = atoi(e) != 0;
+  }
+  bool has_l2fused() const { return fused_.fn != nullptr; }
+  bool l2fused_enabled() const { return fused_on_ && fused_.fn; }
+  void set_l2fused(bool on) { fused_on_ = on && fused_.fn; }
+  bool set_l2fused_depth(unsigned d) {
+    if (!fused_.fn || d < 1 || d > 8) return false;
+    fused_depth_ = d;
+    fused_window_.release();
+    return true;
+  }
+  void set_l2fused_grid(unsigned g) { if (g) fused_grid_ = g; }
+  static constexpr size_t FUSED_MAX_BATCH = 16384;  // transforms per launch (sizes the zeroed control block)
+  // pre-size the window and control block (fourier_hip_reserve_*): launches then never allocate
+  void reserve_l2fused(size_t batch) const {
+    if (!l2fused_enabled()) return;
+    fused_window_.ensure((size_t)FUSED_XCC_IDS * fused_depth_ * n_ * sizeof(cpx<T>));
+    fused_ctrl_.ensure(fused_ctrl_words(std::min(batch, FUSED_MAX_BATCH)) * sizeof(uint32_t));
+  }
+  void run_l2fused(const cpx<T>* in, cpx<T>* out, size_t batch, bool inverse, double scale, hipStream_t stream, Profiler* prof,
+                   int slot) const {
+    reserve_l2fused(batch);
+    const Pass& pa = *passes_[0];
+    const Pass& pb = *passes_[1];
+    FusedArgs f;
+    std::memset(&f, 0, sizeof(f));
+    f.a.tw1 = pa.st->tw1.p; f.a.tw2 = pa.st->tw2.p; f.a.tw_lo = pa.tw_lo.p; f.a.tw_hi = pa.tw_hi.p; f.a.lo_bits = pa.lo_bits;
+    f.a.n = n_; f.a.cn = pa.cn; f.a.s = pa.s; f.a.tiles = pa.cn / fused_.COLS_A; f.a.swap_in = inverse; f.a.scale = 1.0;
+    f.b.tw1 = pb.st->tw1.p; f.b.tw2 = pb.st->tw2.p;
+    f.b.n = n_; f.b.cn = pb.cn; f.b.s = pb.s; f.b.tiles = pb.cn / fused_.COLS_B; f.b.swap_out = inverse; f.b.scale = scale;
+    f.window = fused_window_.p;
+    f.ctrl = (uint32_t*)fused_ctrl_.p;
+    f.depth = fused_depth_;
+    f.tiles_a = (uint32_t)f.a.tiles; f.tiles_b = (uint32_t)f.b.tiles;
+    f.spin_limit = 1u << 21;
+    for (size_t b0 = 0; b0 < batch; b0 += FUSED_MAX_BATCH) {
+      const size_t nb = std::min(FUSED_MAX_BATCH, batch - b0);
+      f.in = in + b0 * n_; f.out = out + b0 * n_; f.batch = (uint32_t)nb;
+      HIP_CHECK(hipMemsetAsync(fused_ctrl_.p, 0, fused_ctrl_words(nb) * sizeof(uint32_t), stream));
+      const uint64_t items = (uint64_t)nb * (f.tiles_a + f.tiles_b);
+      const unsigned grid = (unsigned)std::min<uint64_t>(fused_grid_, items);
+      PROF_BEGIN(prof, slot);
+      FOURIER_LAUNCH(fused_.fn, grid, fused_.NT, fused_.smem, stream, f);
+      PROF_END(prof);
+    }
+  }
+
   // Bluestein fusion is available when the plan has separate first and last passes.
   bool can_fuse_bluestein() const { return !tiny_ && passes_.size() >= 2; }
   void enable_bluestein_fusion() {
@@ -525,11 +658,18 @@ template <typename T> class Pow2Engine {
 
   size_t size() const { return n_; }
   size_t num_passes() const { return tiny_ ? 1 : passes_.size(); }
-  bool needs_scratch(bool in_place) const { return passes_.size() >= 3 || (passes_.size() == 2 && in_place); }
+  // a split last pass cannot run in place: two workgroups read the whole column tile and each writes half of its rows
+  bool last_is_split() const { return !passes_.empty() && passes_.back()->k.split != 0; }
+  size_t hbm_round_trips() const { return l2fused_enabled() ? 1 : num_passes(); }
+  bool needs_scratch(bool in_place) const {
+    if (l2fused_enabled()) return false;  // a transform is read completely before any of it is written
+    return passes_.size() >= 3 || (passes_.size() == 2 && (in_place || last_is_split()));
+  }
   std::string describe() const {
     if (tiny_ || n_ == 16 || (n_ == 32 && sizeof(T) == 4)) return "tiny(" + std::to_string(n_) + ")";
     if (!desc_override_.empty()) return desc_override_;
     std::string d;
+    if (l2fused_enabled()) return std::to_string(fused_.L1) + "x" + std::to_string(fused_.L2) + " one-launch xcd-l2";
     for (size_t p = 0; p < passes_.size(); ++p)
       d += (p ? "x" : "") + std::to_string(passes_[p]->mode == MODE_ODD_LAST ? passes_[p]->odd_r : passes_[p]->k.L);
     return d;
@@ -564,6 +704,10 @@ template <typename T> class Pow2Engine {
       PROF_END(prof);
       return;
     }
+    if (l2fused_enabled() && blu.io == IO_PLAIN && !mul) {
+      run_l2fused(in, out, batch, inverse, scale, stream, prof, slot0);
+      return;
+    }
     const size_t np = passes_.size();
     const bool in_place = ((const void*)in == (const void*)out);
     // Every pass but the last is out of place (its tile footprints differ between input and output); the
@@ -573,7 +717,7 @@ template <typename T> class Pow2Engine {
     cpx<T>* dst[8] = {out};
     if (np > 8) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "too many passes");
     if (np >= 2) {
-      const bool start_scratch = in_place || blu.io == IO_BLU_OUT || (force_scratch && np == 2);
+      const bool start_scratch = in_place || blu.io == IO_BLU_OUT || (force_scratch && np == 2) || (np == 2 && last_is_split());
       for (size_t p = 0; p + 1 < np; ++p) {
         const bool to_scratch = start_scratch ? (p % 2 == 0) : (p % 2 == 1);
         dst[p] = to_scratch ? scratch : out;
@@ -614,7 +758,7 @@ template <typename T> class Pow2Engine {
       a.in = src; a.out = dst;
       a.tw1 = ps.st->tw1.p; a.tw2 = ps.st->tw2.p;
       if (ps.mode == MODE_TWOLEVEL) a.tw2 = ps.st2->tw1.p;
-      a.tw_lo = ps.tw_lo.p; a.tw_hi = ps.tw_hi.p;
+      a.tw_lo = ps.tw_lo.p; a.tw_hi = ps.tw_hi.p; a.tw_half = ps.tw_half.p;
       a.mul = (p + 1 == np) ? mul : nullptr;
       a.n = n_; a.cn = ps.cn; a.s = ps.s;
       a.lo_bits = ps.lo_bits;
@@ -636,8 +780,8 @@ template <typename T> class Pow2Engine {
         a.tiles = 1;
         grid = (batch + ps.k.COLS - 1) / ps.k.COLS;
       } else {
-        a.tiles = ps.cn / ps.k.COLS;
-        grid = (uint64_t)batch * a.tiles;
+        a.tiles = ps.cn / kk.COLS;
+        grid = (uint64_t)batch * a.tiles * (kk.split ? 2 : 1);
       }
       if (grid > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");
       PROF_BEGIN(prof, slot);
@@ -653,6 +797,13 @@ template <typename T> class Pow2Engine {
     if (!can_conv()) return;
     conv_ = get_conv_kernel<T>(passes_.back()->k.L);
     set_smem_attribute(conv_);
+    auto it = stage_.find(conv_.L);  // the last pass may run on half tiles with half-length stage tables
+    if (it == stage_.end()) {
+      auto st = std::unique_ptr<StageTables<T>>(new StageTables<T>());
+      make_stage_tables<T>(conv_.L, *st);
+      it = stage_.emplace(conv_.L, std::move(st)).first;
+    }
+    conv_st_ = it->second.get();
   }
   bool palindromic() const {
     for (size_t p = 0; p < passes_.size(); ++p)
@@ -666,7 +817,7 @@ template <typename T> class Pow2Engine {
     PassArgs a;
     std::memset(&a, 0, sizeof(a));
     a.in = src; a.out = dst;
-    a.tw1 = last.st->tw1.p; a.tw2 = last.st->tw2.p;
+    a.tw1 = conv_st_->tw1.p; a.tw2 = conv_st_->tw2.p;
     a.tw_lo = first.tw_lo.p; a.tw_hi = first.tw_hi.p; a.lo_bits = first.lo_bits;  // W_M^e, the table of any first pass
     a.mul = wtab;
     a.n = n_; a.cn = last.cn; a.s = last.s;
@@ -686,6 +837,11 @@ template <typename T> class Pow2Engine {
   bool tiny_ = false;
   int tl1_ = 0, tl2_ = 0;   // pass lengths of a one-launch (MODE_TWOLEVEL) plan
   KernelInfo blu_small_, conv_;
+  StageTables<T>* conv_st_ = nullptr;
+  FusedInfo fused_;
+  bool fused_on_ = false;
+  unsigned fused_grid_ = 0, fused_depth_ = 2;
+  mutable DevBuf fused_window_, fused_ctrl_;
   std::string desc_override_;
   std::vector<std::unique_ptr<Pass>> passes_;
   std::map<int, std::unique_ptr<StageTables<T>>> stage_;
@@ -847,19 +1003,21 @@ template <typename T> class Plan {
     DeviceGuard g(device_);
     if (is_pow2(n)) {
       eng_.reset(new Pow2Engine<T>(n));
-      desc_ = "stockham " + eng_->describe();
     } else if (Pow2Engine<T>::handles_mixed(n)) {
       // big-radix passes over the 2^a part (a >= 12), then a radix-3^b pass: three HBM round trips at full tile
       // efficiency beat the one-workgroup-per-CU LDS kernel where both apply (3*2^12 f32: 23 % vs 14 %)
       eng_.reset(new Pow2Engine<T>(n));
-      desc_ = "stockham " + eng_->describe();
     } else if (MixedEngine<T>::handles(n)) {
       mix_.reset(new MixedEngine<T>(n));
-      desc_ = "stockham mixed-radix " + mix_->describe();
     } else {
       init_bluestein();
-      desc_ = "bluestein M=" + std::to_string(m_) + " inner " + eng_->describe() + (small_fused_ ? " fused" : "");
     }
+    refresh_desc();
+  }
+  void refresh_desc() {
+    if (mix_) desc_ = "stockham mixed-radix " + mix_->describe();
+    else if (blu_) desc_ = "bluestein M=" + std::to_string(m_) + " inner " + eng_->describe() + (small_fused_ ? " fused" : "");
+    else desc_ = "stockham " + eng_->describe();
     desc_ += sizeof(T) == 4 ? " f32" : " f64";
   }
 
@@ -883,7 +1041,7 @@ template <typename T> class Plan {
     std::string d;
     if (mix_) return "mixed_radix";
     auto passes = [&](const char* tag) {
-      for (size_t p = 0; p < eng_->num_passes(); ++p) d += std::string(d.empty() ? "" : ",") + tag + std::to_string(p);
+      for (size_t p = 0; p < (blu_ ? eng_->num_passes() : eng_->hbm_round_trips()); ++p) d += std::string(d.empty() ? "" : ",") + tag + std::to_string(p);
     };
     if (!blu_) { passes("pass"); return d; }
     if (small_fused_) return "bluestein_one_launch";
@@ -897,7 +1055,7 @@ template <typename T> class Plan {
 
   double model_bytes() const {
     if (mix_) return 2.0 * n_ * ELEM;
-    if (!blu_) return 2.0 * n_ * ELEM * eng_->num_passes();
+    if (!blu_) return 2.0 * n_ * ELEM * eng_->hbm_round_trips();
     // unfused: pre (n + table read, m write) + 2 inner FFTs + w table + post (n + table read, n write);
     // fused: the first / last inner pass read / write the n-point user array instead of an m-point sweep
     if (small_fused_) return (double)ELEM * 2.0 * n_;  // tables stay L2-resident
@@ -918,6 +1076,15 @@ template <typename T> class Plan {
     }
     if (key == "bluestein_conv" && (v == 0 || v == 1)) { conv_ = (v == 1) && conv_ok_; return 0; }
     if (key == "host_chunk_bytes" && v > 0) { host_chunk_bytes_ = (size_t)v; return 0; }
+    // both passes in one launch with the intermediate in the XCD's L2 (2^16..2^18 f32, 2^15..2^17 f64); 0 where unavailable
+    if (key == "l2_fused" && (v == 0 || v == 1)) {
+      if (blu_ || !eng_ || (v == 1 && !eng_->has_l2fused())) return ::fourier::c::FOURIER_HIP_INVALID_ARGUMENT;
+      eng_->set_l2fused(v == 1);
+      refresh_desc();
+      return 0;
+    }
+    if (key == "l2_fused_depth" && !blu_ && eng_ && eng_->set_l2fused_depth((unsigned)v)) return 0;
+    if (key == "l2_fused_grid" && !blu_ && eng_ && eng_->has_l2fused() && v > 0) { eng_->set_l2fused_grid((unsigned)v); return 0; }
     return ::fourier::c::FOURIER_HIP_INVALID_ARGUMENT;
   }
 
@@ -947,6 +1114,7 @@ template <typename T> class Plan {
       }
     };
     if (!blu_) {
+      if (eng_->l2fused_enabled()) { eng_->reserve_l2fused(chunk); return chunk; }
       const bool need = eng_->needs_scratch(in_place) || (force_scratch_ && eng_->num_passes() >= 2);
       if (need) reserve([&](size_t c) { scratch_.ensure(c * n_ * ELEM); });
       return chunk;

@@ -32,6 +32,8 @@
 
 #ifdef FOURIER_EMU
 #define FOURIER_SCHED_FENCE()
+#define FOURIER_WAIT_VMEM()
+#define FOURIER_LAUNDER(v)
 #define FOURIER_DYN_SMEM(name) unsigned char* name = hipemu::smem()
 #define LDS_NOTE(p, bytes, w, site) hipemu::lds_note((p), (bytes), (w), (site))
 #else
@@ -39,6 +41,11 @@
 // stops hipcc from hoisting a whole block of table loads above the arithmetic that consumes them
 // (it otherwise keeps all 16 twiddle units live at once and spills under the 128-VGPR budget)
 #define FOURIER_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// every global access this wave has issued (loads AND stores: gfx9 counts both on vmcnt) has completed at the L2
+#define FOURIER_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// hides a per-lane value from the optimiser: inside a persistent loop it keeps everything derived from the value from
+// being hoisted out of the loop (and spilled there) -- a few VALU instructions per iteration instead
+#define FOURIER_LAUNDER(v) asm volatile("" : "+v"(v))
 #define FOURIER_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #define LDS_NOTE(p, bytes, w, site)
 #endif
@@ -109,6 +116,22 @@ template <typename T, bool NT> __device__ __forceinline__ void store_unit(void* 
 #endif
 }
 
+// Cache policy of a pass's data accesses.  POL_SC1 (loads only) = `buffer_load_dwordx4 ... sc1`: bypasses this CU's L1 and
+// is served by the XCD's L2 -- how a workgroup reads what ANOTHER workgroup of the same XCD stored a moment ago (the
+// L2 is the coherence point of an XCD; a CU's L1 is never refreshed by other CUs' stores, MI355X_MICROARCH.md).
+enum { POL_PLAIN = 0, POL_NT = 1, POL_SC1 = 2 };
+// 16-byte load at byte offset `off` (< 4 GiB) of a buffer descriptor built over a wave-uniform base pointer
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+__device__ __forceinline__ BufRsrc make_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+}
+template <typename T> __device__ __forceinline__ Unit16<T> load_unit_sc1(BufRsrc r, uint32_t off) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, /*aux: sc1*/ 16);
+  Unit16<T> u;
+  __builtin_memcpy(&u, &v, 16);
+  return u;
+}
+
 // one complex element (8 / 16 bytes), optionally non-temporal
 template <typename T, bool NT> __device__ __forceinline__ void store_elem(cpx<T>* p, const cpx<T>& y) {
 #ifndef FOURIER_EMU
@@ -158,6 +181,7 @@ struct PassArgs {
   const void* tw2;    // [R3][16] W_Q^{i*k}             (stage-2 twiddles, only when R3 > 1)
   const void* tw_lo;  // W_size^{e},          e < 2^lo_bits     } two-level table of the
   const void* tw_hi;  // W_size^{h<<lo_bits}, h < size>>lo_bits } inter-pass twiddle W_size^{i*k}
+  const void* tw_half;  // split tiles: W_2L^{n}, n < L (the radix-2 decimation-in-frequency twiddle in front of a length-L tile)
   const void* mul;    // optional pointwise multiplier applied on store, indexed by output index
   uint64_t n;         // elements per transform (batch stride)
   uint64_t cn;        // columns of this pass = n / L
@@ -480,19 +504,31 @@ __device__ __forceinline__ void tile_core(RegTile<T, L, CG>& x, int& th, int& cg
   }
 }
 
-template <typename T, int L, int CG, int MODE, int IO = IO_PLAIN>
-__global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG)) fft_pass_kernel(PassArgs a) {
+// The body of a pass: one tile (block index `blk0` of `nblk`) of one big-radix Stockham pass.  LDPOL / STPOL = cache
+// policy of the data loads / stores (POL_*): the stand-alone pass kernels stream (non-temporal), the XCD-fused kernel
+// parks its intermediate in the L2 (plain stores, sc1 loads).
+//
+// SPLIT = 1 (MODE_LAST only): the pass has length 2L and TWO workgroups share one column tile.  Decimation in frequency:
+// X[2k'+p] = DFT_L( (x[n] + (-1)^p x[n+L]) * W_2L^{p*n} )_k', so workgroup p (= block parity) loads all 2L rows, keeps
+// the sums (p = 0) or the twiddled differences (p = 1) -- L points per column, the register tile of a length-L pass --
+// and produces the even or odd output rows.  A 2048-point pass then runs as two 512-thread workgroups with a 128 KiB
+// tile each (two per CU, load and compute phases overlap) instead of one 1024-thread workgroup whose 256 KiB tile
+// fills the CU's registers; the tile is read twice, the second time from the XCD's L2 (the two workgroups are adjacent
+// blocks of one XCD), written once.
+template <typename T, int L, int CG, int MODE, int IO, int LDPOL, int STPOL, int SPLIT = 0>
+__device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint64_t nblk, unsigned char* smem, const int tid) {
   static_assert(IO == IO_PLAIN || (IO == IO_BLU_IN && MODE == MODE_FIRST) || (IO == IO_BLU_OUT && MODE == MODE_LAST),
                 "Bluestein fusion: chirp-in on the first pass, chirp-out on the last pass");
+  static_assert(SPLIT == 0 || (MODE == MODE_LAST && LDPOL != POL_SC1), "split tiles: last pass only");
+  constexpr int KM = SPLIT ? 2 : 1;  // output rows (and the pass length) are KM times what the register tile holds
   using C = TileCfg<T, L, CG>;
   constexpr int VEC = C::VEC, Q = C::Q, R2 = C::R2, R3 = C::R3, COLS = C::COLS;
   constexpr bool IN_ROWS = (MODE == MODE_ROWS);
   constexpr bool OUT_ROWS = (MODE == MODE_FIRST || MODE == MODE_ROWS);
   constexpr bool TWIDDLED = (MODE == MODE_FIRST || MODE == MODE_MID);
   constexpr bool FINAL = (MODE == MODE_LAST || MODE == MODE_ROWS);
-  FOURIER_DYN_SMEM(smem);
+  (void)R2; (void)R3;
 
-  const int tid = (int)threadIdx.x;
   // cg-fastest mapping ("A") for column-tile I/O, th-fastest ("B") for row-contiguous I/O
   int th = IN_ROWS ? tid % Q : tid / CG;
   int cg = IN_ROWS ? tid / Q : tid % CG;
@@ -502,7 +538,9 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
   // contiguous range of tiles (= whole transforms): each 2 MiB page and each DRAM row is then
   // touched by one XCD's L2/TLB instead of all eight (+11..16% on the strided tile pattern, measured
   // with tools/membench.py --xcd).  Bijective for any grid size; affects speed only.
-  const uint64_t blk = xcd_remap(a, blockIdx.x, gridDim.x);
+  uint64_t blk = xcd_remap(a, blk0, nblk);
+  const int par = SPLIT ? (int)(blk & 1) : 0;
+  if constexpr (SPLIT) blk >>= 1;
   const cpx<T>* __restrict__ in = (const cpx<T>*)a.in;
   cpx<T>* __restrict__ out = (cpx<T>*)a.out;
   uint64_t b = 0, c0 = 0, g0 = 0;
@@ -567,11 +605,45 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
         x[v][r] = val;
       }
     }
+  } else if constexpr (SPLIT) {
+    // rows n and n + L of the 2L-row tile; plain loads: the sibling workgroup's copy of each line comes from the L2
+    const cpx<T>* p = in + b * a.n + (uint64_t)th * a.cn + c0 + (uint64_t)(cg * VEC);
+    const cpx<T>* wh = (const cpx<T>*)a.tw_half + th;  // W_2L^{th + Q*r} at [Q*r + th]
+#pragma unroll
+    for (int r0 = 0; r0 < 16; r0 += 4) {
+      Unit16<T> u0[4], u1[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        u0[q] = load_unit<T, LDPOL == POL_NT>(p + (uint64_t)(Q * (r0 + q)) * a.cn);
+        u1[q] = load_unit<T, LDPOL == POL_NT>(p + (uint64_t)(Q * (r0 + q) + L) * a.cn);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const cpx<T> w = wh[Q * (r0 + q)];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const cpx<T> lo{u0[q].a[2 * v], u0[q].a[2 * v + 1]}, hi{u1[q].a[2 * v], u1[q].a[2 * v + 1]};
+          x[v][r0 + q] = par ? cmul(cpx<T>{lo.re - hi.re, lo.im - hi.im}, w) : cpx<T>{lo.re + hi.re, lo.im + hi.im};
+        }
+      }
+      FOURIER_SCHED_FENCE();
+    }
+  } else if constexpr (LDPOL == POL_SC1) {
+    // L2-served loads of an intermediate another workgroup of this XCD has just written (b == 0: `in` is one transform)
+    const BufRsrc rs = make_rsrc(in);
+    const uint32_t off = (uint32_t)(((uint64_t)th * a.cn + c0 + (uint64_t)(cg * VEC)) * sizeof(cpx<T>));
+    const uint32_t rowb = (uint32_t)((uint64_t)Q * a.cn * sizeof(cpx<T>));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const Unit16<T> u = load_unit_sc1<T>(rs, off + (uint32_t)r * rowb);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
+    }
   } else {
     const cpx<T>* p = in + b * a.n + (uint64_t)th * a.cn + c0 + (uint64_t)(cg * VEC);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const Unit16<T> u = load_unit<T, (MODE == MODE_FIRST && FOURIER_NT_LOAD != 0) || FOURIER_NT_LOAD == 2>(p + (uint64_t)(Q * r) * a.cn);
+      const Unit16<T> u = load_unit<T, LDPOL == POL_NT>(p + (uint64_t)(Q * r) * a.cn);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
     }
@@ -618,20 +690,18 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
           if (a.swap_out) y = {y.im, y.re};
           y = {y.re * scale, y.im * scale};
         }
-        // MODE_ROWS: a wave's element stores only form whole lines for L >= 256; below that they rely on L2
-        // write-combining and a non-temporal hint is a 2-6x loss (N = 16..64, r01 session 9)
-        store_elem<T, (MODE == MODE_ROWS ? (FOURIER_NT_STORE != 0 && L >= 256) : (FOURIER_NT_STORE == 2 && L <= 1024))>(p + Q * r, y);
+        store_elem<T, STPOL == POL_NT>(p + Q * r, y);
       }
     }
   } else if constexpr (IO == IO_BLU_OUT) {
     // out = work (.) x (.) scale, first blu_n points only (bluesteins.rs:240-258)
     const cpx<T>* xt = (const cpx<T>*)a.blu_x;
     const uint64_t i = c0 / a.s, j0 = c0 % a.s;
-    const uint64_t off = j0 + (uint64_t)(cg * VEC) + a.s * ((uint64_t)L * i + (uint64_t)th);
+    const uint64_t off = j0 + (uint64_t)(cg * VEC) + a.s * ((uint64_t)(KM * L) * i + (uint64_t)(KM * th + par));
     cpx<T>* p = out + b * a.blu_n;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const uint64_t idx0 = off + a.s * (uint64_t)(Q * r);
+      const uint64_t idx0 = off + a.s * (uint64_t)(KM * Q * r);
       if (idx0 + VEC <= a.blu_n) {
         const Unit16<T> c = load_unit<T, false>(xt + idx0);
         Unit16<T> u;
@@ -660,7 +730,7 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
     }
   } else {
     const uint64_t i = c0 / a.s, j0 = c0 % a.s;
-    const uint64_t off = j0 + (uint64_t)(cg * VEC) + a.s * ((uint64_t)L * i + (uint64_t)th);
+    const uint64_t off = j0 + (uint64_t)(cg * VEC) + a.s * ((uint64_t)(KM * L) * i + (uint64_t)(KM * th + par));
     cpx<T>* p = out + b * a.n + off;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -669,13 +739,180 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
       for (int v = 0; v < VEC; ++v) {
         cpx<T> y = x[v][r];
         if constexpr (FINAL) {
-          if (mul) y = cmul(y, mul[off + a.s * (uint64_t)(Q * r) + v]);
+          if (mul) y = cmul(y, mul[off + a.s * (uint64_t)(KM * Q * r) + v]);
           if (a.swap_out) y = {y.im, y.re};
           y = {y.re * scale, y.im * scale};
         }
         u.a[2 * v] = y.re; u.a[2 * v + 1] = y.im;
       }
-      store_unit<T, (FINAL ? FOURIER_NT_STORE != 0 : (FOURIER_NT_STORE == 2 && L <= 1024))>(p + a.s * (uint64_t)(Q * r), u);
+      store_unit<T, STPOL == POL_NT>(p + a.s * (uint64_t)(KM * Q * r), u);
+    }
+  }
+}
+
+// default cache policy of the stand-alone pass kernels (see the FOURIER_NT_* notes at the top of this file)
+template <int L, int MODE, int CG = 8> struct PassPolicy {
+  static constexpr bool FINAL = (MODE == MODE_LAST || MODE == MODE_ROWS);
+  // 64-byte-wide tiles (CG = 4): two workgroups share every 128-byte line, the second one must find it in the L2, so
+  // no streaming hint (L = 2048 first pass: 6.5 vs 7.6 ms per 1024 transforms of 2^21, r01 session 11)
+  static constexpr int LD = (MODE != MODE_ROWS && CG < 8) ? POL_PLAIN
+                            : ((MODE == MODE_FIRST && FOURIER_NT_LOAD != 0) || FOURIER_NT_LOAD == 2) ? POL_NT : POL_PLAIN;
+  // MODE_ROWS: a wave's element stores only form whole lines for L >= 256; below that they rely on L2
+  // write-combining and a non-temporal hint is a 2-6x loss (N = 16..64, r01 session 9)
+  static constexpr int ST = (MODE == MODE_ROWS ? (FOURIER_NT_STORE != 0 && L >= 256)
+                             : (FINAL ? FOURIER_NT_STORE != 0 : (FOURIER_NT_STORE == 2 && L <= 1024))) ? POL_NT : POL_PLAIN;
+};
+
+// last pass of length 2L on half tiles (pass_tile, SPLIT = 1): grid = 2 x batch x tiles
+#ifndef FOURIER_SPLIT_LD
+#define FOURIER_SPLIT_LD POL_PLAIN  // the second reader of a line must find it in the L2: no streaming hint on the loads
+#endif
+template <typename T, int L, int CG, int IO = IO_PLAIN>
+__global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG)) fft_last_split_kernel(PassArgs a) {
+  FOURIER_DYN_SMEM(smem);
+  pass_tile<T, L, CG, MODE_LAST, IO, FOURIER_SPLIT_LD, PassPolicy<L, MODE_LAST>::ST, 1>(a, blockIdx.x, gridDim.x, smem, (int)threadIdx.x);
+}
+
+template <typename T, int L, int CG, int MODE, int IO = IO_PLAIN>
+__global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG)) fft_pass_kernel(PassArgs a) {
+  FOURIER_DYN_SMEM(smem);
+  pass_tile<T, L, CG, MODE, IO, PassPolicy<L, MODE, CG>::LD, PassPolicy<L, MODE, CG>::ST>(a, blockIdx.x, gridDim.x, smem, (int)threadIdx.x);
+}
+
+
+// ---- N = L1 x L2 with BOTH passes in one launch and the intermediate parked in the XCD's own L2 --------------------
+// (2^16 .. 2^18 in f32, 2^15 .. 2^17 in f64: N * sizeof(complex) <= 2 MiB.)  The two-launch plan moves every point
+// through HBM twice; here a transform is read from HBM once (pass A = the FIRST pass) and written once (pass B = the
+// LAST pass), and the transposed intermediate between them lives in a small window that is written and read back by
+// workgroups of ONE XCD, so it never leaves that XCD's 4 MiB L2 (measured with tools/membench.py --l2x: a window of
+// <= 1 MiB per XCD that is written with plain stores and read back with sc1 loads costs nothing next to the HBM
+// streams: 5.84 vs 5.85 TB/s; profiles/r02_membench.jsonl).
+//
+// Persistent workgroups, data-flow scheduling, no team barrier.  Every workgroup reads the id of the XCD it runs
+// on (HW_REG_XCC_ID) and pulls work items from THAT XCD's queue, so all items of one transform are executed on one
+// XCD whatever the dispatcher did (placement is observed, never assumed).  The queue of XCD x is the sequence, for
+// step s = 0, 1, ...: the tiles of pass B of its local transform s - 1, then the tiles of pass A of local transform s
+// (older work first: with depth = 1 pass A of s reuses the window pass B of s - 1 is reading).  The workgroup that draws (A, s, tile 0) claims the next global transform from one device-wide counter and
+// publishes it (map[s]); XCDs therefore share the batch dynamically and any number of resident workgroups per XCD
+// (even one) completes the job.  An item waits only for items drawn EARLIER from the same queue (its transform's
+// claim; pass B: all tiles of pass A; pass A: the readers of the window slot's previous tenant, `depth` steps
+// back), every drawn item is held by a running workgroup, hence no deadlock.  Waits are nevertheless bounded
+// (spin_limit) and raise ctrl[1] instead of hanging the device.
+// Visibility: producer = plain stores, every wave waits vmcnt(0) (the stores have reached the XCD's L2), workgroup
+// barrier, then one relaxed agent-scope increment; consumer = one lane polls the counter (relaxed, sc1), workgroup
+// barrier, then sc1 loads, which are served by that same L2.
+struct FusedArgs {
+  PassArgs a, b;       // pass A / pass B arguments; a.in, a.out, b.in, b.out are set per item
+  const void* in;      // user input  (batch stride a.n)
+  void* out;           // user output (may equal in: a transform is read completely before any of it is written)
+  void* window;        // [16 XCC ids][depth][n] intermediates
+  uint32_t* ctrl;      // control block, zeroed before every launch (layout below)
+  uint32_t batch, depth, tiles_a, tiles_b, spin_limit;
+};
+// ctrl: [0] next global transform, [1] abort flag; queue of XCC id x at FUSED_CTRL_HDR + x * fused_ctrl_stride(batch):
+//       [0] next item, [16 + j] map[j] (0 = unclaimed, 0xffffffff = batch exhausted, else transform + 1),
+//       [16 + cap + j] done_a[j], [16 + 2*cap + j] done_b[j], cap = batch + 2
+enum { FUSED_CTRL_HDR = 16, FUSED_XCC_IDS = 16 };
+__host__ __device__ inline uint64_t fused_ctrl_stride(uint64_t batch) { return 16 + 3 * (batch + 2); }
+__host__ __device__ inline uint64_t fused_ctrl_words(uint64_t batch) { return FUSED_CTRL_HDR + FUSED_XCC_IDS * fused_ctrl_stride(batch); }
+
+__device__ __forceinline__ uint32_t ld_relaxed(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// lane 0 only: wait until *p >= target (or *p != 0 when target == 0); false = gave up (abort flag raised)
+__device__ __forceinline__ bool fused_wait(const uint32_t* p, uint32_t target, uint32_t* abort_flag, uint32_t limit, uint32_t* seen) {
+  for (uint32_t spins = 0;; ++spins) {
+    const uint32_t v = ld_relaxed(p);
+    if (target ? v >= target : v != 0) { *seen = v; return true; }
+    if (spins >= limit || ((spins & 63) == 63 && ld_relaxed(abort_flag))) {
+      __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
+#ifndef FOURIER_FUSED_MIN_WAVES
+#define FOURIER_FUSED_MIN_WAVES 4  // four 256-thread workgroups per CU (<= 128 VGPRs), like the stand-alone passes of these lengths
+#endif
+template <typename T, int L1, int CG1, int L2, int CG2>
+__global__ void __launch_bounds__((L1 / 16) * CG1, FOURIER_FUSED_MIN_WAVES) fft_l2fused_kernel(FusedArgs f) {
+  using CA = TileCfg<T, L1, CG1>;
+  using CB = TileCfg<T, L2, CG2>;
+  static_assert(CA::NT == CB::NT, "both passes run on the same workgroup");
+  constexpr size_t SMEM_A = CA::smem_bytes(MODE_FIRST), SMEM_B = CB::smem_bytes(MODE_LAST);
+  constexpr size_t SLOT = ((SMEM_A > SMEM_B ? SMEM_A : SMEM_B) + 15) & ~(size_t)15;  // broadcast words behind the tiles' LDS
+  FOURIER_DYN_SMEM(smem);
+  volatile uint32_t* bc = (volatile uint32_t*)(smem + SLOT);
+  const int tid = (int)threadIdx.x;
+  const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & (FUSED_XCC_IDS - 1);  // HW_REG_XCC_ID[3:0]
+  uint32_t* const q = f.ctrl + FUSED_CTRL_HDR + (uint64_t)xcc * fused_ctrl_stride(f.batch);
+  const uint64_t cap = (uint64_t)f.batch + 2;
+  uint32_t* const map = q + 16;
+  uint32_t* const done_a = map + cap;
+  uint32_t* const done_b = done_a + cap;
+  uint32_t* const abort_flag = f.ctrl + 1;
+  const uint32_t per_step = f.tiles_a + f.tiles_b;
+  cpx<T>* const win0 = (cpx<T>*)f.window + (uint64_t)xcc * f.depth * f.a.n;
+
+  for (;;) {
+    // ---- draw an item; lane 0 resolves its transform and waits for what the item depends on
+    if (tid == 0) {
+      const uint32_t item = __hip_atomic_fetch_add(q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t s = item / per_step, r = item % per_step;
+      const bool is_a = r >= f.tiles_b;  // within a step: pass B of the previous transform first, then pass A of this one
+      const uint32_t tile = is_a ? r - f.tiles_b : r;
+      uint32_t g = 0xffffffffu, j = is_a ? s : s - 1;
+      int act = 0;  // 0 skip, 1 run, 2 exit
+      if (!is_a && s == 0) {
+        act = 0;  // there is no transform -1
+      } else if (j >= cap) {
+        act = 2;
+      } else {
+        uint32_t v = 0;
+        bool ok = true;
+        if (is_a && tile == 0) {
+          const uint32_t t = __hip_atomic_fetch_add(f.ctrl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          v = t < f.batch ? t + 1 : 0xffffffffu;
+          __hip_atomic_store(map + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          ok = fused_wait(map + j, 0, abort_flag, f.spin_limit, &v);
+        }
+        if (!ok) act = 2;
+        else if (v == 0xffffffffu) act = is_a ? 0 : 2;  // the batch is exhausted: nothing after this pass-B item exists
+        else {
+          uint32_t seen;
+          if (is_a) ok = (j < f.depth) || fused_wait(done_b + (j - f.depth), f.tiles_b, abort_flag, f.spin_limit, &seen);
+          else ok = fused_wait(done_a + j, f.tiles_a, abort_flag, f.spin_limit, &seen);
+          act = ok ? 1 : 2;
+          g = v - 1;
+        }
+      }
+      bc[0] = (uint32_t)act; bc[1] = g; bc[2] = j; bc[3] = (is_a ? 0u : 0x80000000u) | tile;
+    }
+    __syncthreads();
+    const uint32_t act = bc[0], g = bc[1], j = bc[2], kt = bc[3];
+    __syncthreads();  // everyone has read the slot before lane 0 of the next iteration rewrites it
+    if (act == 2) return;
+    if (act == 0) continue;
+    const bool is_a = (kt >> 31) == 0;
+    const uint32_t tile = kt & 0x7fffffffu;
+    cpx<T>* const win = win0 + (uint64_t)(j % f.depth) * f.a.n;
+    int tid_i = tid;
+    FOURIER_LAUNDER(tid_i);
+    if (is_a) {
+      PassArgs a = f.a;
+      a.in = (const cpx<T>*)f.in + (uint64_t)g * f.a.n;
+      a.out = win;
+      pass_tile<T, L1, CG1, MODE_FIRST, IO_PLAIN, POL_NT, POL_PLAIN>(a, tile, f.tiles_a, smem, tid_i);
+      FOURIER_WAIT_VMEM();  // this wave's window stores have reached the L2
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(done_a + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      PassArgs b = f.b;
+      b.in = win;
+      b.out = (cpx<T>*)f.out + (uint64_t)g * f.a.n;
+      pass_tile<T, L2, CG2, MODE_LAST, IO_PLAIN, POL_SC1, POL_NT>(b, tile, f.tiles_b, smem, tid_i);
+      __syncthreads();  // every wave holds its window data in registers by now (the tile's LDS exchanges waited for it)
+      if (tid == 0) __hip_atomic_fetch_add(done_b + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }

@@ -167,10 +167,6 @@ def have_avx():
     return bool(lib().oracle_fourier_have_avx())
 
 
-def set_avx_first_pass(on):
-    """bench.py: time the port with (True: clone 2) and without (False: clone 0, scalar) the AVX clone."""
-    return set_clone(AVX if on else GENERIC)
-
 
 def radix_pass(radix, x, forward, size, stride, clone=GENERIC):
     """One Stockham pass (autosort/mod.rs:203-284) of the restatement on a complex128 array of size*stride points."""

@@ -233,6 +233,28 @@ inline int __shfl_xor(int v, int lane_mask) {
   return r;
 }
 
+// ---- device intrinsics used by the XCD-fused kernel (inter-workgroup hand-offs): CPU stand-ins ----
+// blocks run concurrently on worker threads, so the atomics are real; seq_cst gives the ordering the GPU protocol
+// gets from "stores reached the L2 (vmcnt(0)) -> counter increment" / "counter seen -> sc1 loads"
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_WORKGROUP 2
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_SEQ_CST)
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
+inline void __builtin_amdgcn_s_sleep(int) { std::this_thread::yield(); }
+inline uint32_t __builtin_amdgcn_s_getreg(int) {  // HW_REG_XCC_ID: spread the blocks over a few pretend XCDs
+  if (const char* e = getenv("HIPEMU_XCDS")) return hipemu::tls().bid.x % (unsigned)atoi(e);
+  return hipemu::tls().bid.x % 3;
+}
+typedef const unsigned char* __amdgpu_buffer_rsrc_t;
+inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, int, int, int) { return (const unsigned char*)p; }
+struct hipemu_b128 { uint32_t w[4]; };
+inline hipemu_b128 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+  hipemu_b128 v;
+  memcpy(&v, r + voff + soff, 16);
+  return v;
+}
+
 // ---- host API subset ----
 namespace hipemu { inline uint64_t& alloc_count() { static uint64_t c = 0; return c; } }
 inline hipError_t hipMalloc(void** p, size_t n) {
@@ -274,3 +296,6 @@ inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
   return hipSuccess;
 }
 template <typename F> inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
+template <typename F> inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F, int, size_t) { *n = 2; return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 3; return hipSuccess; }

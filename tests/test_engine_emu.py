@@ -534,3 +534,42 @@ def test_device_sharded_driver_runs_every_shard_on_its_own_thread(fa, oracle):
     assert rel_l2(y, oracle.transform_batch(x, oracle.FFT)) <= 2e-6
     with pytest.raises(ValueError):
         drv.transform(ins[:2], outs, fa.Transform.Fft)
+
+
+@pytest.mark.parametrize("dtype,k", [(np.complex64, 16), (np.complex64, 17), (np.complex128, 15), (np.complex128, 17)])
+def test_xcd_fused_one_launch_plan_equals_the_two_launch_plan(fa, monkeypatch, dtype, k):
+    """fft_l2fused_kernel (plan option l2_fused): persistent workgroups pulling (transform, pass, tile) items from the
+    queue of the XCD they run on, inter-workgroup waits through counters.  The emulator runs the blocks concurrently on
+    host threads with real atomics and hands out pretend XCC ids, so the scheduling protocol itself is exercised:
+    bit-identical to the two-launch plan for 1, 3 and 8 pretend XCDs, in and out of place, ragged batches."""
+    n = 1 << k
+    x = hash_normal(k, 7 * n).astype(dtype).reshape(7, n)
+    two = make(fa, n, dtype)
+    ref = run_batch(two, x, 1)
+    for xcds in ("1", "3", "8"):
+        monkeypatch.setenv("HIPEMU_XCDS", xcds)
+        one = make(fa, n, dtype)
+        one.set_option("l2_fused", 1)
+        one.set_option("l2_fused_depth", 1 + int(xcds) % 3)
+        assert "xcd-l2" in one.describe()
+        assert np.array_equal(run_batch(one, x, 1), ref), xcds
+        assert np.array_equal(run_batch(one, x, 1, inplace=True), ref), xcds
+        assert np.array_equal(run_batch(one, x[:1], 1), ref[:1]), xcds
+    with pytest.raises(fa.FourierError):
+        make(fa, 1 << 12, dtype).set_option("l2_fused", 1)
+
+
+def test_l2048_narrow_first_pass_and_split_last_pass(fa, oracle, monkeypatch):
+    """2^21 = 2048 x 1024 (first pass of length 2048 on 64-byte-wide tiles: bit-identical to the 16-column kernel) and
+    2^22 = 2048 x 2048 (last pass on half tiles: radix-2 decimation in frequency + a 1024-point tile per workgroup,
+    routed through the scratch because two workgroups read each column tile), against the wide kernels and the oracle."""
+    for n, same in ((1 << 21, True), (1 << 22, False)):
+        x = hash_normal(n % 1000, n).astype(np.complex64)[None, :]
+        new = make(fa, n, np.complex64)
+        monkeypatch.setenv("FOURIER_WIDE_2048", "1")
+        old = make(fa, n, np.complex64)
+        monkeypatch.delenv("FOURIER_WIDE_2048")
+        yn, yo = run_batch(new, x, 0), run_batch(old, x, 0)
+        assert (np.array_equal(yn, yo) if same else rel_l2(yn, yo) < 3e-7), n
+        assert np.array_equal(run_batch(new, x, 0, inplace=True), yn), n
+        assert rel_l2(yn, oracle.transform_batch(x, oracle.FFT)) <= 1e-6, n

@@ -316,6 +316,70 @@ def test_c5_chunk_of_2p22(torch, fa, oracle):
     _full_size_properties(torch, fa, oracle, 1 << 22, 256, np.complex64, 1e-6)
 
 
+@pytest.mark.parametrize("dtype,ks,tl2", [(np.complex64, (16, 17, 18), 1e-6), (np.complex128, (15, 16, 17), 5e-14)])
+def test_xcd_fused_one_launch_plan_equals_the_two_launch_plan(torch, fa, oracle, dtype, ks, tl2):
+    """Plan option l2_fused: both passes in ONE launch, the intermediate parked in the XCD's L2 (persistent workgroups,
+    per-XCD work queues keyed by the hardware XCC id, data-flow waits).  Same arithmetic as the two-launch plan, so the
+    results must be bit-identical to it -- for a batch large enough that every XCD queue wraps its window ring many
+    times, a ragged batch of 1, in place, and all five transform codes -- and match the oracle."""
+    for k in ks:
+        n = 1 << k
+        batch = max(3, (1 << 28) // (n * np.dtype(dtype).itemsize))  # 256 MiB: thousands of queue items per XCD
+        two, one = make(fa, n, dtype), make(fa, n, dtype)
+        one.set_option("l2_fused", 1)
+        assert "xcd-l2" in one.describe() and "xcd-l2" not in two.describe()
+        cdt = torch.complex64 if dtype == np.complex64 else torch.complex128
+        g = torch.Generator(device="cuda")
+        g.manual_seed(1234 + k)
+        x = torch.empty((batch, n), dtype=cdt, device="cuda")
+        torch.view_as_real(x).normal_(0.0, 1.0, generator=g)
+        for code in range(5):
+            a, b = torch.empty_like(x), torch.full_like(x, float("nan"))
+            two.transform(x, a, fa.Transform(code))
+            one.transform(x, b, fa.Transform(code))
+            torch.cuda.synchronize()
+            assert torch.equal(torch.view_as_real(a), torch.view_as_real(b)), (k, code)
+        z = x.clone()
+        one.transform(z, z, fa.Transform.Fft)   # in place: a transform is read completely before any of it is written
+        two.transform(x, a, fa.Transform.Fft)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.view_as_real(a), torch.view_as_real(z)), k
+        for nb in (1, 2, 9):  # fewer transforms than XCDs / than workgroups
+            one.transform(x[:nb], b[:nb], fa.Transform.Fft)
+            torch.cuda.synchronize()
+            assert torch.equal(torch.view_as_real(a[:nb]), torch.view_as_real(b[:nb])), (k, nb)
+        ref = oracle.transform_batch(x[:2].cpu().numpy(), oracle.FFT)
+        assert rel_l2(b[:2].cpu().numpy(), ref) <= tl2, k
+        with pytest.raises(fa.FourierError):
+            make(fa, 1 << 20, dtype).set_option("l2_fused", 1)  # the intermediate must fit the XCD's L2
+        del x, a, b, z
+        torch.cuda.empty_cache()
+
+
+def test_l2048_passes_narrow_first_and_split_last_match_the_wide_kernels(torch, fa, oracle, monkeypatch):
+    """2^21 / 2^22 / Bluestein M = 2^21: the default plans run the L = 2048 first pass on 64-byte-wide tiles and the
+    L = 2048 last pass on half tiles (two workgroups per column tile, radix-2 decimation in frequency in front of a
+    1024-point tile).  The narrow first pass is the same arithmetic (bit-identical); the split last pass adds one
+    twiddle rounding: both are checked against the 16-column kernels (FOURIER_WIDE_2048=1) and the oracle, in and
+    out of place."""
+    for n, batch, tol in ((1 << 21, 5, 1e-6), (1 << 22, 3, 1e-6), (999983, 2, 2e-6)):
+        x = np.stack([hash_normal(50 + b, n) for b in range(batch)]).astype(np.complex64)
+        new = make(fa, n, np.complex64)
+        monkeypatch.setenv("FOURIER_WIDE_2048", "1")
+        old = make(fa, n, np.complex64)
+        monkeypatch.delenv("FOURIER_WIDE_2048")
+        ref = oracle.transform_batch(x[:1], oracle.FFT)
+        for inplace in (False, True):
+            yn = gpu_batch(torch, fa, new, x, 0, inplace=inplace)
+            yo = gpu_batch(torch, fa, old, x, 0, inplace=inplace)
+            assert rel_l2(yn, yo) <= 3e-7, (n, inplace, rel_l2(yn, yo))
+            assert rel_l2(yn[0], ref[0]) <= tol, (n, inplace)
+        if n == 1 << 21:  # 2048 x 1024: only the first pass changed
+            assert np.array_equal(yn, yo)
+        back = gpu_batch(torch, fa, new, yn, 1)
+        assert rel_l2(back, x) <= 2 * tol, n
+
+
 def test_c5_full_job_65536_transforms_on_one_gpu(torch, fa, oracle):
     """BASELINE configs[4] as specified, on ONE GPU: f32 N=2^22, batch 65536 = 2 TiB of input, walked as 64 resident
     chunks of 1024 transforms (32 GiB), every chunk regenerated on the device (seed = global chunk index) and

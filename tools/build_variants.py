@@ -34,6 +34,8 @@ VARIANTS = {
     "split16k": ["-DFOURIER_SPLIT_THRESHOLD=(16*1024)"],
     "split32k": ["-DFOURIER_SPLIT_THRESHOLD=(32*1024)"],
     "split0": ["-DFOURIER_SPLIT_THRESHOLD=0"],
+    "fused_mw3": ["-DFOURIER_FUSED_MIN_WAVES=3"],
+    "split_nt": ["-DFOURIER_SPLIT_LD=POL_NT"],
     "abl1": ["-DFOURIER_ABLATE=1"],
     "abl2": ["-DFOURIER_ABLATE=2"],
     "abl3": ["-DFOURIER_ABLATE=3"],
