@@ -1,4 +1,6 @@
-"""Builds fourier_amd/lib/libfourier.so for gfx950 with hipcc (in-tree, so it travels to the GPU box)."""
+"""Builds fourier_amd/lib/libfourier.so (+ the static archive libfourier.a, as the reference's CMake package ships
+both: fourier-ffi/CMakeLists.txt:38-65) for gfx950 with hipcc, in-tree, so that they travel to the GPU box.
+One compilation (engine.o), two link steps."""
 import os
 import subprocess
 import sys
@@ -7,8 +9,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "engine.cpp")
 DEPS = [SRC, os.path.join(HERE, "csrc", "fft_kernels.h"), os.path.join(os.path.dirname(HERE), "include", "fourier.h")]
 OUT = os.path.join(HERE, "lib", "libfourier.so")
+OBJ = os.path.join(HERE, "lib", "engine.o")
+STATIC = os.path.join(HERE, "lib", "libfourier.a")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+LINK_FLAGS = ["--offload-arch=gfx950", "-fPIC", "-shared", "-Wl,-soname,libfourier.so.0"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
          "-Wl,-soname,libfourier.so.0", "-Wno-unused-result",
          # SLP-packing f32 math into v_pk_* ops doubles the live register set of the butterflies (222 vs 104
@@ -18,11 +23,17 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x",
 
 def build(force=False, extra=()):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
+    fresh = lambda f: os.path.exists(f) and all(os.path.getmtime(f) >= os.path.getmtime(d) for d in DEPS)  # noqa: E731
+    if not force and fresh(OUT) and fresh(STATIC):
         link_soname()
         return OUT
-    cmd = [HIPCC] + FLAGS + list(extra) + [SRC, "-o", OUT]
-    subprocess.check_call(cmd)
+    compile_flags = [f for f in FLAGS if f != "-shared" and not f.startswith("-Wl,")]
+    subprocess.check_call([HIPCC] + compile_flags + list(extra) + ["-c", SRC, "-o", OBJ])
+    subprocess.check_call([HIPCC] + LINK_FLAGS + [OBJ, "-o", OUT])
+    if os.path.exists(STATIC):
+        os.remove(STATIC)
+    subprocess.check_call(["ar", "rcs", STATIC, OBJ])  # consumers link it with -lamdhip64 -lstdc++ (packaging/CMakeLists.txt)
+    os.remove(OBJ)
     link_soname()
     return OUT
 
