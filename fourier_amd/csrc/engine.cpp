@@ -173,18 +173,26 @@ template <typename T, int L, int CG, int IO = IO_PLAIN> static KernelInfo make_s
 #endif
 // L = 2048 holds a 256 KiB tile per workgroup at 16 columns -- one workgroup per CU, no overlap of its load and
 // compute phases.  Default plans therefore run the FIRST pass on 64-byte-wide tiles (8 columns, 128 KiB, two
-// workgroups per CU; the transposed store does not care about the tile width) and the LAST pass on half tiles
-// (fft_last_split_kernel).  FOURIER_WIDE_2048=1 in the environment at plan creation brings the 16-column kernels back (A/B).
+// workgroups per CU; the transposed store does not care about the tile width): 6.3-6.6 vs 7.2-7.8 ms per 1024
+// transforms of 2^21 (profiles/r02_s2_l2048_and_xcd_fused_ab.jsonl).  FOURIER_WIDE_2048=1 in the environment at plan
+// creation brings the 16-column first pass back (A/B).
 #ifndef FOURIER_CG_2048_FIRST
 #define FOURIER_CG_2048_FIRST 4
 #endif
 
+#ifndef FOURIER_CG_4096
+#define FOURIER_CG_4096 2
+#endif
 template <typename T> static KernelInfo get_kernel(int L, int mode, int io = IO_PLAIN) {
+  // first pass of length 4096 on 32-byte-wide tiles (128 KiB, two workgroups per CU): 2^22 = 4096 x 1024
+  if (L == 4096 && mode == MODE_FIRST && io == IO_PLAIN) return make_info<T, 4096, FOURIER_CG_4096, MODE_FIRST>();
   if (L == 2048 && !getenv("FOURIER_WIDE_2048")) {
     if (mode == MODE_FIRST)
       return io == IO_BLU_IN ? make_info<T, 2048, FOURIER_CG_2048_FIRST, MODE_FIRST, IO_BLU_IN>()
                              : make_info<T, 2048, FOURIER_CG_2048_FIRST, MODE_FIRST>();
-    if (mode == MODE_LAST)
+    // half tiles for the last pass were measured 5-7 % SLOWER than the 16-column kernel (profiles/r02_s2_*_ab.jsonl:
+    // 13.6-14.0 vs 13.1 ms per 1024 transforms of 2^22); kept behind FOURIER_SPLIT_2048=1 for experiments
+    if (mode == MODE_LAST && getenv("FOURIER_SPLIT_2048"))
       return io == IO_BLU_OUT ? make_split_info<T, 2048, FOURIER_CG_1024, IO_BLU_OUT>() : make_split_info<T, 2048, FOURIER_CG_1024>();
   }
 #define FK(LL, CGG)                                                                              \
@@ -418,7 +426,9 @@ template <typename T> class Pow2Engine {
 
   // mirror: the pass lengths in reverse order (the inverse inner FFT of a conv-fused Bluestein plan must start
   // with the length the forward one ends with)
-  explicit Pow2Engine(size_t n, bool mirror = false) : n_(n) {
+  // plain: the plan is used as a whole transform (not as the inner FFT of a Bluestein plan, which needs a last pass and
+  // a mirror image of every length it uses)
+  explicit Pow2Engine(size_t n, bool mirror = false, bool plain = false) : n_(n) {
     size_t p3 = 1, p2 = n;
     while (p2 % 3 == 0 && p3 < 27) { p2 /= 3; p3 *= 3; }
     if (!is_pow2(p2) || (p3 > 1 && p2 < 4096))
@@ -462,6 +472,8 @@ template <typename T> class Pow2Engine {
       tiny_ = true;
     } else if (k <= 11) {
       lens = {k};
+    } else if (k == 22 && plain && p3 == 1 && getenv("FOURIER_PLAN_4096")) {
+      lens = {12, 10};  // experiment: 4096 (narrow first pass) x 1024 instead of 2048 x 2048
     } else if (k <= 22) {
       lens = {(k + 1) / 2, k / 2};
     } else if (k <= 30) {
@@ -1002,7 +1014,7 @@ template <typename T> class Plan {
     device_ = device;
     DeviceGuard g(device_);
     if (is_pow2(n)) {
-      eng_.reset(new Pow2Engine<T>(n));
+      eng_.reset(new Pow2Engine<T>(n, false, true));
     } else if (Pow2Engine<T>::handles_mixed(n)) {
       // big-radix passes over the 2^a part (a >= 12), then a radix-3^b pass: three HBM round trips at full tile
       // efficiency beat the one-workgroup-per-CU LDS kernel where both apply (3*2^12 f32: 23 % vs 14 %)

@@ -515,8 +515,15 @@ __device__ __forceinline__ void tile_core(RegTile<T, L, CG>& x, int& th, int& cg
 // tile each (two per CU, load and compute phases overlap) instead of one 1024-thread workgroup whose 256 KiB tile
 // fills the CU's registers; the tile is read twice, the second time from the XCD's L2 (the two workgroups are adjacent
 // blocks of one XCD), written once.
-template <typename T, int L, int CG, int MODE, int IO, int LDPOL, int STPOL, int SPLIT = 0>
-__device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint64_t nblk, unsigned char* smem, const int tid) {
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+// `before_store` runs (on every thread) after the tile's arithmetic and before its first store: the XCD-fused kernel waits
+// there for its window slot, so that a tile's HBM loads and butterflies are not held up by the readers of the slot's
+// previous tenant.
+template <typename T, int L, int CG, int MODE, int IO, int LDPOL, int STPOL, int SPLIT = 0, typename Hook = NoHook>
+__device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint64_t nblk, unsigned char* smem, const int tid,
+                                          const Hook& before_store = Hook()) {
   static_assert(IO == IO_PLAIN || (IO == IO_BLU_IN && MODE == MODE_FIRST) || (IO == IO_BLU_OUT && MODE == MODE_LAST),
                 "Bluestein fusion: chirp-in on the first pass, chirp-out on the last pass");
   static_assert(SPLIT == 0 || (MODE == MODE_LAST && LDPOL != POL_SC1), "split tiles: last pass only");
@@ -674,6 +681,7 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
   }
 
   // ---- store
+  before_store();
   const T scale = (T)a.scale;
   const cpx<T>* __restrict__ mul = (const cpx<T>*)a.mul;
   if constexpr (OUT_ROWS) {
@@ -795,8 +803,8 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
 // (older work first: with depth = 1 pass A of s reuses the window pass B of s - 1 is reading).  The workgroup that draws (A, s, tile 0) claims the next global transform from one device-wide counter and
 // publishes it (map[s]); XCDs therefore share the batch dynamically and any number of resident workgroups per XCD
 // (even one) completes the job.  An item waits only for items drawn EARLIER from the same queue (its transform's
-// claim; pass B: all tiles of pass A; pass A: the readers of the window slot's previous tenant, `depth` steps
-// back), every drawn item is held by a running workgroup, hence no deadlock.  Waits are nevertheless bounded
+// claim; pass B: all tiles of pass A; pass A, just before its stores: the readers of the window slot's previous
+// tenant, `depth` steps back), every drawn item is held by a running workgroup, hence no deadlock.  Waits are nevertheless bounded
 // (spin_limit) and raise ctrl[1] instead of hanging the device.
 // Visibility: producer = plain stores, every wave waits vmcnt(0) (the stores have reached the XCD's L2), workgroup
 // barrier, then one relaxed agent-scope increment; consumer = one lane polls the counter (relaxed, sc1), workgroup
@@ -833,6 +841,22 @@ __device__ __forceinline__ bool fused_wait(const uint32_t* p, uint32_t target, u
 #ifndef FOURIER_FUSED_MIN_WAVES
 #define FOURIER_FUSED_MIN_WAVES 4  // four 256-thread workgroups per CU (<= 128 VGPRs), like the stand-alone passes of these lengths
 #endif
+struct FusedWindowFree {
+  const uint32_t* counter;  // done_b of the slot's previous tenant, or null when the slot has never been used
+  uint32_t target;
+  uint32_t* abort_flag;
+  uint32_t limit;
+  int tid;
+  __device__ __forceinline__ void operator()() const {
+    if (!counter) return;  // wave-uniform
+    if (tid == 0) {
+      uint32_t seen;
+      (void)fused_wait(counter, target, abort_flag, limit, &seen);  // on give-up the abort flag is up: every later wait bails out
+    }
+    __syncthreads();
+  }
+};
+
 template <typename T, int L1, int CG1, int L2, int CG2>
 __global__ void __launch_bounds__((L1 / 16) * CG1, FOURIER_FUSED_MIN_WAVES) fft_l2fused_kernel(FusedArgs f) {
   using CA = TileCfg<T, L1, CG1>;
@@ -880,8 +904,7 @@ __global__ void __launch_bounds__((L1 / 16) * CG1, FOURIER_FUSED_MIN_WAVES) fft_
         else if (v == 0xffffffffu) act = is_a ? 0 : 2;  // the batch is exhausted: nothing after this pass-B item exists
         else {
           uint32_t seen;
-          if (is_a) ok = (j < f.depth) || fused_wait(done_b + (j - f.depth), f.tiles_b, abort_flag, f.spin_limit, &seen);
-          else ok = fused_wait(done_a + j, f.tiles_a, abort_flag, f.spin_limit, &seen);
+          if (!is_a) ok = fused_wait(done_a + j, f.tiles_a, abort_flag, f.spin_limit, &seen);  // pass A waits later, see WindowFree
           act = ok ? 1 : 2;
           g = v - 1;
         }
@@ -902,7 +925,10 @@ __global__ void __launch_bounds__((L1 / 16) * CG1, FOURIER_FUSED_MIN_WAVES) fft_
       PassArgs a = f.a;
       a.in = (const cpx<T>*)f.in + (uint64_t)g * f.a.n;
       a.out = win;
-      pass_tile<T, L1, CG1, MODE_FIRST, IO_PLAIN, POL_NT, POL_PLAIN>(a, tile, f.tiles_a, smem, tid_i);
+      // the window slot's previous tenant (local transform j - depth) must have been read completely -- checked only
+      // now, with this tile's data already loaded and transformed in registers
+      const FusedWindowFree hook{j >= f.depth ? done_b + (j - f.depth) : nullptr, f.tiles_b, abort_flag, f.spin_limit, tid};
+      pass_tile<T, L1, CG1, MODE_FIRST, IO_PLAIN, POL_NT, POL_PLAIN, 0, FusedWindowFree>(a, tile, f.tiles_a, smem, tid_i, hook);
       FOURIER_WAIT_VMEM();  // this wave's window stores have reached the L2
       __syncthreads();
       if (tid == 0) __hip_atomic_fetch_add(done_a + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -919,6 +945,13 @@ __global__ void __launch_bounds__((L1 / 16) * CG1, FOURIER_FUSED_MIN_WAVES) fft_
 
 #ifndef FOURIER_CONV_MIN_WAVES
 #define FOURIER_CONV_MIN_WAVES(NT) FOURIER_MIN_WAVES(NT)
+#endif
+// A/B knobs of the conv kernel (tools/build_variants.py): non-temporal stores / non-temporal loads of the w table
+#ifndef FOURIER_CONV_ST_NT
+#define FOURIER_CONV_ST_NT 0
+#endif
+#ifndef FOURIER_CONV_W_NT
+#define FOURIER_CONV_W_NT 0
 #endif
 // ---- Bluestein middle (bluesteins.rs:236-239): LAST pass of the forward inner FFT, (.) w, and FIRST pass of
 // the inverse inner FFT in ONE launch.  The last forward pass (R = L, s = M/L) leaves X[j + (M/L)*k] of its
@@ -965,7 +998,7 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16)
     const cpx<T>* w = (const cpx<T>*)a.mul + off;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const Unit16<T> u = load_unit<T, false>(w + (uint64_t)(Q * r) * a.cn);
+      const Unit16<T> u = load_unit<T, FOURIER_CONV_W_NT != 0>(w + (uint64_t)(Q * r) * a.cn);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         const cpx<T> y = cmul(x[v][r], cpx<T>{u.a[2 * v], u.a[2 * v + 1]});
@@ -989,7 +1022,7 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16)
   for (int v = 0; v < VEC; ++v) {
     cpx<T>* p = out + (c0 + (uint64_t)(cg * VEC + v)) * L + th;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) p[Q * r] = x[v][r];  // plain stores measured faster here (r01 session 8)
+    for (int r = 0; r < 16; ++r) store_elem<T, FOURIER_CONV_ST_NT != 0>(p + Q * r, x[v][r]);  // plain stores measured faster here (r01 session 8)
   }
 }
 

@@ -95,3 +95,42 @@ def test_transform_enum_matches_reference():
     assert not Transform.Ifft.is_forward() and not Transform.UnscaledIfft.is_forward()
     assert Transform.Fft.inverse() is Transform.Ifft and Transform.UnscaledIfft.inverse() is None
     assert Transform.SqrtScaledIfft.inverse() is Transform.SqrtScaledFft
+
+
+def test_rust_shim_names_only_exported_symbols(libpath):
+    """rust/fourier-hip/src/lib.rs cannot be compiled here (no rustc): at least every `fn fourier_*` of its
+    `extern "C"` block must be a symbol of the library and be declared in include/fourier.h."""
+    import re
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "rust", "fourier-hip", "src", "lib.rs")).read()
+    block = src[src.index('extern "C" {'):]
+    block = block[:block.index("\n    }")]
+    names = set(re.findall(r"fn (fourier_\w+)\(", block))
+    assert len(names) == 19, sorted(names)
+    exported = set(subprocess.run(["nm", "-D", "--defined-only", libpath], capture_output=True, text=True).stdout.split())
+    header = open(os.path.join(root, "include", "fourier.h")).read()
+    for n in sorted(names):
+        assert n in exported, n
+        assert re.search(r"\b%s\(" % n, header), n
+
+
+def test_cmake_package_configures(tmp_path):
+    """packaging/CMakeLists.txt (shared + static library from one object library, five ctest programs) must at least
+    configure with the ROCm toolchain of this image.  Building it compiles the engine once more (~2 min) and its
+    programs need a GPU, so the build + ctest run is a manual step; the same link lines are exercised
+    against the in-tree libraries by the `-m gpu` tests."""
+    import shutil
+    import subprocess
+
+    if not shutil.which("cmake") or not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("cmake / ROCm clang not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["cmake", "-S", os.path.join(root, "packaging"), "-B", str(tmp_path / "b"),
+                        "-DCMAKE_HIP_COMPILER=/opt/rocm/lib/llvm/bin/clang++", "-DCMAKE_PREFIX_PATH=/opt/rocm"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    targets = subprocess.run(["cmake", "--build", str(tmp_path / "b"), "--target", "help"], capture_output=True, text=True).stdout
+    for t in ("fourier", "fourier_static", "consumer_c", "consumer_cxx", "consumer_c_static", "consumer_cxx_static", "ffi_sequence"):
+        assert t in targets, t

@@ -357,25 +357,28 @@ def test_xcd_fused_one_launch_plan_equals_the_two_launch_plan(torch, fa, oracle,
 
 
 def test_l2048_passes_narrow_first_and_split_last_match_the_wide_kernels(torch, fa, oracle, monkeypatch):
-    """2^21 / 2^22 / Bluestein M = 2^21: the default plans run the L = 2048 first pass on 64-byte-wide tiles and the
-    L = 2048 last pass on half tiles (two workgroups per column tile, radix-2 decimation in frequency in front of a
-    1024-point tile).  The narrow first pass is the same arithmetic (bit-identical); the split last pass adds one
-    twiddle rounding: both are checked against the 16-column kernels (FOURIER_WIDE_2048=1) and the oracle, in and
-    out of place."""
+    """2^21 / 2^22 / Bluestein M = 2^21.  Default plans run the L = 2048 FIRST pass on 64-byte-wide tiles (same
+    arithmetic as the 16-column kernel, FOURIER_WIDE_2048=1: bit-identical).  The half-tile LAST pass (two workgroups
+    per column tile, radix-2 decimation in frequency in front of a 1024-point tile; FOURIER_SPLIT_2048=1, measured
+    slower and therefore off by default) adds one twiddle rounding.  All three against each other and the oracle,
+    in and out of place."""
     for n, batch, tol in ((1 << 21, 5, 1e-6), (1 << 22, 3, 1e-6), (999983, 2, 2e-6)):
         x = np.stack([hash_normal(50 + b, n) for b in range(batch)]).astype(np.complex64)
         new = make(fa, n, np.complex64)
         monkeypatch.setenv("FOURIER_WIDE_2048", "1")
         old = make(fa, n, np.complex64)
         monkeypatch.delenv("FOURIER_WIDE_2048")
+        monkeypatch.setenv("FOURIER_SPLIT_2048", "1")
+        split = make(fa, n, np.complex64)
+        monkeypatch.delenv("FOURIER_SPLIT_2048")
         ref = oracle.transform_batch(x[:1], oracle.FFT)
         for inplace in (False, True):
             yn = gpu_batch(torch, fa, new, x, 0, inplace=inplace)
             yo = gpu_batch(torch, fa, old, x, 0, inplace=inplace)
-            assert rel_l2(yn, yo) <= 3e-7, (n, inplace, rel_l2(yn, yo))
-            assert rel_l2(yn[0], ref[0]) <= tol, (n, inplace)
-        if n == 1 << 21:  # 2048 x 1024: only the first pass changed
-            assert np.array_equal(yn, yo)
+            ys = gpu_batch(torch, fa, split, x, 0, inplace=inplace)
+            assert np.array_equal(yn, yo), (n, inplace)
+            assert rel_l2(ys, yo) <= 3e-7, (n, inplace, rel_l2(ys, yo))
+            assert rel_l2(yn[0], ref[0]) <= tol and rel_l2(ys[0], ref[0]) <= tol, (n, inplace)
         back = gpu_batch(torch, fa, new, yn, 1)
         assert rel_l2(back, x) <= 2 * tol, n
 
@@ -650,6 +653,45 @@ def test_c_and_cxx_consumers_relink_unchanged(fa, tmp_path, src, cc, std):
     env = dict(os.environ, LD_LIBRARY_PATH=f"{libdir}:{tmp_path}:/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     out = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0 and "Tests ran successfully." in out.stdout, out.stderr[-2000:]
+
+
+def _build_and_run_c(tmp_path, src, cc, std, static):
+    import subprocess
+
+    from fourier_amd import _lib
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / (os.path.splitext(src)[0] + ("_static" if static else "")))
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    cmd = [cc, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+           os.path.join(root, "tests", "c", src), "-o", exe]
+    if static:  # the archive carries the gfx950 code object; its only dependencies are the HIP runtime and libstdc++
+        cmd += [os.path.join(libdir, "libfourier.a"), "-L/opt/rocm/lib", "-lamdhip64", "-lstdc++", "-lm", "-lpthread",
+                "-Wl,-rpath,/opt/rocm/lib"]
+    else:
+        cmd += ["-L", libdir, "-l:libfourier.so", "-lm", f"-Wl,-rpath,{libdir}"]
+    subprocess.check_call(cmd)
+    env = dict(os.environ, LD_LIBRARY_PATH=f"{libdir}:/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0 and "Tests ran successfully." in out.stdout, (out.returncode, out.stderr[-2000:])
+    if static:
+        needed = subprocess.run(["readelf", "-d", exe], capture_output=True, text=True).stdout
+        assert "libfourier" not in needed, "the static consumer must not depend on libfourier.so"
+
+
+@pytest.mark.parametrize("static", [False, True])
+def test_c_programs_issue_the_rust_shims_ffi_sequence(fa, tmp_path, static):
+    """rust/fourier-hip cannot be compiled in this image; tests/c/ffi_sequence.c makes exactly its FFI calls
+    (create -> transform_in_place -> transform -> last_status -> batch_host -> reserve -> destroy, both precisions,
+    every transform code, the NULL / unknown-code / size-0 cases) against the shared library and the static archive."""
+    _build_and_run_c(tmp_path, "ffi_sequence.c", "gcc", "-std=c11", static)
+
+
+@pytest.mark.parametrize("src,cc,std", [("consumer.c", "gcc", "-std=c11"), ("consumer.cpp", "g++", "-std=c++14")])
+def test_c_and_cxx_consumers_link_the_static_archive(fa, tmp_path, src, cc, std):
+    """fourier-ffi/CMakeLists.txt:94-111 registers four ctest programs: the C and the C++ consumer, each against the
+    shared and the static library.  The shared pair is test_c_and_cxx_consumers_relink_unchanged; this is the static pair."""
+    _build_and_run_c(tmp_path, src, cc, std, True)
 
 
 def test_error_behaviour(torch, fa):

@@ -35,6 +35,10 @@ VARIANTS = {
     "split32k": ["-DFOURIER_SPLIT_THRESHOLD=(32*1024)"],
     "split0": ["-DFOURIER_SPLIT_THRESHOLD=0"],
     "fused_mw3": ["-DFOURIER_FUSED_MIN_WAVES=3"],
+    "conv_stnt": ["-DFOURIER_CONV_ST_NT=1"],
+    "conv_wnt": ["-DFOURIER_CONV_W_NT=1"],
+    "conv_both": ["-DFOURIER_CONV_ST_NT=1", "-DFOURIER_CONV_W_NT=1"],
+    "cg4096_4": ["-DFOURIER_CG_4096=4"],
     "split_nt": ["-DFOURIER_SPLIT_LD=POL_NT"],
     "abl1": ["-DFOURIER_ABLATE=1"],
     "abl2": ["-DFOURIER_ABLATE=2"],

@@ -80,6 +80,15 @@ def main():
             run("2^22 (C5 chunk)", 1 << 22, 1024, env=env, check=torch_ref)
             run("C4", 999983, 512, env=env)
             run("2^21 f64", 1 << 21, 512, "f64", env=env)
+    if which in ("all", "p4096"):
+        for env in (None, {"FOURIER_PLAN_4096": "1"}, None, {"FOURIER_PLAN_4096": "1"}):
+            run("2^22 (C5 chunk)", 1 << 22, 1024, env=env, check=torch_ref)
+        for env in (None, {"FOURIER_PLAN_4096": "1"}):
+            run("2^22 f64", 1 << 22, 512, "f64", env=env, check=torch_ref)
+    if which in ("all", "conv"):
+        for opts in ((), (("xcd_swizzle", 3),), (), (("xcd_swizzle", 3),)):
+            run("C4", 999983, 512, opts=opts)
+        run("N=65537", 65537, 8192)
     if which in ("all", "fused"):
         for real, ks in (("f32", (16, 17, 18)), ("f64", (15, 16, 17))):
             esz = 8 if real == "f32" else 16
@@ -87,18 +96,21 @@ def main():
                 n = 1 << k
                 batch = (8 << 30) // (n * esz)
                 run(f"2^{k} {real} two-launch", n, batch, real, check=torch_ref)
-                for depth in (1, 2, 3, 4):
+                for depth in (2, 3, 4, 6):
                     run(f"2^{k} {real} fused d{depth}", n, batch, real, opts=(("l2_fused", 1), ("l2_fused_depth", depth)),
                         check=torch_ref if depth == 2 else None)
-                for grid in (256, 512, 768):
-                    run(f"2^{k} {real} fused grid{grid}", n, batch, real, opts=(("l2_fused", 1), ("l2_fused_grid", grid)))
+                for grid in (512, 768):
+                    run(f"2^{k} {real} fused d4 grid{grid}", n, batch, real, opts=(("l2_fused", 1), ("l2_fused_depth", 4), ("l2_fused_grid", grid)))
 
 
 if __name__ == "__main__":
     libs = [None]
+    if "--only-variants" in sys.argv:
+        sys.argv[sys.argv.index("--only-variants")] = "--variants"
+        libs = []
     if "--variants" in sys.argv:
         sys.argv.remove("--variants")
-        libs += [n for n in ("fused_mw3",) if os.path.exists(os.path.join(ROOT, "fourier_amd/lib/variants", f"libfourier_{n}.so"))]
+        libs += [n for n in sys.argv[2:] if os.path.exists(os.path.join(ROOT, "fourier_amd/lib/variants", f"libfourier_{n}.so"))]
     for name in libs:
         if name:
             _lib._lib = _lib.bind(ctypes.CDLL(os.path.join(ROOT, "fourier_amd/lib/variants", f"libfourier_{name}.so")))
