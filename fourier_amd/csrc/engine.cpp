@@ -472,8 +472,10 @@ template <typename T> class Pow2Engine {
       tiny_ = true;
     } else if (k <= 11) {
       lens = {k};
-    } else if (k == 22 && plain && p3 == 1 && getenv("FOURIER_PLAN_4096")) {
-      lens = {12, 10};  // experiment: 4096 (narrow first pass) x 1024 instead of 2048 x 2048
+    } else if (k == 22 && plain && p3 == 1 && (sizeof(T) == 8 ? !getenv("FOURIER_NO_PLAN_4096") : getenv("FOURIER_PLAN_4096") != nullptr)) {
+      // 4096 (first pass on 32-byte-wide tiles) x 1024 instead of 2048 x 2048: f64 27.4 vs 28.9 ms per 512 transforms,
+      // f32 27.3 vs 25.8-26.5 ms per 1024 (profiles/r02_s3_plan4096_conv_and_fused_ab.jsonl) -- so f64 only by default
+      lens = {12, 10};
     } else if (k <= 22) {
       lens = {(k + 1) / 2, k / 2};
     } else if (k <= 30) {
@@ -836,6 +838,10 @@ template <typename T> class Pow2Engine {
     a.tiles = last.cn / conv_.COLS;
     a.nxcd = nxcd & 0xff;
     a.xcd_interleave = (nxcd >> 8) & 3;
+    // this kernel (only) reads a per-transform table indexed like the data, the transformed chirp: let every XCD own an
+    // eighth of the TILES of every transform, so that its 1/8 of the table (2 MiB of 16 at M = 2^21) stays in its L2
+    // (with streaming stores: conv 4.5 vs 4.75 ms per 512 at C4; the plain passes lose 10-15 % under this order)
+    if (a.nxcd == 8 && a.xcd_interleave == 0 && a.tiles % 8 == 0 && !getenv("FOURIER_CONV_XCD_PLAIN")) a.xcd_interleave = 2;
     a.scale = 1.0;
     const uint64_t grid = (uint64_t)batch * a.tiles;
     if (grid > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");

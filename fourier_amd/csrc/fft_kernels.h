@@ -839,7 +839,9 @@ __device__ __forceinline__ bool fused_wait(const uint32_t* p, uint32_t target, u
 }
 
 #ifndef FOURIER_FUSED_MIN_WAVES
-#define FOURIER_FUSED_MIN_WAVES 4  // four 256-thread workgroups per CU (<= 128 VGPRs), like the stand-alone passes of these lengths
+// three 256-thread workgroups per CU (<= 168 VGPRs): at four (<= 128) the two pass bodies spill 56-116 bytes per lane
+// and every size measured slower (profiles/r02_s3_plan4096_conv_and_fused_ab.jsonl)
+#define FOURIER_FUSED_MIN_WAVES 3
 #endif
 struct FusedWindowFree {
   const uint32_t* counter;  // done_b of the slot's previous tenant, or null when the slot has never been used
@@ -948,7 +950,7 @@ __global__ void __launch_bounds__((L1 / 16) * CG1, FOURIER_FUSED_MIN_WAVES) fft_
 #endif
 // A/B knobs of the conv kernel (tools/build_variants.py): non-temporal stores / non-temporal loads of the w table
 #ifndef FOURIER_CONV_ST_NT
-#define FOURIER_CONV_ST_NT 0
+#define FOURIER_CONV_ST_NT 1  // with the XCD-sliced tile order of launch_conv: 4.5 vs 4.75 ms (C4), 7.8 vs 8.3 ms (N = 65537), r02 session 3
 #endif
 #ifndef FOURIER_CONV_W_NT
 #define FOURIER_CONV_W_NT 0
@@ -1022,7 +1024,7 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16)
   for (int v = 0; v < VEC; ++v) {
     cpx<T>* p = out + (c0 + (uint64_t)(cg * VEC + v)) * L + th;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) store_elem<T, FOURIER_CONV_ST_NT != 0>(p + Q * r, x[v][r]);  // plain stores measured faster here (r01 session 8)
+    for (int r = 0; r < 16; ++r) store_elem<T, FOURIER_CONV_ST_NT != 0>(p + Q * r, x[v][r]);
   }
 }
 

@@ -153,7 +153,12 @@ const char *fourier_hip_status_string(int status);
  *   "bluestein_fusion" 1 (default where the inner FFT has >= 2 passes) = chirp steps fused into the inner passes
  *   "host_chunk_bytes" bytes of one chunk of fourier_hip_transform_batch_host_* (default 32 MiB, four in flight)
  *   "bluestein_conv"   1 (default with bluestein_fusion) = the forward inner FFT's last pass, the multiply by the
- *                  transformed chirp and the inverse inner FFT's first pass run as one launch */
+ *                  transformed chirp and the inverse inner FFT's first pass run as one launch
+ *   "l2_fused"     1 = run both passes of a two-pass plan in ONE launch with the intermediate parked in the XCD's L2
+ *                  (persistent workgroups, per-XCD work queues; f32 2^16..2^18, f64 2^15..2^17 only, INVALID_ARGUMENT
+ *                  elsewhere).  Same results bit for bit; measured slower than the two-launch plan on MI355X
+ *                  (DESIGN.md section 4), hence 0 by default.  "l2_fused_depth" (1..8 windows per XCD) and
+ *                  "l2_fused_grid" (persistent workgroups) tune it. */
 int fourier_hip_set_option_float(FOURIER_STRUCT fourier_fft_float *, const char *key, long long value);
 int fourier_hip_set_option_double(FOURIER_STRUCT fourier_fft_double *, const char *key, long long value);
 
