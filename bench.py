@@ -239,7 +239,19 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # RCCL prints a version banner on STDOUT when its communicator comes up; stdout carries exactly one JSON line
+        # (the driver parses it), so the banner is sent to stderr: fd 1 -> fd 2 around the communicator's creation
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     import fourier_amd
     from fourier_amd import Transform, shard

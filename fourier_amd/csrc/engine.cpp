@@ -698,6 +698,9 @@ template <typename T> class Pow2Engine {
     const void* xtab = nullptr;
     uint64_t n = 0;
     int swap = 0;
+    const void* chirp_lo = nullptr;  // non-null: evaluate the chirp in the kernel (two-level table of 2n-th roots)
+    const void* chirp_hi = nullptr;
+    uint32_t chirp_bits = 0;
   };
 
   void run(const cpx<T>* in, cpx<T>* out, cpx<T>* scratch, size_t batch, bool inverse, double scale, const cpx<T>* mul,
@@ -779,7 +782,11 @@ template <typename T> class Pow2Engine {
       a.nxcd = nxcd & 0xff;
       a.xcd_interleave = (nxcd >> 8) & 3;
       const bool blu_here = ps.has_blu && ((blu.io == IO_BLU_IN && p == 0) || (blu.io == IO_BLU_OUT && p + 1 == np));
-      if (blu_here) { a.blu_x = blu.xtab; a.blu_n = blu.n; a.blu_swap = blu.swap; }
+      if (blu_here) {
+        a.blu_x = blu.xtab; a.blu_n = blu.n; a.blu_swap = blu.swap;
+        a.chirp_lo = blu.chirp_lo; a.chirp_hi = blu.chirp_hi; a.chirp_bits = blu.chirp_bits;
+        a.chirp_two_n = 2.0 * (double)blu.n; a.chirp_inv_two_n = 1.0 / a.chirp_two_n;
+      }
       const KernelInfo& kk = blu_here ? ps.k_blu : ps.k;
       a.swap_in = (p == 0) && inverse;
       a.swap_out = (p + 1 == np) && inverse;
@@ -1077,8 +1084,9 @@ template <typename T> class Plan {
     // unfused: pre (n + table read, m write) + 2 inner FFTs + w table + post (n + table read, n write);
     // fused: the first / last inner pass read / write the n-point user array instead of an m-point sweep
     if (small_fused_) return (double)ELEM * 2.0 * n_;  // tables stay L2-resident
-    if (fused_ && conv_) return (double)ELEM * (2.0 * m_ * (2.0 * eng_->num_passes() - 1.0) - 2.0 * (m_ - n_) + m_ + 2.0 * n_);
-    if (fused_) return (double)ELEM * (2.0 * 2.0 * m_ * eng_->num_passes() - 2.0 * (m_ - n_) + m_ + 2.0 * n_);
+    const double chirp_reads = chirp_eval_ ? 0.0 : 2.0 * n_;  // the n-entry chirp table, once per fused end pass
+    if (fused_ && conv_) return (double)ELEM * (2.0 * m_ * (2.0 * eng_->num_passes() - 1.0) - 2.0 * (m_ - n_) + m_ + chirp_reads);
+    if (fused_) return (double)ELEM * (2.0 * 2.0 * m_ * eng_->num_passes() - 2.0 * (m_ - n_) + m_ + chirp_reads);
     return (double)ELEM * ((2.0 * n_ + m_) + 2.0 * 2.0 * m_ * eng_->num_passes() + m_ + 3.0 * n_);
   }
 
@@ -1093,6 +1101,7 @@ template <typename T> class Plan {
       return 0;
     }
     if (key == "bluestein_conv" && (v == 0 || v == 1)) { conv_ = (v == 1) && conv_ok_; return 0; }
+    if (key == "bluestein_chirp_eval" && (v == 0 || v == 1)) { chirp_eval_ = (v == 1) && chirp_lo_.p != nullptr; return 0; }
     if (key == "host_chunk_bytes" && v > 0) { host_chunk_bytes_ = (size_t)v; return 0; }
     // both passes in one launch with the intermediate in the XCD's L2 (2^16..2^18 f32, 2^15..2^17 f64); 0 where unavailable
     if (key == "l2_fused" && (v == 0 || v == 1)) {
@@ -1196,6 +1205,10 @@ template <typename T> class Plan {
         typename Pow2Engine<T>::BluIO bin, bout;
         bin.io = IO_BLU_IN; bin.xtab = xtab_.p; bin.n = n_; bin.swap = inverse;
         bout.io = IO_BLU_OUT; bout.xtab = xtab_.p; bout.n = n_; bout.swap = inverse;
+        if (chirp_eval_) {
+          bin.chirp_lo = bout.chirp_lo = chirp_lo_.p; bin.chirp_hi = bout.chirp_hi = chirp_hi_.p;
+          bin.chirp_bits = bout.chirp_bits = chirp_bits_;
+        }
         const Pow2Engine<T>& inv = eng_inv_ ? *eng_inv_ : *eng_;
         cpx<T>* bufs[2] = {work, (cpx<T>*)scratch_.p};
         const cpx<T>* src = in + b0 * n_;
@@ -1221,6 +1234,10 @@ template <typename T> class Plan {
         typename Pow2Engine<T>::BluIO bin, bout;
         bin.io = IO_BLU_IN; bin.xtab = xtab_.p; bin.n = n_; bin.swap = inverse;
         bout.io = IO_BLU_OUT; bout.xtab = xtab_.p; bout.n = n_; bout.swap = inverse;
+        if (chirp_eval_) {
+          bin.chirp_lo = bout.chirp_lo = chirp_lo_.p; bin.chirp_hi = bout.chirp_hi = chirp_hi_.p;
+          bin.chirp_bits = bout.chirp_bits = chirp_bits_;
+        }
         eng_->run(in + b0 * n_, work, (cpx<T>*)scratch_.p, nb, false, 1.0, (const cpx<T>*)wtab_.p, false, stream, prof, 1,
                   nxcd_, bin);
         eng_->run(work, out + b0 * n_, (cpx<T>*)scratch_.p, nb, true, scale, nullptr, false, stream, prof, 1 + np, nxcd_, bout);
@@ -1358,6 +1375,16 @@ template <typename T> class Plan {
     std::vector<cpx<T>> x(n_);
     for (size_t k = 0; k < n_; ++k) x[k] = {(T)cr[k], (T)ci[k]};  // x_fwd, bluesteins.rs:51-61
     xtab_.upload(x);
+    if (fused_ && !small_fused_) {
+      // the fused passes evaluate the chirp instead of reading the n-entry table: two-level table of 2n-th roots
+      chirp_bits_ = (uint32_t)((ilog2(two_n) + 1) / 2);
+      std::vector<cpx<T>> lo((size_t)1 << chirp_bits_), hi((size_t)((two_n - 1) >> chirp_bits_) + 1);
+      for (size_t e = 0; e < lo.size(); ++e) { double re, im; unit_root(e, two_n, re, im); lo[e] = {(T)re, (T)im}; }
+      for (size_t h = 0; h < hi.size(); ++h) { double re, im; unit_root((uint64_t)h << chirp_bits_, two_n, re, im); hi[h] = {(T)re, (T)im}; }
+      chirp_lo_.upload(lo);
+      chirp_hi_.upload(hi);
+      chirp_eval_ = !getenv("FOURIER_CHIRP_TABLE");
+    }
     // w = FFT_M(conj chirp, mirrored) (bluesteins.rs:18-48), evaluated in f64 on the host, with the
     // inner IFFT's 1/M (bluesteins.rs:239 -> mod.rs:383) folded in.
     std::vector<double> wr(m_, 0.0), wi(m_, 0.0);
@@ -1428,7 +1455,9 @@ template <typename T> class Plan {
   bool blu_ = false;
   std::unique_ptr<Pow2Engine<T>> eng_, eng_inv_;  // eng_inv_: mirrored inverse plan of a conv-fused Bluestein
   std::unique_ptr<MixedEngine<T>> mix_;
-  DevBuf xtab_, wtab_;
+  DevBuf xtab_, wtab_, chirp_lo_, chirp_hi_;
+  uint32_t chirp_bits_ = 0;
+  bool chirp_eval_ = false;  // fused Bluestein passes evaluate the chirp (option "bluestein_chirp_eval")
   mutable DevBuf scratch_, work_, hostio_;
   mutable PinnedBuf pinned_;
   mutable hipStream_t legacy_stream_ = nullptr;  // legacy host-buffer calls (exec_host)

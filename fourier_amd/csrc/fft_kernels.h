@@ -192,6 +192,12 @@ struct PassArgs {
   uint32_t nxcd;      // >1: remap blockIdx so that each XCD (blockIdx % nxcd) walks a contiguous tile range
   uint32_t xcd_interleave;  // block -> tile mapping mode, see xcd_remap()
   const void* blu_x;  // Bluestein chirp table x[0..blu_n) (IO_BLU_IN / IO_BLU_OUT)
+  // chirp evaluated in the kernel instead of read from blu_x (the fused passes of the large sizes: the 8-byte-per-point
+  // table read is a quarter of such a pass's memory traffic): x[k] = W_2n^{k^2 mod 2n} = chirp_lo[e & mask] * chirp_hi[e >> bits]
+  const void* chirp_lo;   // W_2n^{e}, e < 2^chirp_bits; null = read blu_x
+  const void* chirp_hi;   // W_2n^{h << chirp_bits}
+  uint32_t chirp_bits;
+  double chirp_two_n, chirp_inv_two_n;
   uint64_t blu_n;     // user transform length (batch stride of the user-side buffer)
   int blu_swap;       // user-level inverse: swap re/im of the user data
   int swap_in, swap_out;
@@ -385,6 +391,33 @@ __device__ __forceinline__ cpx<T> two_level_twiddle(const PassArgs& a, uint64_t 
   const cpx<T>* hi = (const cpx<T>*)a.tw_hi;
   const uint64_t el = e & ((1ull << a.lo_bits) - 1), eh = e >> a.lo_bits;
   return cmul(lo[el], hi[eh]);
+}
+
+// Bluestein chirp x[k] = exp(-i*pi*k^2/n) (bluesteins.rs:9-15,51-61) without the n-entry table: the exponent is reduced
+// exactly, e = k^2 mod 2n (k < 2^26, so k^2 is exact in f64; the quotient estimate is off by at most one), and W_2n^e
+// comes from a two-level table of 2n-th roots (~2 x sqrt(2n) entries, cache-resident) -- one complex multiply and a
+// handful of f64 operations per point instead of 8-16 bytes of table traffic per point.
+template <typename T> __device__ __forceinline__ cpx<T> chirp_at(const PassArgs& a, uint64_t k) {
+  const double kd = (double)(uint32_t)k, sq = kd * kd;
+  const double q = __builtin_floor(sq * a.chirp_inv_two_n);
+  double r = __builtin_fma(-q, a.chirp_two_n, sq);  // exact: both products are integers below 2^53
+  r = r < 0.0 ? r + a.chirp_two_n : (r >= a.chirp_two_n ? r - a.chirp_two_n : r);
+  const uint32_t e = (uint32_t)r;
+  const cpx<T>* lo = (const cpx<T>*)a.chirp_lo;
+  const cpx<T>* hi = (const cpx<T>*)a.chirp_hi;
+  return cmul(lo[e & ((1u << a.chirp_bits) - 1u)], hi[e >> a.chirp_bits]);
+}
+// VEC consecutive chirp values starting at k (table read or evaluated)
+template <typename T> __device__ __forceinline__ Unit16<T> chirp_unit(const PassArgs& a, uint64_t k) {
+  constexpr int VEC = 16 / (2 * (int)sizeof(T));
+  if (!a.chirp_lo) return load_unit<T, false>((const cpx<T>*)a.blu_x + k);
+  Unit16<T> u;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    const cpx<T> c = chirp_at<T>(a, k + (uint64_t)v);
+    u.a[2 * v] = c.re; u.a[2 * v + 1] = c.im;
+  }
+  return u;
 }
 
 // One big-radix Stockham pass over a tile of COLS columns (or COLS whole transforms in ROWS mode).
@@ -591,7 +624,7 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
     for (int r = 0; r < 16; ++r) {
       const uint64_t idx0 = (uint64_t)(th + Q * r) * a.cn + c0 + (uint64_t)(cg * VEC);
       if (idx0 + VEC <= a.blu_n) {  // whole unit inside the user array: one 16-byte load each for data and chirp
-        const Unit16<T> u = load_unit_a8<T>(p + idx0), c = load_unit<T, false>(xt + idx0);
+        const Unit16<T> u = load_unit_a8<T>(p + idx0), c = chirp_unit<T>(a, idx0);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           cpx<T> val{u.a[2 * v], u.a[2 * v + 1]};
@@ -607,7 +640,7 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
         if (idx < a.blu_n) {
           val = p[idx];
           if (a.blu_swap) val = {val.im, val.re};
-          val = cmul(xt[idx], val);
+          val = cmul(a.chirp_lo ? chirp_at<T>(a, idx) : xt[idx], val);
         }
         x[v][r] = val;
       }
@@ -711,7 +744,7 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
     for (int r = 0; r < 16; ++r) {
       const uint64_t idx0 = off + a.s * (uint64_t)(KM * Q * r);
       if (idx0 + VEC <= a.blu_n) {
-        const Unit16<T> c = load_unit<T, false>(xt + idx0);
+        const Unit16<T> c = chirp_unit<T>(a, idx0);
         Unit16<T> u;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
@@ -730,7 +763,7 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
         if (idx < a.blu_n) {
           cpx<T> y = x[v][r];
           if (a.swap_out) y = {y.im, y.re};
-          y = cmul(y, xt[idx]);
+          y = cmul(y, a.chirp_lo ? chirp_at<T>(a, idx) : xt[idx]);
           if (a.blu_swap) y = {y.im, y.re};
           p[idx] = {y.re * scale, y.im * scale};
         }

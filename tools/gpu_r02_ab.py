@@ -89,6 +89,13 @@ def main():
         for opts in ((), (("xcd_swizzle", 3),), (), (("xcd_swizzle", 3),)):
             run("C4", 999983, 512, opts=opts)
         run("N=65537", 65537, 8192)
+    if which in ("chirp",):
+        for rep in range(2):
+            for ev in (1, 0):
+                run("C4", 999983, 512, opts=(("bluestein_chirp_eval", ev),), check=torch_ref)
+                run("N=65537", 65537, 8192, opts=(("bluestein_chirp_eval", ev),))
+                run("N=40000", 40000, 8192, opts=(("bluestein_chirp_eval", ev),))
+                run("C4 f64", 999983, 256, "f64", opts=(("bluestein_chirp_eval", ev),), check=torch_ref)
     if which in ("all", "fused"):
         for real, ks in (("f32", (16, 17, 18)), ("f64", (15, 16, 17))):
             esz = 8 if real == "f32" else 16
