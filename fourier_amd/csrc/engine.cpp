@@ -1383,7 +1383,9 @@ template <typename T> class Plan {
       for (size_t h = 0; h < hi.size(); ++h) { double re, im; unit_root((uint64_t)h << chirp_bits_, two_n, re, im); hi[h] = {(T)re, (T)im}; }
       chirp_lo_.upload(lo);
       chirp_hi_.upload(hi);
-      chirp_eval_ = !getenv("FOURIER_CHIRP_TABLE");
+      // measured SLOWER than reading the table (C4: first pass 4.6 vs 3.3 ms per 512, profiles/r02_s5_chirp_eval_ab.jsonl:
+      // these passes are instruction-bound, not traffic-bound), so off unless asked for (option "bluestein_chirp_eval")
+      chirp_eval_ = getenv("FOURIER_CHIRP_EVAL") != nullptr;
     }
     // w = FFT_M(conj chirp, mirrored) (bluesteins.rs:18-48), evaluated in f64 on the host, with the
     // inner IFFT's 1/M (bluesteins.rs:239 -> mod.rs:383) folded in.
