@@ -419,9 +419,10 @@ template <typename T> class Pow2Engine {
   // (FIRST, MID...), the 3^b part as one final odd-radix Stockham pass -- the reference's own order, radix 3
   // after the powers of two (RADICES = [4,8,4,3,2], autosort/mod.rs:21).
   static bool handles_mixed(size_t n) {
+    const size_t total = n;
     size_t p3 = 1;
-    while (n % 3 == 0 && p3 < 27) { n /= 3; p3 *= 3; }
-    return p3 > 1 && is_pow2(n) && n >= 4096 && n <= ((size_t)1 << 30);
+    while (n % 3 == 0) { n /= 3; p3 *= 3; }
+    return p3 > 1 && is_pow2(n) && n >= 4096 && total <= ((size_t)1 << 30);
   }
 
   // mirror: the pass lengths in reverse order (the inverse inner FFT of a conv-fused Bluestein plan must start
@@ -430,9 +431,9 @@ template <typename T> class Pow2Engine {
   // a mirror image of every length it uses)
   explicit Pow2Engine(size_t n, bool mirror = false, bool plain = false) : n_(n) {
     size_t p3 = 1, p2 = n;
-    while (p2 % 3 == 0 && p3 < 27) { p2 /= 3; p3 *= 3; }
+    while (p2 % 3 == 0) { p2 /= 3; p3 *= 3; }
     if (!is_pow2(p2) || (p3 > 1 && p2 < 4096))
-      throw EngineError(::fourier::c::FOURIER_HIP_INVALID_ARGUMENT, "StockhamEngine: size must be 2^a or 2^a*3^b (a >= 12, b <= 3)");
+      throw EngineError(::fourier::c::FOURIER_HIP_INVALID_ARGUMENT, "StockhamEngine: size must be 2^a or 2^a*3^b (a >= 12)");
     const int k = ilog2(p2);
     std::vector<int> lens;
     KernelInfo tl;
@@ -472,9 +473,10 @@ template <typename T> class Pow2Engine {
       tiny_ = true;
     } else if (k <= 11) {
       lens = {k};
-    } else if (k == 22 && plain && p3 == 1 && (sizeof(T) == 8 ? !getenv("FOURIER_NO_PLAN_4096") : getenv("FOURIER_PLAN_4096") != nullptr)) {
-      // 4096 (first pass on 32-byte-wide tiles) x 1024 instead of 2048 x 2048: f64 27.4 vs 28.9 ms per 512 transforms,
-      // f32 27.3 vs 25.8-26.5 ms per 1024 (profiles/r02_s3_plan4096_conv_and_fused_ab.jsonl) -- so f64 only by default
+    } else if (k == 22 && plain && p3 == 1 && getenv("FOURIER_PLAN_4096")) {
+      // experiment: 4096 (first pass on 32-byte-wide tiles) x 1024 instead of 2048 x 2048.  f32: 27.3 vs 25.8-26.5 ms per
+      // 1024 transforms; f64: 27.4 vs 28.9 ms per 512 but 7.9 vs 7.4 ms per 128 (profiles/r02_s3_*.jsonl,
+      // r02_s4_sizes.jsonl) -- no consistent gain, so the default stays 2048 x 2048
       lens = {12, 10};
     } else if (k <= 22) {
       lens = {(k + 1) / 2, k / 2};
@@ -517,13 +519,22 @@ template <typename T> class Pow2Engine {
       size /= (uint64_t)L;
     }
     if (p3 == 1 && lens.size() == 2 && !mirror) init_l2fused(k);
-    if (p3 > 1) {  // final odd-radix pass: size == R == p3, stride s == 2^a
+    // odd part 3^b as radix-27 passes plus one of radix 3 / 9 / 27: twiddled middle passes, then the final one
+    // (the reference's order, radix 3 after the powers of two: RADICES = [4,8,4,3,2], autosort/mod.rs:21)
+    while (p3 > 1) {
+      const size_t r = p3 > 27 ? 27 : p3;
       auto pass = std::unique_ptr<Pass>(new Pass());
       pass->mode = MODE_ODD_LAST;
-      pass->odd_r = (int)p3;
-      pass->odd_fn = get_odd_kernel<T>((int)p3);
-      pass->s = s; pass->size = size; pass->cn = n / p3;
+      pass->odd_r = (int)r;
+      pass->odd_fn = get_odd_kernel<T>((int)r);
+      pass->s = s; pass->size = size; pass->cn = size / r;  // cn = m of this pass
+      if (size != r) {  // W_size^{e}, e < size (i*k < m*R)
+        std::vector<cpx<T>> tw((size_t)size);
+        for (size_t e = 0; e < (size_t)size; ++e) { double re, im; unit_root(e, size, re, im); tw[e] = {(T)re, (T)im}; }
+        pass->tw_lo.upload(tw);
+      }
       passes_.push_back(std::move(pass));
+      s *= r; size /= r; p3 /= r;
     }
   }
 
@@ -757,12 +768,14 @@ template <typename T> class Pow2Engine {
       if (ps.mode == MODE_ODD_LAST) {
         OddArgs o;
         std::memset(&o, 0, sizeof(o));
-        o.in = src; o.out = dst; o.mul = mul;
+        const bool final_pass = (p + 1 == np);
+        o.in = src; o.out = dst; o.mul = final_pass ? mul : nullptr;
         o.n = n_; o.s = ps.s; o.batch = batch;
-        o.swap_out = inverse; o.scale = scale;
+        o.m = ps.cn; o.tw = ps.tw_lo.p;
+        o.swap_out = final_pass && inverse; o.scale = final_pass ? scale : 1.0;
         for (int e = 0; e < ps.odd_r; ++e) unit_root((uint64_t)e, (uint64_t)ps.odd_r, o.wr[e], o.wi[e]);
         constexpr int VEC = 16 / (2 * (int)sizeof(T));
-        const uint64_t threads = (uint64_t)batch * (ps.s / VEC);
+        const uint64_t threads = (uint64_t)batch * (ps.s / VEC) * ps.cn;
         const uint64_t grid = (threads + 255) / 256;
         if (grid > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");
         PROF_BEGIN(prof, slot);

@@ -25,7 +25,7 @@
 //   tiny_shfl_kernel<T, N>                N <= 16 (f32: 32): one lane per transform, wave-shuffle unit transpose
 //   mixed_radix_kernel_ct<T, N>           2^a*3^b in LDS with the reference's schedule, one instantiation per length
 //   mixed_radix_kernel<T>                 the same, runtime-parameterised (A/B reference)
-//   odd_last_kernel<T, R>                 final radix-3/9/27 pass of the large 2^a*3^b sizes
+//   odd_last_kernel<T, R>                 radix-3/9/27 passes (twiddled middle ones and the final one) of the large 2^a*3^b sizes
 //   blu_pre_kernel / blu_post_kernel      unfused chirp sweeps (option bluestein_fusion = 0)
 #pragma once
 #include <stdint.h>
@@ -1693,7 +1693,9 @@ __global__ void __launch_bounds__(256) mixed_radix_kernel(MixArgs a) {
 // columns j (one 16-byte unit per row) and all R rows: fully coalesced, in place allowed.
 struct OddArgs {
   const void* in; void* out; const void* mul;
-  uint64_t n, s, batch;       // transform length, stride (= n / R), transforms
+  uint64_t n, s, batch;       // transform length, Stockham stride of this pass, transforms
+  uint64_t m;                 // size_cur / R: 1 for the last pass (stride = n / R), > 1 for a twiddled middle pass
+  const void* tw;             // middle passes: W_size_cur^{e}, e < size_cur (size_cur = R * m)
   int swap_out;
   double scale;
   double wr[27], wi[27];      // W_R^e = exp(-2*pi*i*e/R), e < R (f64 on the host, cast on use)
@@ -1929,17 +1931,26 @@ __global__ void __launch_bounds__(256) mixed_radix_kernel_ct(MixArgs a) {
 
 template <typename T, int R>
 __global__ void __launch_bounds__(256) odd_last_kernel(OddArgs a) {
+  // One radix-R (R = 3, 9, 27) Stockham pass at stride s over the odd part of a 2^a*3^b plan (mod.rs:203-284 with the
+  // reference's radix order, the odd radices after the powers of two):
+  //   out[j + R*s*i + s*k] = W_size^{i*k} * DFT_R(in[j + s*i + s*m*k'])_k,  i < m, j < s.
+  // m == 1 is the final pass (no twiddle; scaling / swap / pointwise multiplier applied); m > 1 a middle pass.
+  // One thread per (transform, i, 16-byte unit of j): s is a multiple of 4096, so a wave shares i and reads whole lines.
   constexpr int VEC = 16 / (2 * (int)sizeof(T));
   const uint64_t units = a.s / VEC;                       // 16-byte units per row
   const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= a.batch * units) return;
-  const uint64_t b = gid / units, u = gid - b * units;
-  const cpx<T>* in = (const cpx<T>*)a.in + b * a.n + u * VEC;
-  cpx<T>* out = (cpx<T>*)a.out + b * a.n + u * VEC;
+  const uint64_t per = units * a.m;                       // threads per transform
+  if (gid >= a.batch * per) return;
+  const uint64_t b = gid / per, rem = gid - b * per;
+  const uint64_t i = rem / units, u = rem - i * units;
+  const bool last = (a.m == 1);
+  const cpx<T>* in = (const cpx<T>*)a.in + b * a.n + u * VEC + a.s * i;
+  cpx<T>* out = (cpx<T>*)a.out + b * a.n + u * VEC + (uint64_t)R * a.s * i;
+  const uint64_t in_step = a.s * a.m;
   cpx<T> x[VEC][R];
 #pragma unroll
   for (int k = 0; k < R; ++k) {
-    const Unit16<T> v = load_unit<T, false>(in + (uint64_t)k * a.s);
+    const Unit16<T> v = load_unit<T, false>(in + (uint64_t)k * in_step);
 #pragma unroll
     for (int c = 0; c < VEC; ++c) x[c][k] = {v.a[2 * c], v.a[2 * c + 1]};
   }
@@ -1947,17 +1958,26 @@ __global__ void __launch_bounds__(256) odd_last_kernel(OddArgs a) {
   for (int c = 0; c < VEC; ++c) dft_pow3<T, R, R, 1>(x[c], a);
   const T scale = (T)a.scale;
   const cpx<T>* mul = (const cpx<T>*)a.mul;
+  const cpx<T>* tw = (const cpx<T>*)a.tw;
 #pragma unroll
   for (int k = 0; k < R; ++k) {
     Unit16<T> v;
+    cpx<T> w{(T)1, (T)0};
+    if (!last && k > 0) w = tw[i * (uint64_t)k];          // wave-uniform address
 #pragma unroll
     for (int c = 0; c < VEC; ++c) {
       cpx<T> y = x[c][k];
-      if (mul) y = cmul(y, mul[u * VEC + c + (uint64_t)k * a.s]);
-      if (a.swap_out) y = {y.im, y.re};
-      v.a[2 * c] = y.re * scale; v.a[2 * c + 1] = y.im * scale;
+      if (last) {
+        if (mul) y = cmul(y, mul[u * VEC + c + (uint64_t)k * a.s]);
+        if (a.swap_out) y = {y.im, y.re};
+        y = {y.re * scale, y.im * scale};
+      } else if (k > 0) {
+        y = cmul(y, w);
+      }
+      v.a[2 * c] = y.re; v.a[2 * c + 1] = y.im;
     }
-    store_unit<T, FOURIER_NT_STORE != 0>(out + (uint64_t)k * a.s, v);
+    if (last) store_unit<T, FOURIER_NT_STORE != 0>(out + (uint64_t)k * a.s, v);
+    else store_unit<T, false>(out + (uint64_t)k * a.s, v);
   }
 }
 

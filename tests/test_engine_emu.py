@@ -163,9 +163,11 @@ def test_length_specialised_mixed_kernels_equal_the_generic_one(fa, monkeypatch)
 
 
 def test_large_mixed_radix_sizes_run_natively(fa, oracle):
-    """N = 2^a*3^b (a >= 12, b <= 3): big-radix passes over the 2^a part + one final radix-3^b Stockham pass
-    (the reference's order, RADICES = [4,8,4,3,2]); every code, in and out of place, against the oracle."""
-    for n, want in ((3 * 4096, "64x64x3"), (9 * 8192, "128x64x9"), (27 * 4096, "64x64x27")):
+    """N = 2^a*3^b (a >= 12, any b): big-radix passes over the 2^a part, then the odd part as radix-27 Stockham passes
+    plus one of radix 3 / 9 / 27 -- twiddled middle passes and a final one (the reference's order, RADICES =
+    [4,8,4,3,2]); every code, in and out of place, against the oracle."""
+    for n, want in ((3 * 4096, "64x64x3"), (9 * 8192, "128x64x9"), (27 * 4096, "64x64x27"), (81 * 4096, "64x64x27x3"),
+                    (243 * 4096, "64x64x27x9")):
         x = np.stack([hash_normal(80 + b, n) for b in range(2)])
         for dtype, tl2 in ((np.complex64, 1e-6), (np.complex128, 5e-14)):
             plan = make(fa, n, dtype)
@@ -174,7 +176,7 @@ def test_large_mixed_radix_sizes_run_natively(fa, oracle):
                 ref = oracle.transform_batch(x.astype(dtype), code)
                 assert rel_l2(run_batch(plan, x.astype(dtype), code), ref) <= tl2, (n, code)
                 assert rel_l2(run_batch(plan, x.astype(dtype), code, inplace=True), ref) <= tl2, (n, code)
-    assert "bluestein" in make(fa, 81 * 4096, np.complex64).describe()  # 3^4: beyond the odd pass's radices
+    assert make(fa, 729 * 4096, np.complex64).describe().startswith("stockham 64x64x27x27")
     assert "mixed-radix" in make(fa, 3 * 2048, np.complex128).describe()  # too little 2^a for two tiled passes: LDS kernel
     assert "bluestein" in make(fa, 9 * 2048, np.complex128).describe()   # f64 18432: beyond both native routes
 

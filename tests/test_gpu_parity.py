@@ -174,9 +174,10 @@ def test_mixed_radix_sizes_are_bit_identical_to_the_oracle(torch, fa, oracle):
                                   oracle.transform_batch(x.astype(dtype), 0)), n
 
 
-@pytest.mark.parametrize("n", [3 * 4096, 9 * 4096, 27 * 4096, 3 * (1 << 15), 9 * (1 << 16), 3 * (1 << 18), 27 * (1 << 16), 3 * (1 << 23)])
+@pytest.mark.parametrize("n", [3 * 4096, 9 * 4096, 27 * 4096, 3 * (1 << 15), 9 * (1 << 16), 3 * (1 << 18), 27 * (1 << 16), 3 * (1 << 23),
+                               81 * 4096, 243 * 4096, 729 * (1 << 13), 2187 * 4096, 81 * (1 << 17)])
 def test_large_mixed_radix_sizes_vs_oracle(torch, fa, oracle, n):
-    """2^a*3^b (a >= 12, b <= 3) natively: big-radix passes + a final radix-3^b pass."""
+    """2^a*3^b (a >= 12, any b) natively: big-radix passes over 2^a, then radix-27/9/3 passes (middle ones twiddled)."""
     x = np.stack([hash_uniform(90 + b, n) for b in range(2)])
     for dtype, tl2 in ((np.complex64, 1e-6), (np.complex128, 5e-14)):
         if n > (1 << 24) and dtype == np.complex128:

@@ -38,6 +38,9 @@ if __name__ == "__main__":
     run("mixed 9*2^16", 9 << 16, 1024)
     run("mixed 27*2^14", 27 << 14, 2048)
     run("mixed 3*2^12", 3 << 12, 65536)
+    run("mixed 81*2^12", 81 << 12, 2048)
+    run("mixed 243*2^12", 243 << 12, 1024)
+    run("mixed 729*2^13", 729 << 13, 128)
     run("C5 chunk 2^22", 1 << 22, 1024)
     run("2^21", 1 << 21, 1024)
     run("2^24 3-pass", 1 << 24, 128)
