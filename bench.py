@@ -343,7 +343,8 @@ def main():
 
         # host copy of the parity / CPU-baseline sample, taken before anything can overwrite the input
         if rank == 0 and world == 1 and not args.no_cpu:
-            sample = min(batch, args.cpu_sample or max(8, min(256, 2 * cores)))
+            # ~20-30 s of CPU work with the AVX clone (2.8 ms per transform on one core of the round-2 box, six thread counts)
+            sample = min(batch, args.cpu_sample or 1024)
             hx = x[:sample].cpu().numpy()
         for _ in range(args.warmup):
             step()
