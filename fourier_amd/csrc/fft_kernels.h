@@ -1022,7 +1022,8 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16)
     const cpx<T>* p = in + off;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const Unit16<T> u = load_unit<T, FOURIER_NT_LOAD == 2>(p + (uint64_t)(Q * r) * a.cn);
+      // tiles narrower than a 128-byte line share every line with a sibling workgroup: no streaming hint then
+      const Unit16<T> u = load_unit<T, FOURIER_NT_LOAD == 2 && (CG >= 8)>(p + (uint64_t)(Q * r) * a.cn);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
     }

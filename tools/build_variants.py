@@ -35,6 +35,9 @@ VARIANTS = {
     "split32k": ["-DFOURIER_SPLIT_THRESHOLD=(32*1024)"],
     "split0": ["-DFOURIER_SPLIT_THRESHOLD=0"],
     "fused_mw3": ["-DFOURIER_FUSED_MIN_WAVES=3"],
+    "conv_cg4": ["-DFOURIER_CONV_CG_1024=4"],
+    "conv_cg4_mw3": ["-DFOURIER_CONV_CG_1024=4", "-DFOURIER_CONV_MIN_WAVES(NT)=((NT)==256?3:FOURIER_MIN_WAVES(NT))"],
+    "conv_cg4_mw4": ["-DFOURIER_CONV_CG_1024=4", "-DFOURIER_CONV_MIN_WAVES(NT)=((NT)==256?4:FOURIER_MIN_WAVES(NT))"],
     "conv_stnt": ["-DFOURIER_CONV_ST_NT=1"],
     "conv_wnt": ["-DFOURIER_CONV_W_NT=1"],
     "conv_both": ["-DFOURIER_CONV_ST_NT=1", "-DFOURIER_CONV_W_NT=1"],
