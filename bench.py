@@ -231,8 +231,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the hot path)")
+    # test hook (tests/test_gpu_parity.py): several ranks on a box with fewer GPUs share devices; RCCL refuses two ranks
+    # on one device, so such a run names BENCH_BACKEND=gloo (only the max-over-ranks time goes through the group)
+    if os.environ.get("BENCH_SHARE_DEVICES"):
+        local_rank %= torch.cuda.device_count()
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the timing scalars are reduced
     dist = None
     if world > 1 or os.environ.get("BENCH_FORCE_DIST"):  # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
@@ -245,7 +251,10 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
             dist.barrier()
             torch.cuda.synchronize(dev)
         finally:
@@ -316,8 +325,8 @@ def main():
         torch.cuda.synchronize(dev)
         sync_all()
         wall = time.perf_counter() - t0
-        elapsed = shard.reduce_max_seconds(fft_s, dist, dev)
-        wall = shard.reduce_max_seconds(wall, dist, dev)
+        elapsed = shard.reduce_max_seconds(fft_s, dist, red_dev)
+        wall = shard.reduce_max_seconds(wall, dist, red_dev)
         extra["wall_ms_per_step_incl_regen"] = round(wall / args.steps * 1e3, 3)
         workload = (f"batched 1D c2c {dtype} N={n} GLOBAL batch={gbatch} batch-sharded over {world} GPU(s) "
                     f"({hi - lo} per GPU as resident chunks of {chunk}, regenerated on the device), forward "
@@ -354,7 +363,7 @@ def main():
             step()
         torch.cuda.synchronize(dev)
         sync_all()
-        elapsed = shard.reduce_max_seconds(time.perf_counter() - t0, dist, dev)
+        elapsed = shard.reduce_max_seconds(time.perf_counter() - t0, dist, red_dev)
         workload = (f"batched 1D c2c {dtype} N={n} batch={batch}/GPU forward "
                     f"{'in-place' if args.inplace else 'out-of-place'} ({cfg['name']})")
         config = {"workload": workload, "n": n, "batch_per_gpu": batch, "global_batch": world * batch,

@@ -441,6 +441,38 @@ def test_two_devices_driven_from_two_host_threads_in_one_process(torch, fa, orac
         pytest.skip("one GPU visible: ran both shards on cuda:0 (two plans, two threads, two streams)")
 
 
+def test_bench_strong_scaling_path_with_two_ranks(torch, fa, tmp_path):
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one rank per GPU): BASELINE
+    configs[4] with the global batch split over the ranks, "scaling": "strong", one JSON line from rank 0.  With two
+    GPUs it runs over RCCL; on a one-GPU box the two ranks share cuda:0 (BENCH_SHARE_DEVICES) and, because RCCL refuses
+    two ranks on one device, the group is gloo -- the data path has no collective either way.  A reduced global batch
+    keeps it short; the plan, chunking, sharding and JSON contract are the full-size ones."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    two = torch.cuda.device_count() >= 2
+    if not two:
+        env.update(BENCH_SHARE_DEVICES="1", BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "1536", "--chunk", "256"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines  # exactly one JSON line on stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 2
+    assert out["config"]["global_batch"] == 1536 and out["config"]["batch_per_gpu"] == 768 and out["config"]["n"] == 1 << 22
+    assert "BASELINE configs[4]" in out["config"]["workload"]
+    assert out["parity"]["rel_l2_vs_oracle"] <= 1e-6
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0.3
+    # value = whole job: global batch * 5 N log2 N / max-over-ranks FFT time
+    assert abs(out["value"] - 1536 * 5 * (1 << 22) * 22 / (out["ms_per_step"] * 1e-3) / 1e9) / out["value"] < 1e-3
+
+
 def test_device_and_overlap_checks_of_the_operator_layer(torch, fa):
     plan = fa.create_fft_f32(256, 0)
     assert plan.device == 0
