@@ -54,6 +54,11 @@ struct EngineError : std::runtime_error {
   } while (0)
 #endif
 
+// kernels that use more than 48 KiB of dynamic LDS must say so once
+static void raise_smem_limit(const void* fn, size_t smem) {
+  if (smem > 48 * 1024) HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+}
+
 // ---------------------------------------------------------------------------------------------
 // device memory RAII
 struct DevBuf {
@@ -551,14 +556,7 @@ template <typename T> class Pow2Engine {
     pass.tw_lo.upload(lo);
     pass.tw_hi.upload(hi);
   }
-  static void set_smem_attribute(const KernelInfo& k) {
-#ifndef FOURIER_EMU
-    if (k.smem > 48 * 1024)
-      HIP_CHECK(hipFuncSetAttribute((const void*)k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.smem));
-#else
-    (void)k;
-#endif
-  }
+  static void set_smem_attribute(const KernelInfo& k) { raise_smem_limit((const void*)k.fn, k.smem); }
 
   // Whole-Bluestein-in-one-launch (bluestein_small_kernel) is available when this (inner) plan is a
   // one-launch two-level plan: it additionally needs the inter-pass table of the role-swapped L2 x L1 problem.
@@ -610,10 +608,7 @@ template <typename T> class Pow2Engine {
     if (passes_.size() != 2 || passes_[0]->k.L != fi.L1 || passes_[1]->k.L != fi.L2) return;
     if ((n_ / fi.L1) % (size_t)fi.COLS_A != 0 || (size_t)fi.L1 % (size_t)fi.COLS_B != 0) return;
     fused_ = fi;
-#ifndef FOURIER_EMU
-    if (fused_.smem > 48 * 1024)
-      HIP_CHECK(hipFuncSetAttribute((const void*)fused_.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_.smem));
-#endif
+    raise_smem_limit((const void*)fused_.fn, fused_.smem);
     int per_cu = 0, cus = 0, dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
     HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_.fn, fused_.NT, fused_.smem));
@@ -677,11 +672,7 @@ template <typename T> class Pow2Engine {
     f.k_blu = get_kernel<T>(f.k.L, MODE_FIRST, IO_BLU_IN);
     l.k_blu = get_kernel<T>(l.k.L, MODE_LAST, IO_BLU_OUT);
     f.has_blu = l.has_blu = true;
-#ifndef FOURIER_EMU
-    for (Pass* p : {&f, &l})
-      if (p->k_blu.smem > 48 * 1024)
-        HIP_CHECK(hipFuncSetAttribute((const void*)p->k_blu.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->k_blu.smem));
-#endif
+    for (Pass* p : {&f, &l}) set_smem_attribute(p->k_blu);
   }
 
   size_t size() const { return n_; }
@@ -964,10 +955,7 @@ template <typename T> class MixedEngine {
     }
     smem_ = nbuf_ * (size_t)group_ * n * sizeof(cpx<T>);
     if (smem_ > 144 * 1024) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "mixed-radix length needs the per-length kernel");
-#ifndef FOURIER_EMU
-    if (smem_ > 48 * 1024)
-      HIP_CHECK(hipFuncSetAttribute((const void*)fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_));
-#endif
+    raise_smem_limit((const void*)fn_, smem_);
   }
   std::string describe() const {
     static const int radices[5] = {4, 8, 4, 3, 2};
