@@ -351,6 +351,22 @@ def test_xcd_fused_one_launch_plan_equals_the_two_launch_plan(torch, fa, oracle,
             assert torch.equal(torch.view_as_real(a[:nb]), torch.view_as_real(b[:nb])), (k, nb)
         ref = oracle.transform_batch(x[:2].cpu().numpy(), oracle.FFT)
         assert rel_l2(b[:2].cpu().numpy(), ref) <= tl2, k
+        # the inter-workgroup hand-offs under UNEVEN load: a second stream keeps part of the chip busy with copies
+        # while the fused plan runs (workgroups then progress at different speeds); every word must still match
+        side = torch.cuda.Stream()
+        noise_src = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+        noise_dst = torch.empty_like(noise_src)
+        two.transform(x, a, fa.Transform.Fft)
+        torch.cuda.synchronize()
+        for rep in range(3):
+            b.fill_(float("nan"))
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    noise_dst[rep::7].copy_(noise_src[rep::7], non_blocking=True)  # strided: many small, slow workgroups
+            one.transform(x, b, fa.Transform.Fft)
+            torch.cuda.synchronize()
+            assert torch.equal(torch.view_as_real(a), torch.view_as_real(b)), (k, "under load", rep)
+        del noise_src, noise_dst
         with pytest.raises(fa.FourierError):
             make(fa, 1 << 20, dtype).set_option("l2_fused", 1)  # the intermediate must fit the XCD's L2
         del x, a, b, z

@@ -430,3 +430,77 @@ extern "C" int mb_l2x(const void* A, void* B, void* S, void* xcc, uint64_t bytes
                                                                  fp_bytes_per_xcd / 16, mode, store_fl, load_fl, xshift);
   return (int)hipGetLastError();
 }
+
+// ---- register-resident transform model (the only on-chip home big enough for a 2^20-point f32 transform: an XCD's
+// registers).  64 persistent workgroups per XCD (2 per CU, 512 threads, a 128 KiB tile each = one 8 MiB transform per
+// XCD).  Per transform: every workgroup streams its tile in from A, the team does an all-to-all in `rounds` rounds
+// through a double-buffered L2 window (per round: 128 KiB / rounds per workgroup written with plain stores, ONE
+// XCD-wide barrier, the same amount read back from another workgroup's region with sc1 loads into the same
+// registers), then streams the tile out to B.  No arithmetic, no LDS exchange: an upper bound for a fused 2^20 FFT
+// that keeps the transform in registers.  Teams form by hardware XCC id (ticket per XCD); an XCD that does not get
+// exactly 64 workgroups, or a barrier that does not complete, raises ctrl[1023] and everybody bails (bounded spins).
+__global__ void __launch_bounds__(512, 4) k_regx(const v4u* __restrict__ A, v4u* __restrict__ B, v4u* __restrict__ S, unsigned* ctrl,
+                                                 uint64_t ntransforms, int rounds) {
+  extern __shared__ unsigned char pad_lds[];
+  __shared__ unsigned bc[2];
+  const int tid = threadIdx.x;
+  const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7;
+  unsigned* abort_flag = ctrl + 1023;
+  unsigned* ticket = ctrl + xcc * 32;
+  unsigned* ctr = ctrl + xcc * 32 + 16;
+  if (tid == 0) bc[0] = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const unsigned w = bc[0];
+  if (w >= 64) { if (tid == 0) __hip_atomic_store(abort_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+  const int upr = 16 / rounds;                              // 16-byte units per thread per round
+  v4u* W = S + (uint64_t)xcc * (2 * 64 * 8192 / rounds);    // two buffers of 64 regions of (8192 / rounds) units
+  unsigned phase = 0;
+  for (uint64_t t = xcc; t < ntransforms; t += 8) {
+    const v4u* a = A + t * (64 * 8192) + (uint64_t)w * 8192 + tid;
+    v4u v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = __builtin_nontemporal_load(a + r * 512);
+    for (int r = 0; r < rounds; ++r) {
+      v4u* wr = W + (uint64_t)(phase & 1) * (64 * 8192 / rounds) + (uint64_t)w * (8192 / rounds) + tid;
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (u / upr == r) wr[(u % upr) * 512] = v[u];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = 64u * (phase + 1);
+        unsigned spins = 0, ok = 1;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1u << 21) || ((spins & 255) == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = 0;
+            break;
+          }
+        }
+        bc[1] = ok;
+      }
+      __syncthreads();
+      if (!bc[1]) return;
+      const unsigned src = (w + 8u * (unsigned)r + 5u) & 63u;  // another workgroup's region of this round
+      const v4u* rd = W + (uint64_t)(phase & 1) * (64 * 8192 / rounds) + (uint64_t)src * (8192 / rounds) + tid;
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (u / upr == r) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[u]) : "v"(rd + (u % upr) * 512) : "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ++phase;
+    }
+    v4u* b = B + t * (64 * 8192) + (uint64_t)w * 8192 + tid;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(v[r], b + r * 512);
+  }
+  (void)pad_lds;
+}
+extern "C" int mb_regx(const void* A, void* B, void* S, void* ctrl, uint64_t bytes, int rounds, int lds_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  hipMemsetAsync(ctrl, 0, 1024 * 4, st);
+  hipFuncSetAttribute((const void*)k_regx, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  k_regx<<<512, 512, lds_bytes, st>>>((const v4u*)A, (v4u*)B, (v4u*)S, (unsigned*)ctrl, bytes / (8 << 20), rounds);
+  return (int)hipGetLastError();
+}

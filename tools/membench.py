@@ -80,6 +80,19 @@ def main():
                     emit(tag="l2x", mode=mname, ring_kib_per_xcd=fp_kib, store=("plain", "sc1", "nt")[sfl], load=("plain", "sc1", "nt")[lfl],
                          read_from_xcd_plus=xshift, ms=round(t * 1e3, 3), alg_tbps=round(2 * big / t / 1e12, 3), us_per_8MiB=round(t / (big / (8 << 20)) * 1e6, 3))
         return
+    L.mb_regx.argtypes = [vp, vp, vp, vp, u64, ci, ci, vp]
+    if "--regx" in sys.argv:
+        # register-resident 2^20 model: one transform per XCD held in the registers of 64 workgroups, all-to-all through
+        # a small double-buffered L2 window in `rounds` rounds with one XCD-wide barrier each, no arithmetic
+        S = torch.empty(8 * (16 << 20), dtype=torch.uint8, device=dev)  # rounds = 1 needs 2 x 8 MiB per XCD
+        ctrl = torch.zeros(1024, dtype=torch.int32, device=dev)
+        for rounds in (1, 2, 4, 8, 16):
+            t = timeit(lambda: L.mb_regx(a.data_ptr(), b.data_ptr(), S.data_ptr(), ctrl.data_ptr(), big, rounds, 69632, st), reps=3, warm=1)
+            torch.cuda.synchronize()
+            tick = ctrl.cpu().numpy()
+            emit(tag="regx", rounds=rounds, window_kib_per_xcd=2 * 8192 // rounds, ms=round(t * 1e3, 3), alg_tbps=round(2 * big / t / 1e12, 3),
+                 us_per_transform=round(t / (big / (8 << 20)) * 1e6, 3), abort_flag=int(tick[1023]), wgs_per_xcd=[int(tick[x * 32]) for x in range(8)])
+        return
     if "--stride" in sys.argv:
         nt = 1024  # transforms of 8 MiB payload
         for sru, dru in ((512, 512), (520, 512), (512, 520), (520, 520), (528, 528), (576, 576), (1024, 1024), (1032, 1032), (2048, 2048), (640, 640)):
