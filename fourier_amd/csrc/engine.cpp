@@ -1353,7 +1353,11 @@ template <typename T> class Plan {
     if (n_ > ((size_t)1 << 26)) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "Bluestein sizes above 2^26 are not supported");
     m_ = 1;
     while (m_ < 2 * n_ - 1) m_ <<= 1;  // bluesteins.rs:110
-    eng_.reset(new Pow2Engine<T>(m_));
+    // forward inner plan: the larger pass first (2048 x 1024 at M = 2^21), so the conv kernel runs at the SHORTER length
+    // and the end passes at the longer one.  FOURIER_BLU_SHORT_FIRST=1 (experiment) swaps the roles: 1024 x 2048 forward,
+    // end passes of length 1024, conv kernel at 2048.
+    const bool short_first = getenv("FOURIER_BLU_SHORT_FIRST") != nullptr;
+    eng_.reset(new Pow2Engine<T>(m_, short_first));
     eng_->enable_bluestein_fusion();
     fused_ = eng_->can_fuse_bluestein();
     small_fused_ = eng_->enable_bluestein_small();
@@ -1362,7 +1366,7 @@ template <typename T> class Plan {
       // lengths read the same in both directions, otherwise its mirror image
       eng_->enable_conv();
       if (!eng_->palindromic()) {
-        eng_inv_.reset(new Pow2Engine<T>(m_, true));
+        eng_inv_.reset(new Pow2Engine<T>(m_, !short_first));
         eng_inv_->enable_bluestein_fusion();
       }
       conv_ = conv_ok_ = true;

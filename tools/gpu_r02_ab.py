@@ -89,6 +89,11 @@ def main():
         for opts in ((), (("xcd_swizzle", 3),), (), (("xcd_swizzle", 3),)):
             run("C4", 999983, 512, opts=opts)
         run("N=65537", 65537, 8192)
+    if which in ("blu_order",):
+        for env in (None, {"FOURIER_BLU_SHORT_FIRST": "1"}, None, {"FOURIER_BLU_SHORT_FIRST": "1"}):
+            run("C4", 999983, 512, env=env, check=torch_ref)
+            run("N=40000", 40000, 8192, env=env)
+            run("C4 f64", 999983, 256, "f64", env=env)
     if which in ("chirp",):
         for rep in range(2):
             for ev in (1, 0):
