@@ -583,3 +583,21 @@ def test_l2048_narrow_first_pass_and_split_last_pass(fa, oracle, monkeypatch):
             assert rel_l2(ys, yo) < 3e-7 and np.array_equal(run_batch(split, x, 0, inplace=True), ys)
         else:
             assert np.array_equal(ys, yo)  # no last pass of length 2048 in this plan
+
+
+def test_empty_batch_is_a_successful_no_op_for_every_plan_family(fa):
+    """batch = 0 through the batched entry points (device-resident, host-streamed, reserve): returns OK, launches
+    nothing, touches no byte -- for every plan family, including the opt-in XCD-fused one."""
+    from fourier_amd import _lib
+
+    L = _lib.lib()
+    for n, opts in ((8, ()), (1024, ()), (4096, ()), (1 << 16, ()), (1 << 16, (("l2_fused", 1),)), (96, ()), (3 * 4096, ()), (100, ()), (40000, ())):
+        plan = make(fa, n, np.complex64)
+        for k, v in opts:
+            plan.set_option(k, v)
+        buf = np.full(n, 7 + 7j, np.complex64)
+        assert L.fourier_hip_transform_batch_float(plan._h, buf.ctypes.data, buf.ctypes.data, 0, 0, None) == 0, n
+        assert L.fourier_hip_transform_batch_host_float(plan._h, buf.ctypes.data, buf.ctypes.data, 0, 0) == 0, n
+        assert L.fourier_hip_reserve_float(plan._h, 0, 1) == 0, n
+        assert L.fourier_hip_last_status_float(plan._h) == 0
+        assert (buf == 7 + 7j).all(), n

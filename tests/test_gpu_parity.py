@@ -765,3 +765,13 @@ def test_error_behaviour(torch, fa):
                        torch.zeros(12, dtype=torch.complex64, device="cuda"), fa.Transform.Fft)
     with pytest.raises(TypeError):
         plan.fft_in_place(torch.zeros(8, dtype=torch.complex128, device="cuda"))
+    # empty batch: a successful no-op for every plan family
+    for n, opts in ((8, ()), (4096, ()), (1 << 16, ()), (1 << 16, (("l2_fused", 1),)), (96, ()), (3 * 4096, ()), (100, ()), (40000, ())):
+        p = fa.create_fft_f32(n)
+        for k, v in opts:
+            p.set_option(k, v)
+        buf = torch.full((n,), 7 + 7j, dtype=torch.complex64, device="cuda")
+        assert L.fourier_hip_transform_batch_float(p._h, buf.data_ptr(), buf.data_ptr(), 0, 0, None) == 0, n
+        assert L.fourier_hip_reserve_float(p._h, 0, 1) == 0
+        torch.cuda.synchronize()
+        assert bool((buf == 7 + 7j).all()), n
