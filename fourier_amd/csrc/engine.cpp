@@ -855,7 +855,8 @@ template <typename T> class Pow2Engine {
     // this kernel (only) reads a per-transform table indexed like the data, the transformed chirp: let every XCD own an
     // eighth of the TILES of every transform, so that its 1/8 of the table (2 MiB of 16 at M = 2^21) stays in its L2
     // (with streaming stores: conv 4.5 vs 4.75 ms per 512 at C4; the plain passes lose 10-15 % under this order)
-    if (a.nxcd == 8 && a.xcd_interleave == 0 && a.tiles % 8 == 0 && !getenv("FOURIER_CONV_XCD_PLAIN")) a.xcd_interleave = 2;
+    static const bool sliced = getenv("FOURIER_CONV_XCD_PLAIN") == nullptr;  // development switch, read once
+    if (sliced && a.nxcd == 8 && a.xcd_interleave == 0 && a.tiles % 8 == 0) a.xcd_interleave = 2;
     a.scale = 1.0;
     const uint64_t grid = (uint64_t)batch * a.tiles;
     if (grid > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");
