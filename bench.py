@@ -24,8 +24,9 @@ Extra objects in the JSON line:
                    rocprofv3 PMC pass (profiles/traffic_latest.json) or null.
   cpu_baseline  -- the oracle (CPU restatement of the reference, kind "port") timed on this box's host
                    cores on a bounded sample of the same workload (rank 0, N=1 only).
-  other_configs -- (N=1, default config only) a few seconds each on C3, C4 and one C5 chunk after the
-                   headline timing: ms, algorithmic fraction, dominant-kernel fraction.
+  other_configs -- (N=1, default config only) a few seconds each on C1 (one N=4096 transform per call through the
+                   host-slice API, beside the CPU port), C3, C4 and one C5 chunk after the headline timing: ms,
+                   algorithmic fraction, dominant-kernel fraction.
 """
 import argparse
 import json
@@ -158,6 +159,38 @@ def quick_config(fourier_amd, torch, dev, key, reps=3):
     del x, y, plan
     torch.cuda.empty_cache()
     return out
+
+
+def config_c1(fourier_amd):
+    """BASELINE configs[0]: ONE f32 N=4096 forward transform through the reference-compatible host-slice API
+    (`Fft::transform` on host memory = fourier_transform_float: H2D + kernels + D2H inside the library, synchronous),
+    beside the oracle (the reference's CPU path restated, AVX clone) on one core.  Plumbing + latency, not throughput."""
+    import numpy as np
+    from fourier_amd import Transform
+    from oracle import oracle as O
+
+    n = 4096
+    rng = np.random.default_rng(1)
+    x = (rng.random(n) + 1j * rng.random(n)).astype(np.complex64)
+    y = np.empty_like(x)
+    plan = fourier_amd.create_fft_f32(n)
+    for _ in range(20):
+        plan.transform(x, y, Transform.Fft)
+    reps = 500
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        plan.transform(x, y, Transform.Fft)
+    gpu_us = (time.perf_counter() - t0) / reps * 1e6
+    orc = O.OracleFft(n, np.complex64)
+    ref = orc.transform(x, O.FFT)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        orc.transform(x, O.FFT)
+    cpu_us = (time.perf_counter() - t0) / reps * 1e6
+    err = float(np.linalg.norm(y.astype(np.complex128) - ref) / np.linalg.norm(ref))
+    return {"workload": "BASELINE configs[0]: f32 N=4096, one forward transform per call on HOST buffers (legacy ABI, PCIe inclusive)",
+            "plan": plan.describe(), "gpu_us_per_call": round(gpu_us, 2), "cpu_port_one_core_us_per_call": round(cpu_us, 2),
+            "rel_l2_vs_oracle": err, "tolerance": 1e-6}
 
 
 def cpu_baseline(torch, plan, hx, n, dtype, dev, stream, cores):
@@ -430,6 +463,10 @@ def main():
             del x, y
             torch.cuda.empty_cache()
             others = {}
+            try:
+                others["c1"] = config_c1(fourier_amd)
+            except Exception as e:
+                others["c1"] = {"error": repr(e)}
             for k in ("c3", "c4", "c5"):
                 try:
                     others[k] = quick_config(fourier_amd, torch, dev, k)
