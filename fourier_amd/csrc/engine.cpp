@@ -486,6 +486,11 @@ template <typename T> class Pow2Engine {
       // 1024 transforms; f64: 27.4 vs 28.9 ms per 512 but 7.9 vs 7.4 ms per 128 (profiles/r02_s3_*.jsonl,
       // r02_s4_sizes.jsonl) -- no consistent gain, so the default stays 2048 x 2048
       lens = {12, 10};
+    } else if (k == 23 && plain && p3 == 1 && (sizeof(T) == 4 ? !getenv("FOURIER_THREE_PASS_2P23") : getenv("FOURIER_TWO_PASS_2P23") != nullptr)) {
+      // 2^23 = 4096 x 2048: two HBM round trips (first pass of length 4096 on 32-byte-wide tiles, 16-column last pass of
+      // length 2048) instead of three at 256 x 256 x 128.  f32: 27.4-30.0 vs 34.1-34.8 ms per 512 transforms (default);
+      // f64: 30.8-35.2 vs 33.5-33.8 ms per 256, no consistent gain (opt-in) -- profiles/r02_s16_plan_2p23_ab.jsonl
+      lens = {12, 11};
     } else if (k <= 22) {
       lens = {(k + 1) / 2, k / 2};
     } else if (k <= 30) {

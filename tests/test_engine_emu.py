@@ -289,16 +289,23 @@ def test_random_sizes_batches_codes_vs_oracle(fa, oracle):
             assert rel_l2(got, ref) <= tol, (n, plan.describe(), batch, code, inplace, rel_l2(got, ref))
 
 
-def test_three_pass_plan(fa):
-    # 2^23 = 256 x 256 x 128: exercises the middle (uniform-twiddle) pass
+def test_three_pass_plan(fa, monkeypatch):
+    """2^23: by default two passes, 4096 (32-byte-wide first-pass tiles) x 2048; FOURIER_THREE_PASS_2P23=1 keeps the
+    256 x 256 x 128 plan, which exercises the middle (uniform-twiddle) pass every size from 2^24 up uses."""
     n = 1 << 23
-    plan = make(fa, n, np.complex64)
-    assert "256x256x128" in plan.describe()
     rng = np.random.default_rng(7)
     x = (rng.standard_normal(n, np.float32) + 1j * rng.standard_normal(n, np.float32)).astype(np.complex64)[None, :]
     ref = np.fft.fft(x[0].astype(np.complex128))
-    assert rel_l2(run_batch(plan, x, 0)[0], ref) <= 1e-6
-    assert rel_l2(run_batch(plan, x, 0, inplace=True)[0], ref) <= 1e-6
+    monkeypatch.setenv("FOURIER_THREE_PASS_2P23", "1")
+    three = make(fa, n, np.complex64)
+    monkeypatch.delenv("FOURIER_THREE_PASS_2P23")
+    assert "256x256x128" in three.describe()
+    assert rel_l2(run_batch(three, x, 0)[0], ref) <= 1e-6
+    assert rel_l2(run_batch(three, x, 0, inplace=True)[0], ref) <= 1e-6
+    two = make(fa, n, np.complex64)
+    assert "4096x2048" in two.describe()
+    assert rel_l2(run_batch(two, x, 0)[0], ref) <= 1e-6
+    assert rel_l2(run_batch(two, x, 0, inplace=True)[0], ref) <= 1e-6
 
 
 def test_chunking_and_scratch_options_do_not_change_results(fa):

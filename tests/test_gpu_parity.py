@@ -243,14 +243,25 @@ def test_random_sizes_batches_codes_vs_oracle(torch, fa, oracle):
             assert rel_l2(got, ref) <= tol, (n, plan.describe(), batch, code, inplace, rel_l2(got, ref))
 
 
-def test_three_pass_size(torch, fa):
+def test_three_pass_size(torch, fa, monkeypatch):
+    """2^23 both ways: the default two-pass plan 4096 x 2048 and the three-pass plan 256 x 256 x 128
+    (FOURIER_THREE_PASS_2P23=1), f32 and f64."""
     n = 1 << 23
-    plan = make(fa, n, np.complex64)
     rng = np.random.default_rng(7)
-    x = (rng.standard_normal(n, np.float32) + 1j * rng.standard_normal(n, np.float32)).astype(np.complex64)[None, :]
-    ref = np.fft.fft(x[0].astype(np.complex128))
-    assert rel_l2(gpu_batch(torch, fa, plan, x, 0)[0], ref) <= 1e-6
-    assert rel_l2(gpu_batch(torch, fa, plan, x, 0, inplace=True)[0], ref) <= 1e-6
+    for dtype, tol in ((np.complex64, 1e-6), (np.complex128, 5e-14)):
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(dtype)[None, :]
+        ref = np.fft.fft(x[0].astype(np.complex128))
+        monkeypatch.setenv("FOURIER_THREE_PASS_2P23", "1")
+        three = make(fa, n, dtype)
+        monkeypatch.delenv("FOURIER_THREE_PASS_2P23")
+        monkeypatch.setenv("FOURIER_TWO_PASS_2P23", "1")  # f64: the two-pass plan is opt-in (no consistent gain)
+        two = make(fa, n, dtype)
+        monkeypatch.delenv("FOURIER_TWO_PASS_2P23")
+        assert "256x256x128" in three.describe() and "4096x2048" in two.describe()
+        assert ("4096x2048" if dtype == np.complex64 else "256x256x128") in make(fa, n, dtype).describe()
+        for plan in (three, two):
+            assert rel_l2(gpu_batch(torch, fa, plan, x, 0)[0], ref) <= tol
+            assert rel_l2(gpu_batch(torch, fa, plan, x, 0, inplace=True)[0], ref) <= tol
 
 
 def _full_size_properties(torch, fa, oracle, n, batch, dtype, tl2, chunk_bytes=None):

@@ -89,6 +89,10 @@ def main():
         for opts in ((), (("xcd_swizzle", 3),), (), (("xcd_swizzle", 3),)):
             run("C4", 999983, 512, opts=opts)
         run("N=65537", 65537, 8192)
+    if which in ("p23",):
+        for env in ({"FOURIER_THREE_PASS_2P23": "1"}, None, {"FOURIER_THREE_PASS_2P23": "1"}, None):
+            run("2^23", 1 << 23, 512, env=env, check=torch_ref)
+            run("2^23 f64", 1 << 23, 256, "f64", env=env, check=torch_ref)
     if which in ("blu_order",):
         for env in (None, {"FOURIER_BLU_SHORT_FIRST": "1"}, None, {"FOURIER_BLU_SHORT_FIRST": "1"}):
             run("C4", 999983, 512, env=env, check=torch_ref)
