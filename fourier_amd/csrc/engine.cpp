@@ -708,9 +708,6 @@ template <typename T> class Pow2Engine {
     const void* xtab = nullptr;
     uint64_t n = 0;
     int swap = 0;
-    const void* chirp_lo = nullptr;  // non-null: evaluate the chirp in the kernel (two-level table of 2n-th roots)
-    const void* chirp_hi = nullptr;
-    uint32_t chirp_bits = 0;
   };
 
   void run(const cpx<T>* in, cpx<T>* out, cpx<T>* scratch, size_t batch, bool inverse, double scale, const cpx<T>* mul,
@@ -720,7 +717,7 @@ template <typename T> class Pow2Engine {
     // N = 16 (and f32 N = 32) also run one lane per transform; their ROWS pass only serves Bluestein M = 16 / 32
     const bool lane_per_transform = tiny_ || n_ == 16 || (n_ == 32 && sizeof(T) == 4);
     if (lane_per_transform && blu.io == IO_PLAIN) {
-      TinyArgs a{in, out, mul, (uint64_t)batch, (int)n_, inverse, inverse, scale};
+      TinyArgs a{in, out, (uint64_t)batch, (int)n_, inverse, inverse, scale};
       PROF_BEGIN(prof, slot0);
       void (*fn)(TinyArgs) = n_ == 32 ? &tiny_shfl_kernel<T, (sizeof(T) == 4 ? 32 : 16)>
                              : n_ == 16 ? &tiny_shfl_kernel<T, 16>
@@ -729,6 +726,7 @@ template <typename T> class Pow2Engine {
                              : n_ == 2 ? &tiny_shfl_kernel<T, 2> : &tiny_dft_kernel<T>;
       FOURIER_LAUNCH(fn, (batch + 255) / 256, 256, 0, stream, a);
       PROF_END(prof);
+      apply_mul(out, batch, mul, inverse, scale, stream);
       return;
     }
     if (l2fused_enabled() && blu.io == IO_PLAIN && !mul) {
@@ -754,12 +752,24 @@ template <typename T> class Pow2Engine {
       dst[np - 1] = out;
     }
     for (size_t p = 0; p < np; ++p)
-      launch_pass(p, src[p], dst[p], batch, inverse, scale, mul, stream, prof, slot0 + (int)p, nxcd, blu);
+      launch_pass(p, src[p], dst[p], batch, inverse, scale, stream, prof, slot0 + (int)p, nxcd, blu);
+    apply_mul(out, batch, mul, inverse, scale, stream);
+  }
+
+  // Pointwise multiplier on the M-point spectrum of a forward, unscaled transform (bluesteins.rs:236-239): its own sweep.
+  // Only the unfused Bluestein options take it (bluestein_fusion = 0, bluestein_conv = 0); the default plans multiply
+  // inside fft_conv_kernel / the one-launch kernels.  Untimed by profile(): those options exist for A/B and tests.
+  void apply_mul(cpx<T>* out, size_t batch, const cpx<T>* mul, bool inverse, double scale, hipStream_t stream) const {
+    if (!mul) return;
+    if (inverse || scale != 1.0) throw EngineError(::fourier::c::FOURIER_HIP_INVALID_ARGUMENT, "pointwise multiplier: forward unscaled only");
+    BluArgs m{nullptr, out, mul, (uint64_t)n_, (uint64_t)n_, (uint64_t)batch, 0, 1.0};
+    const size_t blocks = (batch * n_ + 255) / 256;
+    FOURIER_LAUNCH(&blu_mul_kernel<T>, std::min<size_t>(std::max<size_t>(blocks, 1), 256 * 32), 256, 0, stream, m);
   }
 
   // One pass of the schedule.  inverse / scale / mul take effect on the passes they belong to (leading swap on
   // pass 0, trailing swap + scale + pointwise multiplier on the last pass).
-  void launch_pass(size_t p, const cpx<T>* src, cpx<T>* dst, size_t batch, bool inverse, double scale, const cpx<T>* mul,
+  void launch_pass(size_t p, const cpx<T>* src, cpx<T>* dst, size_t batch, bool inverse, double scale,
                    hipStream_t stream, Profiler* prof, int slot, unsigned nxcd, BluIO blu = BluIO()) const {
     const size_t np = passes_.size();
     {
@@ -768,7 +778,7 @@ template <typename T> class Pow2Engine {
         OddArgs o;
         std::memset(&o, 0, sizeof(o));
         const bool final_pass = (p + 1 == np);
-        o.in = src; o.out = dst; o.mul = final_pass ? mul : nullptr;
+        o.in = src; o.out = dst;
         o.n = n_; o.s = ps.s; o.batch = batch;
         o.m = ps.cn; o.tw = ps.tw_lo.p;
         o.swap_out = final_pass && inverse; o.scale = final_pass ? scale : 1.0;
@@ -788,7 +798,6 @@ template <typename T> class Pow2Engine {
       a.tw1 = ps.st->tw1.p; a.tw2 = ps.st->tw2.p;
       if (ps.mode == MODE_TWOLEVEL) a.tw2 = ps.st2->tw1.p;
       a.tw_lo = ps.tw_lo.p; a.tw_hi = ps.tw_hi.p; a.tw_half = ps.tw_half.p;
-      a.mul = (p + 1 == np) ? mul : nullptr;
       a.n = n_; a.cn = ps.cn; a.s = ps.s;
       a.lo_bits = ps.lo_bits;
       a.nxcd = nxcd & 0xff;
@@ -796,8 +805,6 @@ template <typename T> class Pow2Engine {
       const bool blu_here = ps.has_blu && ((blu.io == IO_BLU_IN && p == 0) || (blu.io == IO_BLU_OUT && p + 1 == np));
       if (blu_here) {
         a.blu_x = blu.xtab; a.blu_n = blu.n; a.blu_swap = blu.swap;
-        a.chirp_lo = blu.chirp_lo; a.chirp_hi = blu.chirp_hi; a.chirp_bits = blu.chirp_bits;
-        a.chirp_two_n = 2.0 * (double)blu.n; a.chirp_inv_two_n = 1.0 / a.chirp_two_n;
       }
       const KernelInfo& kk = blu_here ? ps.k_blu : ps.k;
       a.swap_in = (p == 0) && inverse;
@@ -1094,7 +1101,7 @@ template <typename T> class Plan {
     // unfused: pre (n + table read, m write) + 2 inner FFTs + w table + post (n + table read, n write);
     // fused: the first / last inner pass read / write the n-point user array instead of an m-point sweep
     if (small_fused_) return (double)ELEM * 2.0 * n_;  // tables stay L2-resident
-    const double chirp_reads = chirp_eval_ ? 0.0 : 2.0 * n_;  // the n-entry chirp table, once per fused end pass
+    const double chirp_reads = 2.0 * n_;  // the n-entry chirp table, once per fused end pass
     if (fused_ && conv_) return (double)ELEM * (2.0 * m_ * (2.0 * eng_->num_passes() - 1.0) - 2.0 * (m_ - n_) + m_ + chirp_reads);
     if (fused_) return (double)ELEM * (2.0 * 2.0 * m_ * eng_->num_passes() - 2.0 * (m_ - n_) + m_ + chirp_reads);
     return (double)ELEM * ((2.0 * n_ + m_) + 2.0 * 2.0 * m_ * eng_->num_passes() + m_ + 3.0 * n_);
@@ -1111,7 +1118,6 @@ template <typename T> class Plan {
       return 0;
     }
     if (key == "bluestein_conv" && (v == 0 || v == 1)) { conv_ = (v == 1) && conv_ok_; return 0; }
-    if (key == "bluestein_chirp_eval" && (v == 0 || v == 1)) { chirp_eval_ = (v == 1) && chirp_lo_.p != nullptr; return 0; }
     if (key == "host_chunk_bytes" && v > 0) { host_chunk_bytes_ = (size_t)v; return 0; }
     // both passes in one launch with the intermediate in the XCD's L2 (2^16..2^18 f32, 2^15..2^17 f64); 0 where unavailable
     if (key == "l2_fused" && (v == 0 || v == 1)) {
@@ -1215,16 +1221,12 @@ template <typename T> class Plan {
         typename Pow2Engine<T>::BluIO bin, bout;
         bin.io = IO_BLU_IN; bin.xtab = xtab_.p; bin.n = n_; bin.swap = inverse;
         bout.io = IO_BLU_OUT; bout.xtab = xtab_.p; bout.n = n_; bout.swap = inverse;
-        if (chirp_eval_) {
-          bin.chirp_lo = bout.chirp_lo = chirp_lo_.p; bin.chirp_hi = bout.chirp_hi = chirp_hi_.p;
-          bin.chirp_bits = bout.chirp_bits = chirp_bits_;
-        }
         const Pow2Engine<T>& inv = eng_inv_ ? *eng_inv_ : *eng_;
         cpx<T>* bufs[2] = {work, (cpx<T>*)scratch_.p};
         const cpx<T>* src = in + b0 * n_;
         int cur = 0;
         for (int p = 0; p + 1 < np; ++p) {
-          eng_->launch_pass((size_t)p, src, bufs[cur], nb, false, 1.0, nullptr, stream, prof, 1 + p, nxcd_, p == 0 ? bin : typename Pow2Engine<T>::BluIO());
+          eng_->launch_pass((size_t)p, src, bufs[cur], nb, false, 1.0, stream, prof, 1 + p, nxcd_, p == 0 ? bin : typename Pow2Engine<T>::BluIO());
           src = bufs[cur]; cur ^= 1;
         }
         eng_->launch_conv(src, bufs[cur], nb, wtab_.p, stream, prof, np, nxcd_);
@@ -1232,7 +1234,7 @@ template <typename T> class Plan {
         for (int p = 1; p < np; ++p) {
           const bool last = (p + 1 == np);
           cpx<T>* dst = last ? out + b0 * n_ : bufs[cur];
-          inv.launch_pass((size_t)p, src, dst, nb, true, last ? scale : 1.0, nullptr, stream, prof, 1 + np + p, nxcd_,
+          inv.launch_pass((size_t)p, src, dst, nb, true, last ? scale : 1.0, stream, prof, 1 + np + p, nxcd_,
                           last ? bout : typename Pow2Engine<T>::BluIO());
           src = dst; cur ^= 1;
         }
@@ -1244,10 +1246,6 @@ template <typename T> class Plan {
         typename Pow2Engine<T>::BluIO bin, bout;
         bin.io = IO_BLU_IN; bin.xtab = xtab_.p; bin.n = n_; bin.swap = inverse;
         bout.io = IO_BLU_OUT; bout.xtab = xtab_.p; bout.n = n_; bout.swap = inverse;
-        if (chirp_eval_) {
-          bin.chirp_lo = bout.chirp_lo = chirp_lo_.p; bin.chirp_hi = bout.chirp_hi = chirp_hi_.p;
-          bin.chirp_bits = bout.chirp_bits = chirp_bits_;
-        }
         eng_->run(in + b0 * n_, work, (cpx<T>*)scratch_.p, nb, false, 1.0, (const cpx<T>*)wtab_.p, false, stream, prof, 1,
                   nxcd_, bin);
         eng_->run(work, out + b0 * n_, (cpx<T>*)scratch_.p, nb, true, scale, nullptr, false, stream, prof, 1 + np, nxcd_, bout);
@@ -1359,6 +1357,7 @@ template <typename T> class Plan {
     if (n_ > ((size_t)1 << 26)) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "Bluestein sizes above 2^26 are not supported");
     m_ = 1;
     while (m_ < 2 * n_ - 1) m_ <<= 1;  // bluesteins.rs:110
+    if (2 * n_ > m_) throw EngineError(::fourier::c::FOURIER_HIP_RUNTIME_ERROR, "Bluestein: M < 2N");  // the fused end passes rely on it
     // forward inner plan: the larger pass first (2048 x 1024 at M = 2^21), so the conv kernel runs at the SHORTER length
     // and the end passes at the longer one.  FOURIER_BLU_SHORT_FIRST=1 (experiment) swaps the roles: 1024 x 2048 forward,
     // end passes of length 1024, conv kernel at 2048.
@@ -1389,18 +1388,6 @@ template <typename T> class Plan {
     std::vector<cpx<T>> x(n_);
     for (size_t k = 0; k < n_; ++k) x[k] = {(T)cr[k], (T)ci[k]};  // x_fwd, bluesteins.rs:51-61
     xtab_.upload(x);
-    if (fused_ && !small_fused_) {
-      // the fused passes evaluate the chirp instead of reading the n-entry table: two-level table of 2n-th roots
-      chirp_bits_ = (uint32_t)((ilog2(two_n) + 1) / 2);
-      std::vector<cpx<T>> lo((size_t)1 << chirp_bits_), hi((size_t)((two_n - 1) >> chirp_bits_) + 1);
-      for (size_t e = 0; e < lo.size(); ++e) { double re, im; unit_root(e, two_n, re, im); lo[e] = {(T)re, (T)im}; }
-      for (size_t h = 0; h < hi.size(); ++h) { double re, im; unit_root((uint64_t)h << chirp_bits_, two_n, re, im); hi[h] = {(T)re, (T)im}; }
-      chirp_lo_.upload(lo);
-      chirp_hi_.upload(hi);
-      // measured SLOWER than reading the table (C4: first pass 4.6 vs 3.3 ms per 512, profiles/r02_s5_chirp_eval_ab.jsonl:
-      // these passes are instruction-bound, not traffic-bound), so off unless asked for (option "bluestein_chirp_eval")
-      chirp_eval_ = getenv("FOURIER_CHIRP_EVAL") != nullptr;
-    }
     // w = FFT_M(conj chirp, mirrored) (bluesteins.rs:18-48), evaluated in f64 on the host, with the
     // inner IFFT's 1/M (bluesteins.rs:239 -> mod.rs:383) folded in.
     std::vector<double> wr(m_, 0.0), wi(m_, 0.0);
@@ -1471,9 +1458,7 @@ template <typename T> class Plan {
   bool blu_ = false;
   std::unique_ptr<Pow2Engine<T>> eng_, eng_inv_;  // eng_inv_: mirrored inverse plan of a conv-fused Bluestein
   std::unique_ptr<MixedEngine<T>> mix_;
-  DevBuf xtab_, wtab_, chirp_lo_, chirp_hi_;
-  uint32_t chirp_bits_ = 0;
-  bool chirp_eval_ = false;  // fused Bluestein passes evaluate the chirp (option "bluestein_chirp_eval")
+  DevBuf xtab_, wtab_;
   mutable DevBuf scratch_, work_, hostio_;
   mutable PinnedBuf pinned_;
   mutable hipStream_t legacy_stream_ = nullptr;  // legacy host-buffer calls (exec_host)

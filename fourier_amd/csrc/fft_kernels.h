@@ -120,17 +120,51 @@ template <typename T, bool NT> __device__ __forceinline__ void store_unit(void* 
 // is served by the XCD's L2 -- how a workgroup reads what ANOTHER workgroup of the same XCD stored a moment ago (the
 // L2 is the coherence point of an XCD; a CU's L1 is never refreshed by other CUs' stores, MI355X_MICROARCH.md).
 enum { POL_PLAIN = 0, POL_NT = 1, POL_SC1 = 2 };
-// 16-byte load at byte offset `off` (< 4 GiB) of a buffer descriptor built over a wave-uniform base pointer
+// 16-byte accesses through a buffer descriptor built over a wave-uniform base pointer (buffer_load/store_dwordx4):
+// the address is base + soff (SGPR) + voff (one 32-bit VGPR per lane) -- no 64-bit per-lane pointers -- and the
+// hardware bounds-checks voff, dword by dword, against the descriptor's byte count: out-of-range dwords load as 0 and
+// are not stored (soff is NOT part of the check).  The Bluestein end passes use exactly that for the zero padding
+// behind the user array (bluesteins.rs:229-234) and for dropping the outputs beyond it (bluesteins.rs:240-258).
 typedef __amdgpu_buffer_rsrc_t BufRsrc;
-__device__ __forceinline__ BufRsrc make_rsrc(const void* base) {
-  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+__device__ __forceinline__ BufRsrc make_rsrc(const void* base, uint32_t bytes = 0x7fffffffu) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
 }
-template <typename T> __device__ __forceinline__ Unit16<T> load_unit_sc1(BufRsrc r, uint32_t off) {
-  const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, /*aux: sc1*/ 16);
+enum { BUF_PLAIN = 0, BUF_NT = 2, BUF_SC1 = 16 };  // aux bits of the gfx940+ buffer instructions
+template <typename T, int AUX = BUF_PLAIN> __device__ __forceinline__ Unit16<T> buf_load_unit(BufRsrc r, uint32_t voff, uint32_t soff = 0) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, AUX);
   Unit16<T> u;
   __builtin_memcpy(&u, &v, 16);
   return u;
 }
+template <typename T, int AUX = BUF_PLAIN> __device__ __forceinline__ void buf_store_unit(BufRsrc r, uint32_t voff, const Unit16<T>& u, uint32_t soff = 0) {
+  decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)) v;
+  __builtin_memcpy(&v, &u, 16);
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, AUX);
+}
+// one complex element (8 / 16 bytes) through a descriptor, bounds-checked like the units
+template <typename T> __device__ __forceinline__ cpx<T> buf_load_elem(BufRsrc r, uint32_t voff, uint32_t soff = 0) {
+  cpx<T> y;
+  if constexpr (sizeof(T) == 4) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+    __builtin_memcpy(&y, &v, 8);
+  } else {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    __builtin_memcpy(&y, &v, 16);
+  }
+  return y;
+}
+template <typename T, int AUX = BUF_PLAIN> __device__ __forceinline__ void buf_store_elem(BufRsrc r, uint32_t voff, const cpx<T>& y, uint32_t soff = 0) {
+  if constexpr (sizeof(T) == 4) {
+    decltype(__builtin_amdgcn_raw_buffer_load_b64(r, 0, 0, 0)) v;
+    __builtin_memcpy(&v, &y, 8);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)voff, (int)soff, AUX);
+  } else {
+    decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)) v;
+    __builtin_memcpy(&v, &y, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, AUX);
+  }
+}
+template <typename T> __device__ __forceinline__ Unit16<T> load_unit_sc1(BufRsrc r, uint32_t off) { return buf_load_unit<T, BUF_SC1>(r, off); }
 
 // one complex element (8 / 16 bytes), optionally non-temporal
 template <typename T, bool NT> __device__ __forceinline__ void store_elem(cpx<T>* p, const cpx<T>& y) {
@@ -182,7 +216,7 @@ struct PassArgs {
   const void* tw_lo;  // W_size^{e},          e < 2^lo_bits     } two-level table of the
   const void* tw_hi;  // W_size^{h<<lo_bits}, h < size>>lo_bits } inter-pass twiddle W_size^{i*k}
   const void* tw_half;  // split tiles: W_2L^{n}, n < L (the radix-2 decimation-in-frequency twiddle in front of a length-L tile)
-  const void* mul;    // optional pointwise multiplier applied on store, indexed by output index
+  const void* mul;    // Bluestein kernels (conv / one-launch): the transformed chirp w, indexed like the M-point spectrum
   uint64_t n;         // elements per transform (batch stride)
   uint64_t cn;        // columns of this pass = n / L
   uint64_t s;         // Stockham stride = product of the previous passes' lengths
@@ -192,12 +226,6 @@ struct PassArgs {
   uint32_t nxcd;      // >1: remap blockIdx so that each XCD (blockIdx % nxcd) walks a contiguous tile range
   uint32_t xcd_interleave;  // block -> tile mapping mode, see xcd_remap()
   const void* blu_x;  // Bluestein chirp table x[0..blu_n) (IO_BLU_IN / IO_BLU_OUT)
-  // chirp evaluated in the kernel instead of read from blu_x (the fused passes of the large sizes: the 8-byte-per-point
-  // table read is a quarter of such a pass's memory traffic): x[k] = W_2n^{k^2 mod 2n} = chirp_lo[e & mask] * chirp_hi[e >> bits]
-  const void* chirp_lo;   // W_2n^{e}, e < 2^chirp_bits; null = read blu_x
-  const void* chirp_hi;   // W_2n^{h << chirp_bits}
-  uint32_t chirp_bits;
-  double chirp_two_n, chirp_inv_two_n;
   uint64_t blu_n;     // user transform length (batch stride of the user-side buffer)
   int blu_swap;       // user-level inverse: swap re/im of the user data
   int swap_in, swap_out;
@@ -385,6 +413,23 @@ __device__ __forceinline__ void lds_exchange(RegTile<T, L, CG>& x, unsigned char
   }
 }
 
+// Sixteen table units, one per register row of a tile, applied B at a time: the B loads of a batch are issued back to
+// back, then consumed.  Left to itself hipcc (128-VGPR budget, 64 of them the tile) issues ONE load, waits for it,
+// multiplies, and only then issues the next -- sixteen exposed L2 / HBM latencies per tile.
+template <typename T, int B, typename Ld, typename Use>
+__device__ __forceinline__ void units_batched(const Ld& ld, const Use& use) {
+#pragma unroll
+  for (int r0 = 0; r0 < 16; r0 += B) {
+    Unit16<T> u[B];
+#pragma unroll
+    for (int q = 0; q < B; ++q) u[q] = ld(r0 + q);
+    FOURIER_SCHED_FENCE();
+#pragma unroll
+    for (int q = 0; q < B; ++q) use(r0 + q, u[q]);
+    FOURIER_SCHED_FENCE();
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ cpx<T> two_level_twiddle(const PassArgs& a, uint64_t e) {
   const cpx<T>* lo = (const cpx<T>*)a.tw_lo;
@@ -393,38 +438,11 @@ __device__ __forceinline__ cpx<T> two_level_twiddle(const PassArgs& a, uint64_t 
   return cmul(lo[el], hi[eh]);
 }
 
-// Bluestein chirp x[k] = exp(-i*pi*k^2/n) (bluesteins.rs:9-15,51-61) without the n-entry table: the exponent is reduced
-// exactly, e = k^2 mod 2n (k < 2^26, so k^2 is exact in f64; the quotient estimate is off by at most one), and W_2n^e
-// comes from a two-level table of 2n-th roots (~2 x sqrt(2n) entries, cache-resident) -- one complex multiply and a
-// handful of f64 operations per point instead of 8-16 bytes of table traffic per point.
-template <typename T> __device__ __forceinline__ cpx<T> chirp_at(const PassArgs& a, uint64_t k) {
-  const double kd = (double)(uint32_t)k, sq = kd * kd;
-  const double q = __builtin_floor(sq * a.chirp_inv_two_n);
-  double r = __builtin_fma(-q, a.chirp_two_n, sq);  // exact: both products are integers below 2^53
-  r = r < 0.0 ? r + a.chirp_two_n : (r >= a.chirp_two_n ? r - a.chirp_two_n : r);
-  const uint32_t e = (uint32_t)r;
-  const cpx<T>* lo = (const cpx<T>*)a.chirp_lo;
-  const cpx<T>* hi = (const cpx<T>*)a.chirp_hi;
-  return cmul(lo[e & ((1u << a.chirp_bits) - 1u)], hi[e >> a.chirp_bits]);
-}
-// VEC consecutive chirp values starting at k (table read or evaluated)
-template <typename T> __device__ __forceinline__ Unit16<T> chirp_unit(const PassArgs& a, uint64_t k) {
-  constexpr int VEC = 16 / (2 * (int)sizeof(T));
-  if (!a.chirp_lo) return load_unit<T, false>((const cpx<T>*)a.blu_x + k);
-  Unit16<T> u;
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) {
-    const cpx<T> c = chirp_at<T>(a, k + (uint64_t)v);
-    u.a[2 * v] = c.re; u.a[2 * v + 1] = c.im;
-  }
-  return u;
-}
-
 // One big-radix Stockham pass over a tile of COLS columns (or COLS whole transforms in ROWS mode).
 //   MODE_FIRST: s == 1. column-tile load, transposed (row-contiguous) store, twiddle W_size^{i*k}.
 //   MODE_MID  : s >= COLS. column-tile load/store, twiddle W_size^{i*k} with i uniform per tile.
-//   MODE_LAST : size == L. column-tile load/store, no twiddle; mul / swap_out / scale on store.
-//   MODE_ROWS : whole transforms of length L, contiguous rows; mul / swap_out / scale on store.
+//   MODE_LAST : size == L. column-tile load/store, no twiddle; swap_out / scale on store.
+//   MODE_ROWS : whole transforms of length L, contiguous rows; swap_out / scale on store.
 // Workgroup b is dispatched to XCD b % 8 (observed, MI355X_MICROARCH.md).  Bijective remap of the block index so
 // that each XCD's L2/TLB sees a compact working set; affects speed only.
 //   mode 0: every XCD owns a contiguous range of tiles (= whole transforms): each 2 MiB page and each DRAM row is
@@ -448,9 +466,11 @@ __device__ __forceinline__ uint64_t xcd_remap(const PassArgs& a, uint64_t blk, u
 // ---- in-tile DFT of length L = 16 x R2 x R3 on a register tile (the body of every pass kernel) ----
 // In: thread (th, cg) holds rows th + Q*r of columns cg*VEC + v.  Out: register r holds output index
 // k = th + Q*r; for MODE_FIRST the last exchange also switches the thread mapping from cg-fastest ("A") to
-// th-fastest ("B", th = thB, cg = cgB) for the row-contiguous store.  Uses the exchange buffer at smem.
+// th-fastest ("B", th = tid % Q, cg = tid / Q) for the row-contiguous store.  Uses the exchange buffer at smem.
+// The "B" mapping is derived from a laundered copy of tid where it is first needed, so that nothing that depends on
+// it (the store addresses of the whole tile) is computed at the top of the kernel and carried through the butterflies.
 template <typename T, int L, int CG, int MODE>
-__device__ __forceinline__ void tile_core(RegTile<T, L, CG>& x, int& th, int& cg, const int thB, const int cgB,
+__device__ __forceinline__ void tile_core(RegTile<T, L, CG>& x, int& th, int& cg, const int tid,
                                           unsigned char* smem, const cpx<T>* tw1, const cpx<T>* tw2) {
   using C = TileCfg<T, L, CG>;
   constexpr int VEC = C::VEC, Q = C::Q, R2 = C::R2, R3 = C::R3;
@@ -474,8 +494,10 @@ __device__ __forceinline__ void tile_core(RegTile<T, L, CG>& x, int& th, int& cg
       }
     }
     {
-      const bool remap = (MODE == MODE_FIRST) && (R3 == 1);
-      const int th_r = remap ? thB : th, cg_r = remap ? cgB : cg;
+      constexpr bool remap = (MODE == MODE_FIRST) && (R3 == 1);
+      int tb = tid;
+      if constexpr (remap) FOURIER_LAUNDER(tb);
+      const int th_r = remap ? tb % Q : th, cg_r = remap ? tb / Q : cg;
       const int th_w = th;
       // both sides cg-fastest and split planes -> xor layout; anything row-contiguous -> skew layout
       constexpr int LAY1 = (C::SPLIT && !IN_ROWS && !(MODE == MODE_FIRST && R3 == 1)) ? 1 : 0;
@@ -511,8 +533,10 @@ __device__ __forceinline__ void tile_core(RegTile<T, L, CG>& x, int& th, int& cg
         }
       }
       {
-        const bool remap = (MODE == MODE_FIRST);
-        const int th_r = remap ? thB : th, cg_r = remap ? cgB : cg;
+        constexpr bool remap = (MODE == MODE_FIRST);
+        int tb = tid;
+        if constexpr (remap) FOURIER_LAUNDER(tb);
+        const int th_r = remap ? tb % Q : th, cg_r = remap ? tb / Q : cg;
         const int jw = th & 15, iw = th >> 4;
         __syncthreads();  // all reads of exchange 1 are done before the buffer is rewritten
         if constexpr (DO_EXCH)
@@ -572,7 +596,6 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
   // cg-fastest mapping ("A") for column-tile I/O, th-fastest ("B") for row-contiguous I/O
   int th = IN_ROWS ? tid % Q : tid / CG;
   int cg = IN_ROWS ? tid / Q : tid % CG;
-  const int thB = tid % Q, cgB = tid / Q;
 
   // Workgroup b is dispatched to XCD b % 8 (observed, MI355X_MICROARCH.md).  Give every XCD its own
   // contiguous range of tiles (= whole transforms): each 2 MiB page and each DRAM row is then
@@ -591,6 +614,13 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
     c0 = (blk % a.tiles) * COLS;
     g0 = b * a.cn + c0;
   }
+  // Column-tile accesses (everything but the row-contiguous side of FIRST / ROWS) go through buffer descriptors: the
+  // wave-uniform part of an address -- transform, tile, and the row r of the sixteen a thread owns -- sits in the
+  // descriptor base (scalar registers, one 64-bit scalar add per row), the per-lane part is ONE 32-bit byte offset
+  // for all sixteen rows, instead of sixteen 64-bit pointers in vector registers.  No size limit: a lane offset is below
+  // n * sizeof(complex) / 16.
+  constexpr int LDAUX = LDPOL == POL_NT ? BUF_NT : (LDPOL == POL_SC1 ? BUF_SC1 : BUF_PLAIN);
+  constexpr int STAUX = STPOL == POL_NT ? BUF_NT : BUF_PLAIN;
 
   // ---- inter-pass twiddle table for this tile: tabU[col][r] = W_size^{i_col * Q * r}
   if constexpr (TWIDDLED) {
@@ -617,34 +647,28 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
       for (int r = 0; r < 16; ++r) x[v][r] = valid ? p[Q * r] : cpx<T>{0, 0};
     }
   } else if constexpr (IO == IO_BLU_IN) {
-    // work = x (.) in, zero padded (bluesteins.rs:229-234); the user array is only 8-byte aligned
-    const cpx<T>* xt = (const cpx<T>*)a.blu_x;
-    const cpx<T>* p = in + b * a.blu_n;
+    // work = x (.) in, zero padded (bluesteins.rs:229-234).  M >= 2N - 1 and M even give 2N <= M (bluesteins.rs:110; the
+    // engine checks it), so rows L/2 .. L-1 of every column hold padding only: registers 8..15 are zero without a
+    // load.  The others come through two bounds-checked descriptors (user array, chirp table; the user array is only
+    // 8-byte aligned): everything at or beyond blu_n loads as zero, all sixteen loads are in flight together.
+    const uint32_t nbytes = (uint32_t)(a.blu_n * sizeof(cpx<T>));
+    const BufRsrc rd = make_rsrc(in + b * a.blu_n, nbytes), rc = make_rsrc(a.blu_x, nbytes);
+    const uint32_t voff = (uint32_t)(((uint64_t)th * a.cn + c0 + (uint64_t)(cg * VEC)) * sizeof(cpx<T>));
+    const uint32_t rowb = (uint32_t)((uint64_t)Q * a.cn * sizeof(cpx<T>));
+    Unit16<T> d[8], c[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const uint64_t idx0 = (uint64_t)(th + Q * r) * a.cn + c0 + (uint64_t)(cg * VEC);
-      if (idx0 + VEC <= a.blu_n) {  // whole unit inside the user array: one 16-byte load each for data and chirp
-        const Unit16<T> u = load_unit_a8<T>(p + idx0), c = chirp_unit<T>(a, idx0);
+    for (int r = 0; r < 8; ++r) d[r] = buf_load_unit<T, LDAUX>(rd, voff + (uint32_t)r * rowb);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          cpx<T> val{u.a[2 * v], u.a[2 * v + 1]};
-          if (a.blu_swap) val = {val.im, val.re};
-          x[v][r] = cmul(cpx<T>{c.a[2 * v], c.a[2 * v + 1]}, val);
-        }
-        continue;
-      }
+    for (int r = 0; r < 8; ++r) c[r] = buf_load_unit<T>(rc, voff + (uint32_t)r * rowb);
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
-        const uint64_t idx = idx0 + v;
-        cpx<T> val{0, 0};
-        if (idx < a.blu_n) {
-          val = p[idx];
-          if (a.blu_swap) val = {val.im, val.re};
-          val = cmul(a.chirp_lo ? chirp_at<T>(a, idx) : xt[idx], val);
-        }
-        x[v][r] = val;
+        cpx<T> val{d[r].a[2 * v], d[r].a[2 * v + 1]};
+        if (a.blu_swap) val = {val.im, val.re};
+        x[v][r] = cmul(cpx<T>{c[r].a[2 * v], c[r].a[2 * v + 1]}, val);
+        x[v][r + 8] = cpx<T>{0, 0};
       }
-    }
   } else if constexpr (SPLIT) {
     // rows n and n + L of the 2L-row tile; plain loads: the sibling workgroup's copy of each line comes from the L2
     const cpx<T>* p = in + b * a.n + (uint64_t)th * a.cn + c0 + (uint64_t)(cg * VEC);
@@ -668,22 +692,13 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
       }
       FOURIER_SCHED_FENCE();
     }
-  } else if constexpr (LDPOL == POL_SC1) {
-    // L2-served loads of an intermediate another workgroup of this XCD has just written (b == 0: `in` is one transform)
-    const BufRsrc rs = make_rsrc(in);
-    const uint32_t off = (uint32_t)(((uint64_t)th * a.cn + c0 + (uint64_t)(cg * VEC)) * sizeof(cpx<T>));
-    const uint32_t rowb = (uint32_t)((uint64_t)Q * a.cn * sizeof(cpx<T>));
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const Unit16<T> u = load_unit_sc1<T>(rs, off + (uint32_t)r * rowb);
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
-    }
   } else {
-    const cpx<T>* p = in + b * a.n + (uint64_t)th * a.cn + c0 + (uint64_t)(cg * VEC);
+    // (POL_SC1: L2-served loads of an intermediate another workgroup of this XCD has just written)
+    const cpx<T>* p = in + b * a.n + c0;
+    const uint32_t voff = (uint32_t)(((uint64_t)th * a.cn + (uint64_t)(cg * VEC)) * sizeof(cpx<T>));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const Unit16<T> u = load_unit<T, LDPOL == POL_NT>(p + (uint64_t)(Q * r) * a.cn);
+      const Unit16<T> u = buf_load_unit<T, LDAUX>(make_rsrc(p + (uint64_t)(Q * r) * a.cn), voff);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
     }
@@ -696,9 +711,8 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
   }
 
   // ---- in-tile DFT_L: register r <- row th + Q*r  ==>  register r holds output index k = th + Q*r
-  tile_core<T, L, CG, MODE>(x, th, cg, thB, cgB, smem, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw2);
+  tile_core<T, L, CG, MODE>(x, th, cg, tid, smem, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw2);
   // now register r holds output index k = th + Q*r of columns (cg*VEC + v)
-
   // ---- inter-pass twiddle W_size^{i*k} = W^{i*th} * tabU[col][r]
   if constexpr (TWIDDLED && FOURIER_ABLATE == 0) {
     if constexpr (Q == 1) __syncthreads();  // tabU visibility when there was no exchange barrier
@@ -716,7 +730,6 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
   // ---- store
   before_store();
   const T scale = (T)a.scale;
-  const cpx<T>* __restrict__ mul = (const cpx<T>*)a.mul;
   if constexpr (OUT_ROWS) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
@@ -727,7 +740,6 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
       for (int r = 0; r < 16; ++r) {
         cpx<T> y = x[v][r];
         if constexpr (FINAL) {
-          if (mul) y = cmul(y, mul[th + Q * r]);
           if (a.swap_out) y = {y.im, y.re};
           y = {y.re * scale, y.im * scale};
         }
@@ -735,44 +747,35 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
       }
     }
   } else if constexpr (IO == IO_BLU_OUT) {
-    // out = work (.) x (.) scale, first blu_n points only (bluesteins.rs:240-258)
-    const cpx<T>* xt = (const cpx<T>*)a.blu_x;
-    const uint64_t i = c0 / a.s, j0 = c0 % a.s;
-    const uint64_t off = j0 + (uint64_t)(cg * VEC) + a.s * ((uint64_t)(KM * L) * i + (uint64_t)(KM * th + par));
-    cpx<T>* p = out + b * a.blu_n;
+    // out = work (.) x (.) scale, first blu_n points only (bluesteins.rs:240-258).  This is the last pass (c0 < s), and
+    // 2N <= M puts the output rows of registers 8..15 (index >= M/2) beyond the user array: they are never stored.
+    // Chirp loads and stores go through bounds-checked descriptors, so the ragged end needs no branch.
+    const uint32_t nbytes = (uint32_t)(a.blu_n * sizeof(cpx<T>));
+    const BufRsrc ro = make_rsrc(out + b * a.blu_n, nbytes), rc = make_rsrc(a.blu_x, nbytes);
+    const uint32_t voff = (uint32_t)((c0 + (uint64_t)(cg * VEC) + a.s * (uint64_t)(KM * th + par)) * sizeof(cpx<T>));
+    const uint32_t rowb = (uint32_t)(a.s * (uint64_t)(KM * Q) * sizeof(cpx<T>));
+    Unit16<T> c[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const uint64_t idx0 = off + a.s * (uint64_t)(KM * Q * r);
-      if (idx0 + VEC <= a.blu_n) {
-        const Unit16<T> c = chirp_unit<T>(a, idx0);
-        Unit16<T> u;
+    for (int r = 0; r < 8; ++r) c[r] = buf_load_unit<T>(rc, voff + (uint32_t)r * rowb);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          cpx<T> y = x[v][r];
-          if (a.swap_out) y = {y.im, y.re};
-          y = cmul(y, cpx<T>{c.a[2 * v], c.a[2 * v + 1]});
-          if (a.blu_swap) y = {y.im, y.re};
-          u.a[2 * v] = y.re * scale; u.a[2 * v + 1] = y.im * scale;
-        }
-        store_unit_a8<T>(p + idx0, u);
-        continue;
-      }
+    for (int r = 0; r < 8; ++r) {
+      Unit16<T> u;
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
-        const uint64_t idx = idx0 + v;
-        if (idx < a.blu_n) {
-          cpx<T> y = x[v][r];
-          if (a.swap_out) y = {y.im, y.re};
-          y = cmul(y, a.chirp_lo ? chirp_at<T>(a, idx) : xt[idx]);
-          if (a.blu_swap) y = {y.im, y.re};
-          p[idx] = {y.re * scale, y.im * scale};
-        }
+        cpx<T> y = x[v][r];
+        if (a.swap_out) y = {y.im, y.re};
+        y = cmul(y, cpx<T>{c[r].a[2 * v], c[r].a[2 * v + 1]});
+        if (a.blu_swap) y = {y.im, y.re};
+        u.a[2 * v] = y.re * scale; u.a[2 * v + 1] = y.im * scale;
       }
+      buf_store_unit<T, STAUX>(ro, voff + (uint32_t)r * rowb, u);
     }
   } else {
+    // output row of register r: j0 + s * (KM*L*i + KM*(th + Q*r) + par); uniform part in the descriptor base
     const uint64_t i = c0 / a.s, j0 = c0 % a.s;
-    const uint64_t off = j0 + (uint64_t)(cg * VEC) + a.s * ((uint64_t)(KM * L) * i + (uint64_t)(KM * th + par));
-    cpx<T>* p = out + b * a.n + off;
+    const uint64_t base = b * a.n + j0 + a.s * ((uint64_t)(KM * L) * i + (uint64_t)par);
+    const uint32_t voff = (uint32_t)(((uint64_t)(cg * VEC) + a.s * (uint64_t)(KM * th)) * sizeof(cpx<T>));
+    const uint64_t rows = a.s * (uint64_t)(KM * Q);  // elements between a thread's consecutive output rows
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       Unit16<T> u;
@@ -780,13 +783,12 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
       for (int v = 0; v < VEC; ++v) {
         cpx<T> y = x[v][r];
         if constexpr (FINAL) {
-          if (mul) y = cmul(y, mul[off + a.s * (uint64_t)(KM * Q * r) + v]);
           if (a.swap_out) y = {y.im, y.re};
           y = {y.re * scale, y.im * scale};
         }
         u.a[2 * v] = y.re; u.a[2 * v + 1] = y.im;
       }
-      store_unit<T, STPOL == POL_NT>(p + a.s * (uint64_t)(KM * Q * r), u);
+      buf_store_unit<T, STAUX>(make_rsrc(out + base + rows * (uint64_t)r), voff, u);
     }
   }
 }
@@ -988,6 +990,9 @@ __global__ void __launch_bounds__((L1 / 16) * CG1, FOURIER_FUSED_MIN_WAVES) fft_
 #ifndef FOURIER_CONV_W_NT
 #define FOURIER_CONV_W_NT 0
 #endif
+#ifndef FOURIER_CONV_W_BATCH
+#define FOURIER_CONV_W_BATCH 8  // loads of the w table in flight per thread
+#endif
 // ---- Bluestein middle (bluesteins.rs:236-239): LAST pass of the forward inner FFT, (.) w, and FIRST pass of
 // the inverse inner FFT in ONE launch.  The last forward pass (R = L, s = M/L) leaves X[j + (M/L)*k] of its
 // column tile in registers; an inverse FFT whose first pass has the same length (R = L, s = 1, m = M/L) reads
@@ -1001,12 +1006,14 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16)
   static_assert(Q > 1, "conv kernel: L >= 32");
   FOURIER_DYN_SMEM(smem);
   const int tid = (int)threadIdx.x;
-  int th = tid / CG, cg = tid % CG;
-  const int thB = tid % Q, cgB = tid / Q;
   const uint64_t blk = xcd_remap(a, blockIdx.x, gridDim.x);
   const uint64_t b = blk / a.tiles, c0 = (blk % a.tiles) * COLS;
   const cpx<T>* __restrict__ in = (const cpx<T>*)a.in + b * a.n;
   cpx<T>* __restrict__ out = (cpx<T>*)a.out + b * a.n;
+  // Everything a phase derives from the thread index is derived from a laundered copy taken AT that phase: hipcc
+  // otherwise computes the addresses of all phases at the top of the kernel and carries (or spills) them across the
+  // two in-tile FFTs.
+  const uint32_t rowb = (uint32_t)((uint64_t)Q * a.cn * sizeof(cpx<T>));  // byte distance of a thread's consecutive rows
 
   // inter-pass twiddle table of the inverse FFT's first pass: tabU[col][r] = W_M^{i_col * Q * r}
   cpx<T>* tabU = (cpx<T>*)(smem + C::TABU_OFF);
@@ -1017,34 +1024,43 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16)
 
   // forward LAST pass: rows th + Q*r (stride cn) of columns c0 + cg*VEC + v
   cpx<T> x[VEC][16];
-  const uint64_t off = (uint64_t)th * a.cn + c0 + (uint64_t)(cg * VEC);
+  int th = tid / CG, cg = tid % CG;
   {
-    const cpx<T>* p = in + off;
+    const BufRsrc rs = make_rsrc(in);
+    const uint32_t voff = (uint32_t)(((uint64_t)th * a.cn + c0 + (uint64_t)(cg * VEC)) * sizeof(cpx<T>));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       // tiles narrower than a 128-byte line share every line with a sibling workgroup: no streaming hint then
-      const Unit16<T> u = load_unit<T, FOURIER_NT_LOAD == 2 && (CG >= 8)>(p + (uint64_t)(Q * r) * a.cn);
+      const Unit16<T> u = buf_load_unit<T, (FOURIER_NT_LOAD == 2 && CG >= 8) ? BUF_NT : BUF_PLAIN>(rs, voff, (uint32_t)r * rowb);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
     }
   }
-  tile_core<T, L, CG, MODE_LAST>(x, th, cg, thB, cgB, smem, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw2);
+  tile_core<T, L, CG, MODE_LAST>(x, th, cg, tid, smem, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw2);
   // register r holds X[c + cn*(th + Q*r)]: (.) w (FFT'd chirp, 1/M folded in), then the inverse's leading swap
   {
-    const cpx<T>* w = (const cpx<T>*)a.mul + off;
+    int t = tid;
+    FOURIER_LAUNDER(t);
+    const BufRsrc rw = make_rsrc(a.mul);
+    const uint32_t voff = (uint32_t)(((uint64_t)(t / CG) * a.cn + c0 + (uint64_t)((t % CG) * VEC)) * sizeof(cpx<T>));
+    units_batched<T, FOURIER_CONV_W_BATCH>(
+        [&](int r) { return buf_load_unit<T, FOURIER_CONV_W_NT != 0 ? BUF_NT : BUF_PLAIN>(rw, voff, (uint32_t)r * rowb); },
+        [&](int r, const Unit16<T>& u) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const Unit16<T> u = load_unit<T, FOURIER_CONV_W_NT != 0>(w + (uint64_t)(Q * r) * a.cn);
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        const cpx<T> y = cmul(x[v][r], cpx<T>{u.a[2 * v], u.a[2 * v + 1]});
-        x[v][r] = {y.im, y.re};
-      }
-    }
+          for (int v = 0; v < VEC; ++v) {
+            const cpx<T> y = cmul(x[v][r], cpx<T>{u.a[2 * v], u.a[2 * v + 1]});
+            x[v][r] = {y.im, y.re};
+          }
+        });
   }
   __syncthreads();  // every read of the last exchange is done before the buffer is rewritten
   // inverse FIRST pass on the same tile (columns i = c0 + ..., s = 1), thread mapping switches to th-fastest
-  tile_core<T, L, CG, MODE_FIRST>(x, th, cg, thB, cgB, smem, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw2);
+  {
+    int t = tid;
+    FOURIER_LAUNDER(t);
+    th = t / CG; cg = t % CG;
+    tile_core<T, L, CG, MODE_FIRST>(x, th, cg, tid, smem, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw2);
+  }
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
     const uint64_t i = c0 + (uint64_t)(cg * VEC + v);
@@ -1101,6 +1117,9 @@ __device__ __forceinline__ void two_stage_fft(RegTile<T, L, CG>& x, int th, int 
     }
 }
 
+#ifndef FOURIER_TWOLEVEL_TW_BATCH
+#define FOURIER_TWOLEVEL_TW_BATCH(NT) ((NT) <= 128 ? 4 : 8)  // loads of the inter-pass twiddle table in flight per thread (2-wave workgroups live on occupancy: stay under 128 VGPRs)
+#endif
 // Both passes of an N = L1 x L2 transform on register-resident data.  In: thread (th = tid / CG1,
 // cg = tid % CG1) holds rows th + Q1*r of the L1 x L2 row-major matrix (element row*L2 + col), columns
 // cg*VEC + v.  Out: thread (th2 = tid / CG2, cg2 = tid % CG2) holds X[k1 + L1*k2] for k2 = th2 + Q2*r,
@@ -1120,17 +1139,19 @@ __device__ __forceinline__ void twolevel_core(cpx<T> (*x)[16], int tid, unsigned
   // full table (the reference's per-pass layout idea, mod.rs:24-46) is kept, stored [k1][i] so that a
   // thread reads it with the same coalesced 16-byte units as the data; it stays L2-resident.
   {
-    const cpx<T>* tw = tw_full + (uint64_t)th * L2 + cg * VEC;
+    const BufRsrc rt = make_rsrc(tw_full);
+    const uint32_t voff = (uint32_t)((th * L2 + cg * VEC) * sizeof(cpx<T>));
+    units_batched<T, FOURIER_TWOLEVEL_TW_BATCH(Q1 * CG1)>(
+        [&](int r) { return buf_load_unit<T>(rt, voff, (uint32_t)((Q1 * r) * L2 * sizeof(cpx<T>))); },
+        [&](int r, const Unit16<T>& u) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const Unit16<T> u = *(const Unit16<T>*)(tw + (Q1 * r) * L2);
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) xr[v][r] = cmul(xr[v][r], cpx<T>{u.a[2 * v], u.a[2 * v + 1]});
-      if ((r & 3) == 3) FOURIER_SCHED_FENCE();
-    }
+          for (int v = 0; v < VEC; ++v) xr[v][r] = cmul(xr[v][r], cpx<T>{u.a[2 * v], u.a[2 * v + 1]});
+        });
   }
   // ---- transpose through LDS: element (i, k1) -> row i, column k1 of the L2 x L1 matrix
-  const int th2 = tid / CG2, cg2 = tid % CG2;
+  int tb = tid;
+  FOURIER_LAUNDER(tb);  // phase B's mapping is derived here, not at the top of the kernel (see tile_core)
+  const int th2 = tb / CG2, cg2 = tb % CG2;
   {
     constexpr bool SPLIT = CB::SPLIT;
     __syncthreads();  // the reads of phase A's exchange are done
@@ -1182,70 +1203,9 @@ __device__ __forceinline__ void twolevel_core(cpx<T> (*x)[16], int tid, unsigned
   two_stage_fft<T, L2, CG2>(xr, th2, cg2, smem, tw1_b, site + 12);
 }
 
-// L-point FFT (16 <= L <= 1024) of register-resident columns with up to three stages (16 x R2 x R3), the
-// row-kernel's core as a chainable function: register r holds position th + Q*r on entry AND on exit
-// (natural order), so two calls can follow each other without any re-layout.
-template <typename T, int L, int CG>
-__device__ __forceinline__ void rows_fft(RegTile<T, L, CG>& x, int th, int cg, unsigned char* smem, const cpx<T>* tw1,
-                                         const cpx<T>* tw2, unsigned site) {
-  using C = TileCfg<T, L, CG>;
-  constexpr int VEC = C::VEC, Q = C::Q, R2 = C::R2, R3 = C::R3;
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) dft16(x[v]);
-  if constexpr (Q > 1) {
-    const cpx<T>* t1 = tw1 + th * 16;
-    FOURIER_SCHED_FENCE();
-#pragma unroll
-    for (int k = 1; k < 16; ++k) {
-      const cpx<T> w = t1[k];
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) x[v][k] = cmul(x[v][k], w);
-      if ((k & 3) == 3) FOURIER_SCHED_FENCE();
-    }
-    lds_exchange<T, L, CG, 0>(x, smem, cg, [=](int r) { return 16 * th + r; }, th, cg, site);
-    FOURIER_SCHED_FENCE();
-    constexpr int NB2 = 16 / R2;
-#pragma unroll
-    for (int v = 0; v < VEC; ++v)
-#pragma unroll
-      for (int u = 0; u < NB2; ++u) {
-        cpx<T> t[R2];
-#pragma unroll
-        for (int k = 0; k < R2; ++k) t[k] = x[v][u + NB2 * k];
-        dft_r<T, R2>(t);
-#pragma unroll
-        for (int k = 0; k < R2; ++k) x[v][u + NB2 * k] = t[k];
-      }
-    if constexpr (R3 > 1) {
-      const cpx<T>* t2 = tw2 + (th >> 4) * 16;
-#pragma unroll
-      for (int k = 1; k < 16; ++k) {
-        const cpx<T> w = t2[k];
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) x[v][k] = cmul(x[v][k], w);
-        if ((k & 3) == 3) FOURIER_SCHED_FENCE();
-      }
-      const int jw = th & 15, iw = th >> 4;
-      __syncthreads();
-      lds_exchange<T, L, CG, 0>(x, smem, cg, [=](int r) { return jw + 16 * (16 * iw + r); }, th, cg, site + 4);
-      constexpr int NB3 = 16 / R3;
-#pragma unroll
-      for (int v = 0; v < VEC; ++v)
-#pragma unroll
-        for (int u = 0; u < NB3; ++u) {
-          cpx<T> t[R3];
-#pragma unroll
-          for (int k = 0; k < R3; ++k) t[k] = x[v][u + NB3 * k];
-          dft_r<T, R3>(t);
-#pragma unroll
-          for (int k = 0; k < R3; ++k) x[v][u + NB3 * k] = t[k];
-        }
-    }
-  }
-}
-
 // ---- whole Bluestein chirp-z in ONE launch for M = L <= 1024: COLS transforms per workgroup ----
-// Same chain as bluestein_small_kernel with the row core: x(.)in -> FFT_M -> (.)w -> swap -> FFT_M -> swap
+// Same chain as bluestein_small_kernel with the row form of the in-tile FFT (tile_core, MODE_ROWS: natural order in and
+// out, so two calls chain without a re-layout): x(.)in -> FFT_M -> (.)w -> swap -> FFT_M -> swap
 // -> (.)x(.)scale; lane-contiguous 8/16-byte accesses to the N-point user arrays.
 template <typename T, int L, int CG>
 __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG)) bluestein_rows_kernel(PassArgs a) {
@@ -1253,57 +1213,94 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
   constexpr int VEC = C::VEC, Q = C::Q, COLS = C::COLS;
   FOURIER_DYN_SMEM(smem);
   const int tid = (int)threadIdx.x;
-  const int th = tid % Q, cg = tid / Q;
   const uint32_t n = (uint32_t)a.blu_n;
   const uint64_t g0 = (uint64_t)blockIdx.x * COLS;
-  const cpx<T>* __restrict__ xt = (const cpx<T>*)a.blu_x;
-  const cpx<T>* __restrict__ wt = (const cpx<T>*)a.mul;
+  // One descriptor over this workgroup's transforms (a ragged last workgroup ends where the batch ends: transforms
+  // beyond it load as zero and are not stored), one over the chirp; branch-free element accesses, RB rows in flight.
+  // Every phase derives its lane offsets from a laundered copy of the thread index (see tile_core).
+  const uint64_t left = a.total_cols - g0;
+  const uint32_t ncols = (uint32_t)(left < (uint64_t)COLS ? left : (uint64_t)COLS);
+  const uint32_t nbytes = ncols * n * (uint32_t)sizeof(cpx<T>);
+  const BufRsrc ri = make_rsrc((const cpx<T>*)a.in + g0 * a.blu_n, nbytes), ro = make_rsrc((cpx<T>*)a.out + g0 * a.blu_n, nbytes);
+  const BufRsrc rc = make_rsrc(a.blu_x, n * (uint32_t)sizeof(cpx<T>));
+  constexpr int RB = 4;  // rows per batch: RB chirp values and RB * VEC data elements in flight per thread
+  constexpr uint32_t ES = (uint32_t)sizeof(cpx<T>);
   cpx<T> x[VEC][16];
+  {
+    const int th = tid % Q, cg = tid / Q;
 #pragma unroll
-  for (int v = 0; v < VEC; ++v) {
-    const uint64_t g = g0 + (uint64_t)(cg * VEC + v);
-    const bool valid = g < a.total_cols;
-    const cpx<T>* p = (const cpx<T>*)a.in + g * a.blu_n;
+    for (int r0 = 0; r0 < 16; r0 += RB) {
+      cpx<T> c[RB];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const uint32_t pos = (uint32_t)(th + Q * r);
-      cpx<T> val{0, 0};
-      if (valid && pos < n) {
-        val = p[pos];
-        if (a.blu_swap) val = {val.im, val.re};
-        val = cmul(xt[pos], val);
-      }
-      x[v][r] = val;
+      for (int q = 0; q < RB; ++q) c[q] = buf_load_elem<T>(rc, (uint32_t)(th + Q * (r0 + q)) * ES);  // 0 beyond n
+#pragma unroll
+      for (int v = 0; v < VEC; ++v)
+#pragma unroll
+        for (int q = 0; q < RB; ++q)
+          x[v][r0 + q] = buf_load_elem<T>(ri, ((uint32_t)(cg * VEC + v) * n + (uint32_t)(th + Q * (r0 + q))) * ES);
+      FOURIER_SCHED_FENCE();
+#pragma unroll
+      for (int v = 0; v < VEC; ++v)
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {  // bluesteins.rs:229-234; positions n .. L-1 are padding: the chirp loaded there is zero
+          cpx<T> val = x[v][r0 + q];
+          if (a.blu_swap) val = {val.im, val.re};
+          x[v][r0 + q] = cmul(c[q], val);
+        }
+      FOURIER_SCHED_FENCE();
     }
+    int th_ = th, cg_ = cg;
+    tile_core<T, L, CG, MODE_ROWS>(x, th_, cg_, tid, smem, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw2);
   }
-  rows_fft<T, L, CG>(x, th, cg, smem, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw2, 0);
+  {
+    int t = tid;
+    FOURIER_LAUNDER(t);
+    const cpx<T>* __restrict__ wt = (const cpx<T>*)a.mul + t % Q;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const cpx<T> w = wt[th + Q * r];
+    for (int r0 = 0; r0 < 16; r0 += RB) {
+      cpx<T> w[RB];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      const cpx<T> y = cmul(x[v][r], w);
-      x[v][r] = {y.im, y.re};
+      for (int q = 0; q < RB; ++q) w[q] = wt[Q * (r0 + q)];
+      FOURIER_SCHED_FENCE();
+#pragma unroll
+      for (int q = 0; q < RB; ++q)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const cpx<T> y = cmul(x[v][r0 + q], w[q]);
+          x[v][r0 + q] = {y.im, y.re};
+        }
+      FOURIER_SCHED_FENCE();
     }
   }
   if constexpr (Q > 1) __syncthreads();
-  rows_fft<T, L, CG>(x, th, cg, smem, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw2, 16);
+  {
+    int t = tid;
+    FOURIER_LAUNDER(t);
+    int th_ = t % Q, cg_ = t / Q;
+    tile_core<T, L, CG, MODE_ROWS>(x, th_, cg_, tid, smem, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw2);
+  }
   const T scale = (T)a.scale;
+  int t = tid;
+  FOURIER_LAUNDER(t);
+  const int th = t % Q, cg = t / Q;
 #pragma unroll
-  for (int v = 0; v < VEC; ++v) {
-    const uint64_t g = g0 + (uint64_t)(cg * VEC + v);
-    if (g >= a.total_cols) continue;
-    cpx<T>* p = (cpx<T>*)a.out + g * a.blu_n;
+  for (int r0 = 0; r0 < 16; r0 += RB) {
+    cpx<T> c[RB];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const uint32_t pos = (uint32_t)(th + Q * r);
-      if (pos < n) {
-        cpx<T> y{x[v][r].im, x[v][r].re};
-        y = cmul(y, xt[pos]);
+    for (int q = 0; q < RB; ++q) c[q] = buf_load_elem<T>(rc, (uint32_t)(th + Q * (r0 + q)) * ES);
+    FOURIER_SCHED_FENCE();
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+#pragma unroll
+      for (int q = 0; q < RB; ++q) {
+        const uint32_t pos = (uint32_t)(th + Q * (r0 + q));
+        cpx<T> y{x[v][r0 + q].im, x[v][r0 + q].re};
+        y = cmul(y, c[q]);
         if (a.blu_swap) y = {y.im, y.re};
-        p[pos] = {y.re * scale, y.im * scale};
+        // positions beyond n would land in the next transform's row: push them out of the descriptor's range instead
+        buf_store_elem<T>(ro, pos < n ? ((uint32_t)(cg * VEC + v) * n + pos) * ES : 0xfffffff0u, cpx<T>{y.re * scale, y.im * scale});
       }
-    }
+    FOURIER_SCHED_FENCE();
   }
 }
 
@@ -1321,15 +1318,15 @@ __global__ void __launch_bounds__(FOURIER_TWOLEVEL_NT(T, L1, L2), FOURIER_MIN_WA
     const uint64_t nwg = gridDim.x, nx = a.nxcd, xcd = blk % nx, q = nwg / nx, r = nwg % nx;
     blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + blk / nx;
   }
-  const cpx<T>* __restrict__ in = (const cpx<T>*)a.in + blk * N;
-  cpx<T>* __restrict__ out = (cpx<T>*)a.out + blk * N;
-  const int th = tid / CG1, cg = tid % CG1;
+  // one descriptor per transform, one 32-bit lane offset, the row offsets are compile-time scalars
+  const BufRsrc ri = make_rsrc((const cpx<T>*)a.in + blk * N), ro = make_rsrc((cpx<T>*)a.out + blk * N);
   cpx<T> x[VEC][16];
   {
-    const cpx<T>* p = in + (uint64_t)th * L2 + cg * VEC;
+    const int th = tid / CG1, cg = tid % CG1;
+    const uint32_t voff = (uint32_t)((th * L2 + cg * VEC) * sizeof(cpx<T>));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const Unit16<T> u = load_unit<T, (FOURIER_NT_LOAD != 0)>(p + (Q1 * r) * L2);
+      const Unit16<T> u = buf_load_unit<T, FOURIER_NT_LOAD != 0 ? BUF_NT : BUF_PLAIN>(ri, voff, (uint32_t)((Q1 * r) * L2 * sizeof(cpx<T>)));
 #pragma unroll
       for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
     }
@@ -1342,21 +1339,21 @@ __global__ void __launch_bounds__(FOURIER_TWOLEVEL_NT(T, L1, L2), FOURIER_MIN_WA
   }
   twolevel_core<T, L1, L2>(x, tid, smem, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw2, (const cpx<T>*)a.tw_lo, 0);
   // register r now holds k2 = th2 + Q2*r: X[k1 + L1*k2]
-  const int th2 = tid / CG2, cg2 = tid % CG2;
+  int tb = tid;
+  FOURIER_LAUNDER(tb);
+  const int th2 = tb / CG2, cg2 = tb % CG2;
   const T scale = (T)a.scale;
-  const cpx<T>* __restrict__ mul = (const cpx<T>*)a.mul;
-  cpx<T>* p = out + (uint64_t)th2 * L1 + cg2 * VEC;
+  const uint32_t voff = (uint32_t)((th2 * L1 + cg2 * VEC) * sizeof(cpx<T>));
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     Unit16<T> u;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       cpx<T> y = x[v][r];
-      if (mul) y = cmul(y, mul[(th2 + Q2 * r) * L1 + cg2 * VEC + v]);
       if (a.swap_out) y = {y.im, y.re};
       u.a[2 * v] = y.re * scale; u.a[2 * v + 1] = y.im * scale;
     }
-    store_unit<T, FOURIER_NT_STORE != 0>(p + (Q2 * r) * L1, u);
+    buf_store_unit<T, FOURIER_NT_STORE != 0 ? BUF_NT : BUF_PLAIN>(ro, voff, u, (uint32_t)((Q2 * r) * L1 * sizeof(cpx<T>)));
   }
 }
 
@@ -1377,62 +1374,75 @@ __global__ void __launch_bounds__(FOURIER_TWOLEVEL_NT(T, L1, L2), FOURIER_MIN_WA
     const uint64_t nwg = gridDim.x, nx = a.nxcd, xcd = blk % nx, q = nwg / nx, r = nwg % nx;
     blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + blk / nx;
   }
-  const uint32_t n = (uint32_t)a.blu_n;
-  const cpx<T>* __restrict__ in = (const cpx<T>*)a.in + blk * a.blu_n;
-  cpx<T>* __restrict__ out = (cpx<T>*)a.out + blk * a.blu_n;
-  const cpx<T>* __restrict__ xt = (const cpx<T>*)a.blu_x;
+  // bounds-checked descriptors over this transform's user arrays and the chirp: everything at or beyond blu_n loads
+  // as zero (the padding, bluesteins.rs:229-234) and is not stored (bluesteins.rs:240-258); no branches, and the
+  // user rows of an odd-length f32 batch are only 8-byte aligned, which buffer_load/store_dwordx4 tolerate
+  const uint32_t nbytes = (uint32_t)(a.blu_n * sizeof(cpx<T>));
+  const BufRsrc ri = make_rsrc((const cpx<T>*)a.in + blk * a.blu_n, nbytes), ro = make_rsrc((cpx<T>*)a.out + blk * a.blu_n, nbytes);
+  const BufRsrc rc = make_rsrc(a.blu_x, nbytes);
   const int th = tid / CG1, cg = tid % CG1;
+  const uint32_t voff = (uint32_t)((th * L2 + cg * VEC) * sizeof(cpx<T>));
+  constexpr uint32_t ROWB = (uint32_t)(Q1 * L2 * sizeof(cpx<T>));  // register r holds index (th + Q1*r)*L2 + cg*VEC + v
   cpx<T> x[VEC][16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
+    const Unit16<T> u = buf_load_unit<T>(ri, voff + (uint32_t)r * ROWB);
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      const uint32_t idx = (uint32_t)((th + Q1 * r) * L2 + cg * VEC + v);
-      cpx<T> val{0, 0};
-      if (idx < n) {  // bluesteins.rs:229-234
-        val = in[idx];
-        if (a.blu_swap) val = {val.im, val.re};
-        val = cmul(xt[idx], val);
-      }
-      x[v][r] = val;
-    }
+    for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
   }
+  units_batched<T, 8>([&](int r) { return buf_load_unit<T>(rc, voff + (uint32_t)r * ROWB); },
+                      [&](int r, const Unit16<T>& c) {
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                          cpx<T> val = x[v][r];
+                          if (a.blu_swap) val = {val.im, val.re};
+                          x[v][r] = cmul(cpx<T>{c.a[2 * v], c.a[2 * v + 1]}, val);
+                        }
+                      });
   twolevel_core<T, L1, L2>(x, tid, smem, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw2, (const cpx<T>*)a.tw_lo, 0);
   {  // (.) w (already FFT'd and scaled by 1/M on the host), then swap for the inverse transform (bluesteins.rs:236-239)
-    const int th2 = tid / CG2, cg2 = tid % CG2;
-    const cpx<T>* w = (const cpx<T>*)a.mul + (uint64_t)th2 * L1 + cg2 * VEC;
+    int tb = tid;
+    FOURIER_LAUNDER(tb);
+    const BufRsrc rw = make_rsrc(a.mul);
+    const uint32_t woff = (uint32_t)(((tb / CG2) * L1 + (tb % CG2) * VEC) * sizeof(cpx<T>));
+    units_batched<T, 8>([&](int r) { return buf_load_unit<T>(rw, woff, (uint32_t)((Q2 * r) * L1 * sizeof(cpx<T>))); },
+                        [&](int r, const Unit16<T>& u) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const Unit16<T> u = *(const Unit16<T>*)(w + (Q2 * r) * L1);
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        const cpx<T> y = cmul(x[v][r], cpx<T>{u.a[2 * v], u.a[2 * v + 1]});
-        x[v][r] = {y.im, y.re};
-      }
-      if ((r & 3) == 3) FOURIER_SCHED_FENCE();
-    }
+                          for (int v = 0; v < VEC; ++v) {
+                            const cpx<T> y = cmul(x[v][r], cpx<T>{u.a[2 * v], u.a[2 * v + 1]});
+                            x[v][r] = {y.im, y.re};
+                          }
+                        });
   }
   __syncthreads();
-  twolevel_core<T, L2, L1>(x, tid, smem, (const cpx<T>*)a.tw2, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw_hi, 32);
+  {
+    int t2 = tid;
+    FOURIER_LAUNDER(t2);  // the inverse's lane mappings are derived here, not carried through the forward transform
+    twolevel_core<T, L2, L1>(x, t2, smem, (const cpx<T>*)a.tw2, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw_hi, 32);
+  }
   // back in the original layout: register r holds index (th + Q1*r)*L2 + cg*VEC + v of the swapped inverse
   const T scale = (T)a.scale;
+  {
+    int tb = tid;
+    FOURIER_LAUNDER(tb);
+    const uint32_t soff = (uint32_t)(((tb / CG1) * L2 + (tb % CG1) * VEC) * sizeof(cpx<T>));
+    units_batched<T, 8>([&](int r) { return buf_load_unit<T>(rc, soff + (uint32_t)r * ROWB); },
+                        [&](int r, const Unit16<T>& c) {
+                          Unit16<T> u;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      const uint32_t idx = (uint32_t)((th + Q1 * r) * L2 + cg * VEC + v);
-      if (idx < n) {  // bluesteins.rs:240-258
-        cpx<T> y{x[v][r].im, x[v][r].re};
-        y = cmul(y, xt[idx]);
-        if (a.blu_swap) y = {y.im, y.re};
-        out[idx] = {y.re * scale, y.im * scale};
-      }
-    }
+                          for (int v = 0; v < VEC; ++v) {
+                            cpx<T> y{x[v][r].im, x[v][r].re};
+                            y = cmul(y, cpx<T>{c.a[2 * v], c.a[2 * v + 1]});
+                            if (a.blu_swap) y = {y.im, y.re};
+                            u.a[2 * v] = y.re * scale; u.a[2 * v + 1] = y.im * scale;
+                          }
+                          buf_store_unit<T>(ro, soff + (uint32_t)r * ROWB, u);
+                        });
   }
 }
 
 struct TinyArgs {
-  const void* in; void* out; const void* mul;
+  const void* in; void* out;
   uint64_t batch; int n; int swap_in, swap_out; double scale;
 };
 
@@ -1491,14 +1501,12 @@ __global__ void __launch_bounds__(256) tiny_shfl_kernel(TinyArgs a) {
   }
   dft_r<T, N>(x);
   const T scale = (T)a.scale;
-  const cpx<T>* mul = (const cpx<T>*)a.mul;
 #pragma unroll
   for (int j = 0; j < U; ++j) {
     Unit16<T> v;
 #pragma unroll
     for (int c = 0; c < VEC; ++c) {
       cpx<T> y = x[j * VEC + c];
-      if (mul) y = cmul(y, mul[j * VEC + c]);
       if (a.swap_out) y = {y.im, y.re};
       v.a[2 * c] = y.re * scale; v.a[2 * c + 1] = y.im * scale;
     }
@@ -1521,7 +1529,6 @@ __global__ void __launch_bounds__(256) tiny_dft_kernel(TinyArgs a) {
   if (b >= a.batch) return;
   const cpx<T>* in = (const cpx<T>*)a.in + b * a.n;
   cpx<T>* out = (cpx<T>*)a.out + b * a.n;
-  const cpx<T>* mul = (const cpx<T>*)a.mul;
   cpx<T> x[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -1534,7 +1541,6 @@ __global__ void __launch_bounds__(256) tiny_dft_kernel(TinyArgs a) {
   for (int i = 0; i < 8; ++i) {
     if (i < a.n) {
       cpx<T> y = x[i];
-      if (mul) y = cmul(y, mul[i]);
       if (a.swap_out) y = {y.im, y.re};
       out[i] = {y.re * scale, y.im * scale};
     }
@@ -1693,7 +1699,7 @@ __global__ void __launch_bounds__(256) mixed_radix_kernel(MixArgs a) {
 // reference reaches radix 3 last as well (RADICES = [4,8,4,3,2], mod.rs:21).  One thread owns VEC adjacent
 // columns j (one 16-byte unit per row) and all R rows: fully coalesced, in place allowed.
 struct OddArgs {
-  const void* in; void* out; const void* mul;
+  const void* in; void* out;
   uint64_t n, s, batch;       // transform length, Stockham stride of this pass, transforms
   uint64_t m;                 // size_cur / R: 1 for the last pass (stride = n / R), > 1 for a twiddled middle pass
   const void* tw;             // middle passes: W_size_cur^{e}, e < size_cur (size_cur = R * m)
@@ -1935,7 +1941,7 @@ __global__ void __launch_bounds__(256) odd_last_kernel(OddArgs a) {
   // One radix-R (R = 3, 9, 27) Stockham pass at stride s over the odd part of a 2^a*3^b plan (mod.rs:203-284 with the
   // reference's radix order, the odd radices after the powers of two):
   //   out[j + R*s*i + s*k] = W_size^{i*k} * DFT_R(in[j + s*i + s*m*k'])_k,  i < m, j < s.
-  // m == 1 is the final pass (no twiddle; scaling / swap / pointwise multiplier applied); m > 1 a middle pass.
+  // m == 1 is the final pass (no twiddle; scaling / swap applied); m > 1 a middle pass.
   // One thread per (transform, i, 16-byte unit of j): s is a multiple of 4096, so a wave shares i and reads whole lines.
   constexpr int VEC = 16 / (2 * (int)sizeof(T));
   const uint64_t units = a.s / VEC;                       // 16-byte units per row
@@ -1958,7 +1964,6 @@ __global__ void __launch_bounds__(256) odd_last_kernel(OddArgs a) {
 #pragma unroll
   for (int c = 0; c < VEC; ++c) dft_pow3<T, R, R, 1>(x[c], a);
   const T scale = (T)a.scale;
-  const cpx<T>* mul = (const cpx<T>*)a.mul;
   const cpx<T>* tw = (const cpx<T>*)a.tw;
 #pragma unroll
   for (int k = 0; k < R; ++k) {
@@ -1969,7 +1974,6 @@ __global__ void __launch_bounds__(256) odd_last_kernel(OddArgs a) {
     for (int c = 0; c < VEC; ++c) {
       cpx<T> y = x[c][k];
       if (last) {
-        if (mul) y = cmul(y, mul[u * VEC + c + (uint64_t)k * a.s]);
         if (a.swap_out) y = {y.im, y.re};
         y = {y.re * scale, y.im * scale};
       } else if (k > 0) {
@@ -1987,6 +1991,15 @@ struct BluArgs {
   const void* in; void* out; const void* xtab;
   uint64_t n, m, batch; int swap; double scale;
 };
+// work[b][i] *= w[i], i < m                                     (bluesteins.rs:236-239; unfused options only)
+template <typename T>
+__global__ void __launch_bounds__(256) blu_mul_kernel(BluArgs a) {
+  cpx<T>* work = (cpx<T>*)a.out;
+  const cpx<T>* wt = (const cpx<T>*)a.xtab;
+  const uint64_t total = a.batch * a.m;
+  for (uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * 256)
+    work[idx] = cmul(work[idx], wt[idx % a.m]);
+}
 // work[b][i] = x[i] * in[b][i] for i < n, 0 for n <= i < m      (bluesteins.rs:229-234)
 template <typename T>
 __global__ void __launch_bounds__(256) blu_pre_kernel(BluArgs a) {

@@ -246,13 +246,38 @@ inline uint32_t __builtin_amdgcn_s_getreg(int) {  // HW_REG_XCC_ID: spread the b
   if (const char* e = getenv("HIPEMU_XCDS")) return hipemu::tls().bid.x % (unsigned)atoi(e);
   return hipemu::tls().bid.x % 3;
 }
-typedef const unsigned char* __amdgpu_buffer_rsrc_t;
-inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, int, int, int) { return (const unsigned char*)p; }
+// buffer descriptor: base + byte count; the offset (not the scalar offset) is range-checked dword by dword, as the hardware does
+struct __amdgpu_buffer_rsrc_t { unsigned char* base; uint32_t num_records; };
+inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, int, int num_records, int) { return {(unsigned char*)p, (uint32_t)num_records}; }
 struct hipemu_b128 { uint32_t w[4]; };
 inline hipemu_b128 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
   hipemu_b128 v;
-  memcpy(&v, r + voff + soff, 16);
+  for (int d = 0; d < 4; ++d) {
+    const uint64_t o = (uint64_t)(uint32_t)voff + 4u * (unsigned)d;
+    if (o + 4 <= r.num_records) memcpy(&v.w[d], r.base + (uint32_t)soff + o, 4); else v.w[d] = 0;
+  }
   return v;
+}
+struct hipemu_b64 { uint32_t w[2]; };
+inline hipemu_b64 __builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+  hipemu_b64 v;
+  for (int d = 0; d < 2; ++d) {
+    const uint64_t o = (uint64_t)(uint32_t)voff + 4u * (unsigned)d;
+    if (o + 4 <= r.num_records) memcpy(&v.w[d], r.base + (uint32_t)soff + o, 4); else v.w[d] = 0;
+  }
+  return v;
+}
+inline void __builtin_amdgcn_raw_buffer_store_b64(hipemu_b64 v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+  for (int d = 0; d < 2; ++d) {
+    const uint64_t o = (uint64_t)(uint32_t)voff + 4u * (unsigned)d;
+    if (o + 4 <= r.num_records) memcpy(r.base + (uint32_t)soff + o, &v.w[d], 4);
+  }
+}
+inline void __builtin_amdgcn_raw_buffer_store_b128(hipemu_b128 v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+  for (int d = 0; d < 4; ++d) {
+    const uint64_t o = (uint64_t)(uint32_t)voff + 4u * (unsigned)d;
+    if (o + 4 <= r.num_records) memcpy(r.base + (uint32_t)soff + o, &v.w[d], 4);
+  }
 }
 
 // ---- host API subset ----
