@@ -1111,7 +1111,7 @@ template <typename T> class Plan {
     DeviceGuard g(device_);  // bluestein_fusion may allocate tables: they must land on the plan's device
     if (key == "chunk_bytes" && v >= 0) { chunk_bytes_ = (size_t)v; return 0; }
     if (key == "scratch" && (v == 0 || v == 1)) { force_scratch_ = (v == 1); return 0; }
-    if (key == "xcd_swizzle" && v >= 0 && v <= 3) { nxcd_ = v == 0 ? 1 : (8 | ((unsigned)(v - 1) << 8)); return 0; }
+    if (key == "xcd_swizzle" && v >= 0 && v <= 4) { nxcd_ = v == 0 ? 1 : (8 | ((unsigned)(v - 1) << 8)); return 0; }
     if (key == "bluestein_fusion" && (v == 0 || v == 1)) {
       fused_ = (v == 1) && blu_ && eng_->can_fuse_bluestein();
       small_fused_ = (v == 1) && blu_ && eng_->enable_bluestein_small();

@@ -136,10 +136,15 @@ template <typename T, int AUX = BUF_PLAIN> __device__ __forceinline__ Unit16<T> 
   __builtin_memcpy(&u, &v, 16);
   return u;
 }
-template <typename T, int AUX = BUF_PLAIN> __device__ __forceinline__ void buf_store_unit(BufRsrc r, uint32_t voff, const Unit16<T>& u, uint32_t soff = 0) {
+// Stores take NO scalar offset, on purpose: `buffer_store_dwordx4 v[a:a+3], voff, rsrc, sN offen` followed a few
+// instructions later by VALU writes to v[a:a+3] (hipcc reuses the data registers of consecutive stores, and inserts its
+// wait state only for the soffset-less form) corrupted the stored data of lanes 12-15 of every 16 on gfx950 under load
+// (2^14 / 2^15 one-launch plans, round 3; profiles/r03_s2_store_soffset_hazard.txt).  A row offset therefore goes into
+// the descriptor base (scalar adds) or into voff.
+template <typename T, int AUX = BUF_PLAIN> __device__ __forceinline__ void buf_store_unit(BufRsrc r, uint32_t voff, const Unit16<T>& u) {
   decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)) v;
   __builtin_memcpy(&v, &u, 16);
-  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, AUX);
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, 0, AUX);
 }
 // one complex element (8 / 16 bytes) through a descriptor, bounds-checked like the units
 template <typename T> __device__ __forceinline__ cpx<T> buf_load_elem(BufRsrc r, uint32_t voff, uint32_t soff = 0) {
@@ -153,15 +158,15 @@ template <typename T> __device__ __forceinline__ cpx<T> buf_load_elem(BufRsrc r,
   }
   return y;
 }
-template <typename T, int AUX = BUF_PLAIN> __device__ __forceinline__ void buf_store_elem(BufRsrc r, uint32_t voff, const cpx<T>& y, uint32_t soff = 0) {
+template <typename T, int AUX = BUF_PLAIN> __device__ __forceinline__ void buf_store_elem(BufRsrc r, uint32_t voff, const cpx<T>& y) {
   if constexpr (sizeof(T) == 4) {
     decltype(__builtin_amdgcn_raw_buffer_load_b64(r, 0, 0, 0)) v;
     __builtin_memcpy(&v, &y, 8);
-    __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)voff, (int)soff, AUX);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)voff, 0, AUX);
   } else {
     decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)) v;
     __builtin_memcpy(&v, &y, 16);
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, 0, AUX);
   }
 }
 template <typename T> __device__ __forceinline__ Unit16<T> load_unit_sc1(BufRsrc r, uint32_t off) { return buf_load_unit<T, BUF_SC1>(r, off); }
@@ -450,6 +455,9 @@ __device__ __forceinline__ cpx<T> two_level_twiddle(const PassArgs& a, uint64_t 
 //   mode 1: XCD x takes transforms x, x + 8, ... (eight XCDs on eight adjacent transforms; measured slower)
 //   mode 2: XCD x owns the x-th eighth of the TILES of every transform: the slice of a per-transform table (Bluestein
 //           chirp / transformed chirp, indexed like the data) that an XCD reads stays in its 4 MiB L2
+//   mode 3: every XCD owns a contiguous range of whole transforms (as mode 0) but walks it band-major: an eighth of the
+//           tile columns for ALL of its transforms, then the next eighth -- a per-transform table's band is re-read from
+//           the L2 by transform after transform while no transform or page is shared between XCDs
 __device__ __forceinline__ uint64_t xcd_remap(const PassArgs& a, uint64_t blk, uint64_t nwg) {
   if (a.nxcd <= 1) return blk;
   const uint64_t nx = a.nxcd, xcd = blk % nx, slot = blk / nx;
@@ -459,10 +467,20 @@ __device__ __forceinline__ uint64_t xcd_remap(const PassArgs& a, uint64_t blk, u
     const uint64_t tpx = a.tiles / nx;
     return (slot / tpx) * a.tiles + xcd * tpx + slot % tpx;
   }
+  if (a.xcd_interleave == 3 && a.tiles > 0 && a.tiles % 8 == 0 && nwg % (nx * a.tiles) == 0) {
+    const uint64_t tpb = a.tiles / 8, t_per_xcd = nwg / (nx * a.tiles), per_band = t_per_xcd * tpb;
+    const uint64_t band = slot / per_band, rem = slot % per_band;
+    return (xcd * t_per_xcd + rem / tpb) * a.tiles + band * tpb + rem % tpb;
+  }
   const uint64_t q = nwg / nx, r = nwg % nx;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
+#ifdef FOURIER_AB_NO_FIRST_LAUNDER
+#define FOURIER_AB_LAUNDER(v)
+#else
+#define FOURIER_AB_LAUNDER(v) FOURIER_LAUNDER(v)
+#endif
 // ---- in-tile DFT of length L = 16 x R2 x R3 on a register tile (the body of every pass kernel) ----
 // In: thread (th, cg) holds rows th + Q*r of columns cg*VEC + v.  Out: register r holds output index
 // k = th + Q*r; for MODE_FIRST the last exchange also switches the thread mapping from cg-fastest ("A") to
@@ -496,7 +514,7 @@ __device__ __forceinline__ void tile_core(RegTile<T, L, CG>& x, int& th, int& cg
     {
       constexpr bool remap = (MODE == MODE_FIRST) && (R3 == 1);
       int tb = tid;
-      if constexpr (remap) FOURIER_LAUNDER(tb);
+      if constexpr (remap) FOURIER_AB_LAUNDER(tb);
       const int th_r = remap ? tb % Q : th, cg_r = remap ? tb / Q : cg;
       const int th_w = th;
       // both sides cg-fastest and split planes -> xor layout; anything row-contiguous -> skew layout
@@ -535,7 +553,7 @@ __device__ __forceinline__ void tile_core(RegTile<T, L, CG>& x, int& th, int& cg
       {
         constexpr bool remap = (MODE == MODE_FIRST);
         int tb = tid;
-        if constexpr (remap) FOURIER_LAUNDER(tb);
+        if constexpr (remap) FOURIER_AB_LAUNDER(tb);
         const int th_r = remap ? tb % Q : th, cg_r = remap ? tb / Q : cg;
         const int jw = th & 15, iw = th >> 4;
         __syncthreads();  // all reads of exchange 1 are done before the buffer is rewritten
@@ -698,7 +716,11 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
     const uint32_t voff = (uint32_t)(((uint64_t)th * a.cn + (uint64_t)(cg * VEC)) * sizeof(cpx<T>));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
+#ifdef FOURIER_AB_PTR_LOADS  // A/B: per-lane 64-bit pointers (the round-2 form)
+      const Unit16<T> u = load_unit<T, LDPOL == POL_NT>((const char*)(p + (uint64_t)(Q * r) * a.cn) + voff);
+#else
       const Unit16<T> u = buf_load_unit<T, LDAUX>(make_rsrc(p + (uint64_t)(Q * r) * a.cn), voff);
+#endif
 #pragma unroll
       for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
     }
@@ -1319,7 +1341,9 @@ __global__ void __launch_bounds__(FOURIER_TWOLEVEL_NT(T, L1, L2), FOURIER_MIN_WA
     blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + blk / nx;
   }
   // one descriptor per transform, one 32-bit lane offset, the row offsets are compile-time scalars
-  const BufRsrc ri = make_rsrc((const cpx<T>*)a.in + blk * N), ro = make_rsrc((cpx<T>*)a.out + blk * N);
+  cpx<T>* const obase = (cpx<T>*)a.out + blk * N;
+  const BufRsrc ri = make_rsrc((const cpx<T>*)a.in + blk * N), ro = make_rsrc(obase);
+  (void)ro;
   cpx<T> x[VEC][16];
   {
     const int th = tid / CG1, cg = tid % CG1;
@@ -1353,7 +1377,12 @@ __global__ void __launch_bounds__(FOURIER_TWOLEVEL_NT(T, L1, L2), FOURIER_MIN_WA
       if (a.swap_out) y = {y.im, y.re};
       u.a[2 * v] = y.re * scale; u.a[2 * v + 1] = y.im * scale;
     }
-    buf_store_unit<T, FOURIER_NT_STORE != 0 ? BUF_NT : BUF_PLAIN>(ro, voff, u, (uint32_t)((Q2 * r) * L1 * sizeof(cpx<T>)));
+#ifdef FOURIER_TWOLEVEL_STORE_SOFF  // A/B only: reproduces the corruption described at buf_store_unit
+    __builtin_amdgcn_raw_buffer_store_b128(*(const decltype(__builtin_amdgcn_raw_buffer_load_b128(ro, 0, 0, 0))*)&u, ro, (int)voff,
+                                           (int)((Q2 * r) * L1 * sizeof(cpx<T>)), FOURIER_NT_STORE != 0 ? BUF_NT : BUF_PLAIN);
+#else
+    buf_store_unit<T, FOURIER_NT_STORE != 0 ? BUF_NT : BUF_PLAIN>(make_rsrc(obase + (Q2 * r) * L1), voff, u);
+#endif
   }
 }
 

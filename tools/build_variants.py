@@ -43,6 +43,10 @@ VARIANTS = {
     "conv_both": ["-DFOURIER_CONV_ST_NT=1", "-DFOURIER_CONV_W_NT=1"],
     "cg4096_4": ["-DFOURIER_CG_4096=4"],
     "split_nt": ["-DFOURIER_SPLIT_LD=POL_NT"],
+    "tl_store_soff": ["-DFOURIER_TWOLEVEL_STORE_SOFF=1"],
+    "ptr_loads": ["-DFOURIER_AB_PTR_LOADS=1"],
+    "no_first_launder": ["-DFOURIER_AB_NO_FIRST_LAUNDER=1"],
+    "ptr_nolaunder": ["-DFOURIER_AB_PTR_LOADS=1", "-DFOURIER_AB_NO_FIRST_LAUNDER=1"],
     "abl1": ["-DFOURIER_ABLATE=1"],
     "abl2": ["-DFOURIER_ABLATE=2"],
     "abl3": ["-DFOURIER_ABLATE=3"],
