@@ -16,7 +16,10 @@ Workloads (`--config`, default `auto`):
         device syncs and reported separately as wall_ms_per_step_incl_regen).  THE DEFAULT AT N>1: this is the
         configuration BASELINE.json names for the 1/2/4/8-GPU scaling curve.
   c3 / c4   configs[2] (f64 N=2^20 x 4096) and configs[3] (Bluestein N=999983 f32 x 512), same form as c2.
-`auto` = c2 on one GPU, c5 under torch.distributed.run with more than one rank.
+`auto` = c2 on one GPU, c5 under torch.distributed.run with more than one rank.  The line names its configuration
+(`config_key`); a c5 line carries its own single-GPU reference (`strong_scaling.single_gpu_reference`: rank 0 alone on
+two chunks while the other ranks idle), every rank's time, the process group's backend and world size, and the
+efficiency against that reference, so that one record is enough to judge batch-shard scaling.
 
 Extra objects in the JSON line:
   roofline      -- dominant kernel, algorithmic bytes per launch / HIP-event duration (events on the
@@ -348,6 +351,24 @@ def main():
                 t_fft += time.perf_counter() - t1
             return t_fft
 
+        # ---- in-run single-GPU reference: rank 0 alone times two full-size chunks (after one warm chunk) while every
+        # other rank waits at the barrier below, so that the line holds what ONE GPU does per chunk with an idle node
+        # around it.  ideal step time = reference x chunks of the largest shard; efficiency = ideal / measured.
+        ref_ms_per_chunk = None
+        if dist is not None:
+            dist.barrier()
+        if rank == 0:
+            ts_ref = []
+            for i in range(3):
+                gen.manual_seed(0x5EED0AAA + i)
+                torch.view_as_real(x).uniform_(0.0, 1.0, generator=gen)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                plan.transform_batch_ptr(x.data_ptr(), y.data_ptr(), chunk, int(Transform.Fft), stream)
+                torch.cuda.synchronize(dev)
+                if i:
+                    ts_ref.append(time.perf_counter() - t1)
+            ref_ms_per_chunk = sum(ts_ref) / len(ts_ref) * 1e3
         for w in range(args.warmup):
             step(-1 - w)
         sync_all()
@@ -359,8 +380,21 @@ def main():
         sync_all()
         wall = time.perf_counter() - t0
         elapsed = shard.reduce_max_seconds(fft_s, dist, red_dev)
+        per_rank = shard.gather_seconds(fft_s, dist, red_dev)
         wall = shard.reduce_max_seconds(wall, dist, red_dev)
         extra["wall_ms_per_step_incl_regen"] = round(wall / args.steps * 1e3, 3)
+        if rank == 0:
+            shards = [shard.batch_shard(gbatch, world, r) for r in range(world)]
+            largest = max(h - l for l, h in shards)
+            ideal_ms = ref_ms_per_chunk * largest / chunk
+            extra["strong_scaling"] = {
+                "per_rank_fft_ms_per_step": [round(t / args.steps * 1e3, 3) for t in per_rank],
+                "transforms_per_rank": [h - l for l, h in shards],
+                "single_gpu_reference": {"ms_per_chunk": round(ref_ms_per_chunk, 3), "chunk": chunk,
+                                         "how": "rank 0 alone, two timed chunks after one warm chunk, the other ranks idle at a barrier"},
+                "ideal_ms_per_step": round(ideal_ms, 3),  # reference x (largest shard / chunk): perfect batch-shard scaling
+                "efficiency_vs_reference": round(ideal_ms / (elapsed / args.steps * 1e3), 4),
+            }
         workload = (f"batched 1D c2c {dtype} N={n} GLOBAL batch={gbatch} batch-sharded over {world} GPU(s) "
                     f"({hi - lo} per GPU as resident chunks of {chunk}, regenerated on the device), forward "
                     f"{'in-place' if args.inplace else 'out-of-place'} ({cfg['name']})")
@@ -396,7 +430,11 @@ def main():
             step()
         torch.cuda.synchronize(dev)
         sync_all()
-        elapsed = shard.reduce_max_seconds(time.perf_counter() - t0, dist, red_dev)
+        mine = time.perf_counter() - t0
+        elapsed = shard.reduce_max_seconds(mine, dist, red_dev)
+        if dist is not None:
+            per_rank = shard.gather_seconds(mine, dist, red_dev)
+            extra["weak_scaling"] = {"per_rank_ms_per_step": [round(t / args.steps * 1e3, 3) for t in per_rank]}
         workload = (f"batched 1D c2c {dtype} N={n} batch={batch}/GPU forward "
                     f"{'in-place' if args.inplace else 'out-of-place'} ({cfg['name']})")
         config = {"workload": workload, "n": n, "batch_per_gpu": batch, "global_batch": world * batch,
@@ -424,6 +462,9 @@ def main():
         "dtype": dtype,
         "data": "synthetic",
         "config": config,
+        "config_key": key,  # c2 (weak, per-GPU batch fixed) or c5 (strong, global batch fixed): a curve must not mix them
+        "process_group": None if dist is None else {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                                    "collectives": "timing scalars only (max, all-gather of one double per rank)"},
         "hbm_gbps_algorithmic": round(alg_gbps, 1),
         "hbm_frac_algorithmic": round(alg_gbps / (HBM_PEAK_GBPS * world), 4),
     }

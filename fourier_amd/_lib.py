@@ -15,7 +15,7 @@ SUFFIXES = ("float", "double")
 # every symbol include/fourier.h declares
 LEGACY_SYMBOLS = [f"fourier_{op}_{s}" for s in SUFFIXES for op in ("create", "destroy", "transform_in_place", "transform")]
 EXT_SYMBOLS = [f"fourier_hip_{op}_{s}" for s in SUFFIXES
-               for op in ("create", "size", "transform_batch", "reserve", "device", "transform_batch_host", "last_status", "set_option", "describe", "model_bytes",
+               for op in ("create", "size", "transform_batch", "reserve", "device", "synchronize", "transform_batch_host", "last_status", "set_option", "describe", "model_bytes",
                           "profile", "slot_names")] + [
     "fourier_hip_status_string"]
 ALL_SYMBOLS = LEGACY_SYMBOLS + EXT_SYMBOLS
@@ -35,6 +35,7 @@ def bind(cdll):
         f = getattr(cdll, f"fourier_hip_transform_batch_host_{s}"); f.restype = ci; f.argtypes = [vp, vp, vp, sz, ci]
         f = getattr(cdll, f"fourier_hip_reserve_{s}"); f.restype = ci; f.argtypes = [vp, sz, ci]
         f = getattr(cdll, f"fourier_hip_device_{s}"); f.restype = ci; f.argtypes = [vp]
+        f = getattr(cdll, f"fourier_hip_synchronize_{s}"); f.restype = ci; f.argtypes = [vp, vp]
         f = getattr(cdll, f"fourier_hip_last_status_{s}"); f.restype = ci; f.argtypes = [vp]
         f = getattr(cdll, f"fourier_hip_set_option_{s}"); f.restype = ci; f.argtypes = [vp, cp, ll]
         f = getattr(cdll, f"fourier_hip_describe_{s}"); f.restype = cp; f.argtypes = [vp]

@@ -11,6 +11,10 @@ DEPS = [SRC, os.path.join(HERE, "csrc", "fft_kernels.h"), os.path.join(os.path.d
 OUT = os.path.join(HERE, "lib", "libfourier.so")
 OBJ = os.path.join(HERE, "lib", "engine.o")
 STATIC = os.path.join(HERE, "lib", "libfourier.a")
+# The same sources with -DFOURIER_EXPERIMENTS: the measured-slower designs (XCD-fused one-launch plan, half-tile last pass)
+# and the environment switches that select alternative plans.  Loaded only by the GPU tests of those designs and by A/B
+# tools; never by the operator layer (fourier_amd/_lib.py binds libfourier.so).
+OUT_EXPERIMENTS = os.path.join(HERE, "lib", "libfourier_experiments.so")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 LINK_FLAGS = ["--offload-arch=gfx950", "-fPIC", "-shared", "-Wl,-soname,libfourier.so.0"]
@@ -38,6 +42,37 @@ def build(force=False, extra=()):
     return OUT
 
 
+def build_experiments(force=False):
+    fresh = os.path.exists(OUT_EXPERIMENTS) and all(os.path.getmtime(OUT_EXPERIMENTS) >= os.path.getmtime(d) for d in DEPS)
+    if not force and fresh:
+        return OUT_EXPERIMENTS
+    os.makedirs(os.path.dirname(OUT_EXPERIMENTS), exist_ok=True)
+    flags = [f for f in FLAGS if not f.startswith("-Wl,-soname")]
+    subprocess.check_call([HIPCC] + flags + ["-DFOURIER_EXPERIMENTS", SRC, "-o", OUT_EXPERIMENTS])
+    return OUT_EXPERIMENTS
+
+
+def build_all(force=False):
+    """Product library and experiments library side by side (two independent compilations, ~2 minutes together)."""
+    import threading
+
+    err = []
+
+    def side():
+        try:
+            build_experiments(force)
+        except Exception as e:  # noqa: BLE001
+            err.append(e)
+
+    t = threading.Thread(target=side)
+    t.start()
+    out = build(force)
+    t.join()
+    if err:
+        raise err[0]
+    return out
+
+
 def link_soname():
     """libfourier.so.0 -> libfourier.so, the name consumers' DT_NEEDED carries (fourier-ffi/CMakeLists.txt:55)."""
     so0 = OUT + ".0"
@@ -46,4 +81,7 @@ def link_soname():
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, extra=[a for a in sys.argv[1:] if a != "--force"]))
+    if "--all" in sys.argv:
+        print(build_all(force="--force" in sys.argv))
+    else:
+        print(build(force="--force" in sys.argv, extra=[a for a in sys.argv[1:] if a != "--force"]))

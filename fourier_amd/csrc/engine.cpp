@@ -54,6 +54,17 @@ struct EngineError : std::runtime_error {
   } while (0)
 #endif
 
+// Development switches (environment variables read at plan creation) exist only in builds with -DFOURIER_EXPERIMENTS:
+// the emulator build of the CPU tests and lib/libfourier_experiments.so (A/B sessions, the GPU tests of the
+// measured-slower designs).  The product library's plan selection never depends on the environment of the process
+// that links it; FOURIER_HIP_VERBOSE (error text on stderr) is the one variable it reads.  The same flag compiles the
+// experiment kernels (fft_l2fused_kernel, fft_last_split_kernel): DESIGN.md section 4 has their measurements.
+#ifdef FOURIER_EXPERIMENTS
+static inline const char* dev_env(const char* name) { return getenv(name); }
+#else
+static inline const char* dev_env(const char*) { return nullptr; }
+#endif
+
 // kernels that use more than 48 KiB of dynamic LDS must say so once
 static void raise_smem_limit(const void* fn, size_t smem) {
   if (smem > 48 * 1024) HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -156,6 +167,7 @@ template <typename T, int L, int CG, int MODE, int IO = IO_PLAIN> static KernelI
   return k;
 }
 
+#ifdef FOURIER_EXPERIMENTS
 // last pass of length L on half tiles: the register tile (and the thread count) of a length-L/2 pass
 template <typename T, int L, int CG, int IO = IO_PLAIN> static KernelInfo make_split_info() {
   using C = TileCfg<T, L / 2, CG>;
@@ -165,6 +177,7 @@ template <typename T, int L, int CG, int IO = IO_PLAIN> static KernelInfo make_s
   k.smem = C::smem_bytes(MODE_LAST);
   return k;
 }
+#endif
 
 // tile widths (column groups of 16 bytes) per pass length; overridable for A/B builds
 #ifndef FOURIER_CG_512
@@ -191,14 +204,16 @@ template <typename T, int L, int CG, int IO = IO_PLAIN> static KernelInfo make_s
 template <typename T> static KernelInfo get_kernel(int L, int mode, int io = IO_PLAIN) {
   // first pass of length 4096 on 32-byte-wide tiles (128 KiB, two workgroups per CU): 2^22 = 4096 x 1024
   if (L == 4096 && mode == MODE_FIRST && io == IO_PLAIN) return make_info<T, 4096, FOURIER_CG_4096, MODE_FIRST>();
-  if (L == 2048 && !getenv("FOURIER_WIDE_2048")) {
+  if (L == 2048 && !dev_env("FOURIER_WIDE_2048")) {
     if (mode == MODE_FIRST)
       return io == IO_BLU_IN ? make_info<T, 2048, FOURIER_CG_2048_FIRST, MODE_FIRST, IO_BLU_IN>()
                              : make_info<T, 2048, FOURIER_CG_2048_FIRST, MODE_FIRST>();
     // half tiles for the last pass were measured 5-7 % SLOWER than the 16-column kernel (profiles/r02_s2_*_ab.jsonl:
     // 13.6-14.0 vs 13.1 ms per 1024 transforms of 2^22); kept behind FOURIER_SPLIT_2048=1 for experiments
-    if (mode == MODE_LAST && getenv("FOURIER_SPLIT_2048"))
+#ifdef FOURIER_EXPERIMENTS
+    if (mode == MODE_LAST && dev_env("FOURIER_SPLIT_2048"))
       return io == IO_BLU_OUT ? make_split_info<T, 2048, FOURIER_CG_1024, IO_BLU_OUT>() : make_split_info<T, 2048, FOURIER_CG_1024>();
+#endif
   }
 #define FK(LL, CGG)                                                                              \
   case LL:                                                                                       \
@@ -335,6 +350,7 @@ template <typename T, int L1, int CG1, int L2, int CG2> static FusedInfo make_fu
 }
 // N * sizeof(complex) <= 2 MiB and two passes: f32 2^16 .. 2^18, f64 2^15 .. 2^17 (64 KiB tiles, 256 threads)
 template <typename T> static bool get_fused_kernel(int k, FusedInfo& info) {
+#ifdef FOURIER_EXPERIMENTS
   if constexpr (sizeof(T) == 4) {
     switch (k) {
       case 16: info = make_fused_info<T, 256, 16, 256, 16>(); return true;
@@ -350,6 +366,10 @@ template <typename T> static bool get_fused_kernel(int k, FusedInfo& info) {
       default: return false;
     }
   }
+#else
+  (void)k; (void)info;
+  return false;  // measured 30-45 % slower than the two-launch plan: not in the product build
+#endif
 }
 
 enum { MODE_ODD_LAST = 5 };  // host-side tag for odd_last_kernel (final radix-3^b pass of a 2^a*3^b plan)
@@ -446,7 +466,7 @@ template <typename T> class Pow2Engine {
     std::vector<int> lens;
     KernelInfo tl;
     int tl1 = 0, tl2 = 0;
-    if (p3 == 1 && !getenv("FOURIER_NO_TWOLEVEL") && get_twolevel_kernel<T>(k, tl, tl1, tl2)) {
+    if (p3 == 1 && !dev_env("FOURIER_NO_TWOLEVEL") && get_twolevel_kernel<T>(k, tl, tl1, tl2)) {
       // one launch, one HBM round trip: both passes inside a workgroup
       auto pass = std::unique_ptr<Pass>(new Pass());
       pass->mode = MODE_TWOLEVEL;
@@ -481,12 +501,12 @@ template <typename T> class Pow2Engine {
       tiny_ = true;
     } else if (k <= 11) {
       lens = {k};
-    } else if (k == 22 && plain && p3 == 1 && getenv("FOURIER_PLAN_4096")) {
+    } else if (k == 22 && plain && p3 == 1 && dev_env("FOURIER_PLAN_4096")) {
       // experiment: 4096 (first pass on 32-byte-wide tiles) x 1024 instead of 2048 x 2048.  f32: 27.3 vs 25.8-26.5 ms per
       // 1024 transforms; f64: 27.4 vs 28.9 ms per 512 but 7.9 vs 7.4 ms per 128 (profiles/r02_s3_*.jsonl,
       // r02_s4_sizes.jsonl) -- no consistent gain, so the default stays 2048 x 2048
       lens = {12, 10};
-    } else if (k == 23 && plain && p3 == 1 && (sizeof(T) == 4 ? !getenv("FOURIER_THREE_PASS_2P23") : getenv("FOURIER_TWO_PASS_2P23") != nullptr)) {
+    } else if (k == 23 && plain && p3 == 1 && (sizeof(T) == 4 ? !dev_env("FOURIER_THREE_PASS_2P23") : dev_env("FOURIER_TWO_PASS_2P23") != nullptr)) {
       // 2^23 = 4096 x 2048: two HBM round trips (first pass of length 4096 on 32-byte-wide tiles, 16-column last pass of
       // length 2048) instead of three at 256 x 256 x 128.  f32: 27.4-30.0 vs 34.1-34.8 ms per 512 transforms (default);
       // f64: 30.8-35.2 vs 33.5-33.8 ms per 256, no consistent gain (opt-in) -- profiles/r02_s16_plan_2p23_ab.jsonl
@@ -621,7 +641,7 @@ template <typename T> class Pow2Engine {
     fused_grid_ = (unsigned)std::max(1, per_cu) * (unsigned)std::max(1, cus);  // persistent: every workgroup resident
     const size_t bytes = n_ * sizeof(cpx<T>);
     fused_depth_ = bytes <= (512u << 10) ? 3 : 2;  // windows per XCD: <= 2 MiB of the 4 MiB L2 (profiles/r02_membench.jsonl, l2x)
-    if (const char* e = getenv("FOURIER_L2_FUSED")) fused_on_ = atoi(e) != 0;
+    if (const char* e = dev_env("FOURIER_L2_FUSED")) fused_on_ = atoi(e) != 0;
   }
   bool has_l2fused() const { return fused_.fn != nullptr; }
   bool l2fused_enabled() const { return fused_on_ && fused_.fn; }
@@ -665,6 +685,14 @@ template <typename T> class Pow2Engine {
       PROF_BEGIN(prof, slot);
       FOURIER_LAUNCH(fused_.fn, grid, fused_.NT, fused_.smem, stream, f);
       PROF_END(prof);
+      // The kernel bounds its inter-workgroup waits (spin_limit) and raises ctrl[1] when one gives up; every workgroup
+      // then returns early and part of the output is unwritten.  That must not read as success: the flag comes back
+      // before the call returns (this plan option is therefore synchronous) and turns into FOURIER_HIP_RUNTIME_ERROR.
+      fused_flag_.ensure(sizeof(uint32_t));
+      HIP_CHECK(hipMemcpyAsync(fused_flag_.h, (const uint32_t*)fused_ctrl_.p + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      if (*(const volatile uint32_t*)fused_flag_.h != 0)
+        throw EngineError(::fourier::c::FOURIER_HIP_RUNTIME_ERROR, "l2_fused: an inter-workgroup wait timed out; the output is incomplete");
     }
   }
 
@@ -867,7 +895,7 @@ template <typename T> class Pow2Engine {
     // this kernel (only) reads a per-transform table indexed like the data, the transformed chirp: let every XCD own an
     // eighth of the TILES of every transform, so that its 1/8 of the table (2 MiB of 16 at M = 2^21) stays in its L2
     // (with streaming stores: conv 4.5 vs 4.75 ms per 512 at C4; the plain passes lose 10-15 % under this order)
-    static const bool sliced = getenv("FOURIER_CONV_XCD_PLAIN") == nullptr;  // development switch, read once
+    static const bool sliced = dev_env("FOURIER_CONV_XCD_PLAIN") == nullptr;  // development switch, read once
     if (sliced && a.nxcd == 8 && a.xcd_interleave == 0 && a.tiles % 8 == 0) a.xcd_interleave = 2;
     a.scale = 1.0;
     const uint64_t grid = (uint64_t)batch * a.tiles;
@@ -887,6 +915,7 @@ template <typename T> class Pow2Engine {
   bool fused_on_ = false;
   unsigned fused_grid_ = 0, fused_depth_ = 2;
   mutable DevBuf fused_window_, fused_ctrl_;
+  mutable PinnedBuf fused_flag_;  // ctrl[1] (abort flag) of the last fused launch, read back before the call returns
   std::string desc_override_;
   std::vector<std::unique_ptr<Pass>> passes_;
   std::map<int, std::unique_ptr<StageTables<T>>> stage_;
@@ -913,7 +942,7 @@ template <typename T> class MixedEngine {
   }
   static bool handles(size_t n) {
     uint32_t c[5];
-    const char* cap = getenv("FOURIER_MIX_MAX_N");  // development switch: A/B against the Bluestein / odd-pass routes
+    const char* cap = dev_env("FOURIER_MIX_MAX_N");  // development switch: A/B against the Bluestein / odd-pass routes
     return n <= (cap ? std::min<size_t>(MAX_N, (size_t)atoll(cap)) : MAX_N) && !is_pow2(n) && factor(n, c);
   }
   // twiddle.rs:7-19 verbatim: theta = (index*2) as f64 * PI / size as f64; (cos, -sin) cast to T.
@@ -945,7 +974,7 @@ template <typename T> class MixedEngine {
     // fill the 256 threads better lose more in occupancy than they gain, r01 session 9)
     group_ = (uint32_t)std::max<size_t>(1, 1024 / n);
     fn_ = &mixed_radix_kernel<T>;
-    if (!getenv("FOURIER_MIX_GENERIC")) {  // lengths with a compile-time specialisation (same arithmetic, constant index math)
+    if (!dev_env("FOURIER_MIX_GENERIC")) {  // lengths with a compile-time specialisation (same arithmetic, constant index math)
 #define FOURIER_MIX_CT(NN)                                                      \
   case NN:                                                                      \
     if constexpr ((size_t)NN <= MAX_N) { fn_ = &mixed_radix_kernel_ct<T, NN>; group_ = mix_group<T>(NN); nbuf_ = mix_inplace<T>(NN) ? 1 : 2; } \
@@ -1263,6 +1292,12 @@ template <typename T> class Plan {
     }
   }
 
+  // Wait for everything queued on `stream` of the plan's device (the blocking half of a stream-ordered batched call).
+  void synchronize(hipStream_t stream) const {
+    DeviceGuard g(device_);
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
+
   // Legacy host-buffer path (fourier-ffi/src/lib.rs:31-59): H2D, one transform, D2H, synchronous.
   void exec_host(const void* h_in, void* h_out, int code) const {
     if (!h_in || !h_out) throw EngineError(::fourier::c::FOURIER_HIP_INVALID_ARGUMENT, "null buffer");
@@ -1361,7 +1396,7 @@ template <typename T> class Plan {
     // forward inner plan: the larger pass first (2048 x 1024 at M = 2^21), so the conv kernel runs at the SHORTER length
     // and the end passes at the longer one.  FOURIER_BLU_SHORT_FIRST=1 (experiment) swaps the roles: 1024 x 2048 forward,
     // end passes of length 1024, conv kernel at 2048.
-    const bool short_first = getenv("FOURIER_BLU_SHORT_FIRST") != nullptr;
+    const bool short_first = dev_env("FOURIER_BLU_SHORT_FIRST") != nullptr;
     eng_.reset(new Pow2Engine<T>(m_, short_first));
     eng_->enable_bluestein_fusion();
     fused_ = eng_->can_fuse_bluestein();
@@ -1540,6 +1575,10 @@ namespace fc = ::fourier::c;
   }                                                                                                              \
   extern "C" int fourier_hip_device_##SUFFIX(const fc::fourier_fft_##SUFFIX* h) {                                \
     return h ? ((const Plan<T>*)h)->device() : -1;                                                               \
+  }                                                                                                              \
+  extern "C" int fourier_hip_synchronize_##SUFFIX(const fc::fourier_fft_##SUFFIX* h, void* stream) {            \
+    const Plan<T>* p = (const Plan<T>*)h;                                                                        \
+    return guarded<T>(p, [&] { p->synchronize((hipStream_t)stream); });                                          \
   }                                                                                                              \
   extern "C" int fourier_hip_transform_batch_host_##SUFFIX(const fc::fourier_fft_##SUFFIX* h, const std::complex<T>* in, \
                                                            std::complex<T>* out, size_t batch, int code) {      \

@@ -435,6 +435,43 @@ __device__ __forceinline__ void units_batched(const Ld& ld, const Use& use) {
   }
 }
 
+// x[v][k] *= t[k], k = 1..15 (t[0] = 1): the stage twiddles of one thread, sixteen consecutive table entries.  All of
+// them (f64: half of them) are loaded in one batch -- under FOURIER_STAGE_TW_BATCHED; otherwise hipcc picks the grouping
+#ifndef FOURIER_STAGE_TW_BATCH
+#define FOURIER_STAGE_TW_BATCH 8
+#endif
+template <typename T, int VEC>
+__device__ __forceinline__ void stage_twiddle(cpx<T> (&x)[VEC][16], const cpx<T>* t) {
+#if FOURIER_STAGE_TW_BATCH > 0
+  constexpr int PER = 16 / (int)sizeof(cpx<T>), NU = 16 / PER, B = FOURIER_STAGE_TW_BATCH < NU ? FOURIER_STAGE_TW_BATCH : NU;
+#pragma unroll
+  for (int u0 = 0; u0 < NU; u0 += B) {
+    Unit16<T> u[B];
+#pragma unroll
+    for (int q = 0; q < B; ++q) u[q] = *(const Unit16<T>*)(t + (u0 + q) * PER);
+    FOURIER_SCHED_FENCE();
+#pragma unroll
+    for (int q = 0; q < B; ++q)
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const int k = (u0 + q) * PER + j;
+        if (k == 0) continue;
+        const cpx<T> w{u[q].a[2 * j], u[q].a[2 * j + 1]};
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) x[v][k] = cmul(x[v][k], w);
+      }
+    FOURIER_SCHED_FENCE();
+  }
+#else
+#pragma unroll
+  for (int k = 1; k < 16; ++k) {
+    const cpx<T> w = t[k];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) x[v][k] = cmul(x[v][k], w);
+  }
+#endif
+}
+
 template <typename T>
 __device__ __forceinline__ cpx<T> two_level_twiddle(const PassArgs& a, uint64_t e) {
   const cpx<T>* lo = (const cpx<T>*)a.tw_lo;
@@ -503,13 +540,7 @@ __device__ __forceinline__ void tile_core(RegTile<T, L, CG>& x, int& th, int& cg
 
   if constexpr (Q > 1) {
     if constexpr (DO_MATH) {
-      const cpx<T>* t1 = tw1 + th * 16;
-#pragma unroll
-      for (int k = 1; k < 16; ++k) {
-        const cpx<T> w = t1[k];
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) x[v][k] = cmul(x[v][k], w);
-      }
+      stage_twiddle<T, VEC>(x, tw1 + th * 16);
     }
     {
       constexpr bool remap = (MODE == MODE_FIRST) && (R3 == 1);
@@ -542,13 +573,7 @@ __device__ __forceinline__ void tile_core(RegTile<T, L, CG>& x, int& th, int& cg
     if constexpr (R3 > 1) {
       // here R2 == 16, one butterfly per thread: q = th, j = th & 15, i = th >> 4
       if constexpr (DO_MATH) {
-        const cpx<T>* t2 = tw2 + (th >> 4) * 16;
-#pragma unroll
-        for (int k = 1; k < 16; ++k) {
-          const cpx<T> w = t2[k];
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) x[v][k] = cmul(x[v][k], w);
-        }
+        stage_twiddle<T, VEC>(x, tw2 + (th >> 4) * 16);
       }
       {
         constexpr bool remap = (MODE == MODE_FIRST);
@@ -590,6 +615,15 @@ __device__ __forceinline__ void tile_core(RegTile<T, L, CG>& x, int& th, int& cg
 // tile each (two per CU, load and compute phases overlap) instead of one 1024-thread workgroup whose 256 KiB tile
 // fills the CU's registers; the tile is read twice, the second time from the XCD's L2 (the two workgroups are adjacent
 // blocks of one XCD), written once.
+#ifdef FOURIER_AB_NO_CHIRP  // timing experiment only (wrong results): the chirp is not read
+template <typename T> __device__ __forceinline__ Unit16<T> ab_ones() { Unit16<T> u; for (int i = 0; i < (int)(16 / sizeof(T)); ++i) u.a[i] = (i & 1) ? (T)0 : (T)1; return u; }
+#define FOURIER_AB_CHIRP_LOAD(rc, off) ab_ones<T>()
+#else
+#define FOURIER_AB_CHIRP_LOAD(rc, off) buf_load_unit<T>(rc, off)
+#endif
+#ifndef FOURIER_BLU_OUT_ST_NT
+#define FOURIER_BLU_OUT_ST_NT 0
+#endif
 struct NoHook {
   __device__ __forceinline__ void operator()() const {}
 };
@@ -677,7 +711,7 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
 #pragma unroll
     for (int r = 0; r < 8; ++r) d[r] = buf_load_unit<T, LDAUX>(rd, voff + (uint32_t)r * rowb);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) c[r] = buf_load_unit<T>(rc, voff + (uint32_t)r * rowb);
+    for (int r = 0; r < 8; ++r) c[r] = FOURIER_AB_CHIRP_LOAD(rc, voff + (uint32_t)r * rowb);
 #pragma unroll
     for (int r = 0; r < 8; ++r)
 #pragma unroll
@@ -778,7 +812,7 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
     const uint32_t rowb = (uint32_t)(a.s * (uint64_t)(KM * Q) * sizeof(cpx<T>));
     Unit16<T> c[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) c[r] = buf_load_unit<T>(rc, voff + (uint32_t)r * rowb);
+    for (int r = 0; r < 8; ++r) c[r] = FOURIER_AB_CHIRP_LOAD(rc, voff + (uint32_t)r * rowb);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       Unit16<T> u;
@@ -790,7 +824,9 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
         if (a.blu_swap) y = {y.im, y.re};
         u.a[2 * v] = y.re * scale; u.a[2 * v + 1] = y.im * scale;
       }
-      buf_store_unit<T, STAUX>(ro, voff + (uint32_t)r * rowb, u);
+      // no streaming hint: the user rows of an odd-length f32 batch are only 8-byte aligned, a wave's 128-byte row segment
+      // then straddles two lines, and the L2 must be allowed to merge the halves (NT: +29 % bytes written, PMC, round 3)
+      buf_store_unit<T, FOURIER_BLU_OUT_ST_NT ? STAUX : BUF_PLAIN>(ro, voff + (uint32_t)r * rowb, u);
     }
   } else {
     // output row of register r: j0 + s * (KM*L*i + KM*(th + Q*r) + par); uniform part in the descriptor base
@@ -810,7 +846,11 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
         }
         u.a[2 * v] = y.re; u.a[2 * v + 1] = y.im;
       }
+#ifdef FOURIER_AB_PTR_STORES  // A/B: per-lane 64-bit pointers (the round-2 form)
+      store_unit<T, STPOL == POL_NT>((char*)(out + base + rows * (uint64_t)r) + voff, u);
+#else
       buf_store_unit<T, STAUX>(make_rsrc(out + base + rows * (uint64_t)r), voff, u);
+#endif
     }
   }
 }
@@ -1066,7 +1106,13 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16)
     const BufRsrc rw = make_rsrc(a.mul);
     const uint32_t voff = (uint32_t)(((uint64_t)(t / CG) * a.cn + c0 + (uint64_t)((t % CG) * VEC)) * sizeof(cpx<T>));
     units_batched<T, FOURIER_CONV_W_BATCH>(
-        [&](int r) { return buf_load_unit<T, FOURIER_CONV_W_NT != 0 ? BUF_NT : BUF_PLAIN>(rw, voff, (uint32_t)r * rowb); },
+        [&](int r) {
+#ifdef FOURIER_AB_NO_W
+          Unit16<T> u1; for (int i = 0; i < (int)(16 / sizeof(T)); ++i) u1.a[i] = (i & 1) ? (T)0 : (T)1; return u1;
+#else
+          return buf_load_unit<T, FOURIER_CONV_W_NT != 0 ? BUF_NT : BUF_PLAIN>(rw, voff, (uint32_t)r * rowb);
+#endif
+        },
         [&](int r, const Unit16<T>& u) {
 #pragma unroll
           for (int v = 0; v < VEC; ++v) {
@@ -1114,15 +1160,8 @@ __device__ __forceinline__ void two_stage_fft(RegTile<T, L, CG>& x, int th, int 
   static_assert(C::R3 == 1 && Q > 1, "two_stage_fft: 32 <= L <= 256");
 #pragma unroll
   for (int v = 0; v < VEC; ++v) dft16(x[v]);
-  const cpx<T>* t1 = tw1 + th * 16;
   FOURIER_SCHED_FENCE();
-#pragma unroll
-  for (int k = 1; k < 16; ++k) {
-    const cpx<T> w = t1[k];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) x[v][k] = cmul(x[v][k], w);
-    if ((k & 3) == 3) FOURIER_SCHED_FENCE();
-  }
+  stage_twiddle<T, VEC>(x, tw1 + th * 16);
   lds_exchange<T, L, CG, 0>(x, smem, cg, [=](int r) { return 16 * th + r; }, th, cg, site);
   FOURIER_SCHED_FENCE();
   constexpr int NB2 = 16 / R2;

@@ -105,6 +105,13 @@ class Fft:
         if st != 0:
             raise FourierError(self._L.fourier_hip_status_string(st).decode())
 
+    def synchronize(self, stream=0):
+        """Blocks until everything queued on `stream` (a HIP stream handle, 0 = the NULL stream) of the plan's device has
+        finished: the wait that follows a stream-ordered transform_batch_ptr when no other runtime owns the stream."""
+        st = getattr(self._L, f"fourier_hip_synchronize_{self._suffix}")(self._h, stream)
+        if st != 0:
+            raise FourierError(self._L.fourier_hip_status_string(st).decode())
+
     def reserve(self, batch, in_place=False):
         """Pre-size the plan-owned device buffers so that later batched calls of up to `batch` transforms never
         allocate (hipMalloc synchronises the device; needed before HIP-graph capture)."""

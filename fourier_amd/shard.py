@@ -33,6 +33,18 @@ def reduce_max_seconds(seconds, dist=None, device=None):
     return float(t.item())
 
 
+def gather_seconds(seconds, dist=None, device=None):
+    """Every rank's own figure, in rank order (the multi-GPU bench line carries them so that a straggler is visible)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(seconds)]
+    import torch
+
+    mine = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
 def gather_rows(local_rows, dist=None):
     """Gather per-rank numpy row blocks (used for checksums / parity samples, not in the data path)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
@@ -70,12 +82,20 @@ class DeviceShardedFft:
         return [0] * len(self.devices)
 
     def transform(self, inputs, outputs, transform):
-        """inputs/outputs: per-shard torch CUDA tensors (or raw (ptr, batch) pairs).  Returns when every shard is done."""
+        """inputs/outputs: per-shard torch CUDA tensors (or raw (ptr, batch) pairs, which run on the NULL stream of
+        their device).  Returns when every shard is done: each worker synchronises its stream before it exits."""
         import threading
 
         if not (len(inputs) == len(outputs) == len(self.plans)):
             raise ValueError("one input and one output per shard")
         handles = self._stream_handles(inputs)
+        # torch's current stream is thread-local: the streams the CALLER produced the inputs on are looked up here, on
+        # the calling thread, and handed to the workers (a worker thread would only ever see the default stream)
+        producers = [None] * len(self.plans)
+        if _is_torch_tensor(inputs[0]):
+            import torch
+
+            producers = [torch.cuda.current_stream(d) for d in self.devices]
         errors = [None] * len(self.plans)
 
         def work(g):
@@ -89,12 +109,13 @@ class DeviceShardedFft:
                     if x.numel() != y.numel() or x.numel() % plan.size() != 0:
                         raise ValueError(f"shard {g}: not a whole number of transforms")
                     with torch.cuda.device(plan.device):
-                        self._streams[g].wait_stream(torch.cuda.current_stream(plan.device))  # inputs produced on the current stream
+                        self._streams[g].wait_stream(producers[g])  # inputs produced on the caller's current stream
                         plan.transform_batch_ptr(x.data_ptr(), y.data_ptr(), x.numel() // plan.size(), int(transform), handles[g])
                         self._streams[g].synchronize()
                 else:
                     (xp, nb), (yp, _) = x, y
                     plan.transform_batch_ptr(xp, yp, nb, int(transform), 0)
+                    plan.synchronize(0)  # fourier_hip_synchronize_*: the NULL stream of the plan's device
             except Exception as e:  # re-raised on the calling thread
                 errors[g] = e
 

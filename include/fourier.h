@@ -122,6 +122,12 @@ int fourier_hip_reserve_double(const FOURIER_STRUCT fourier_fft_double *, FOURIE
 int fourier_hip_device_float(const FOURIER_STRUCT fourier_fft_float *);
 int fourier_hip_device_double(const FOURIER_STRUCT fourier_fft_double *);
 
+/* Blocks until everything queued on `stream` (a hipStream_t, NULL = the NULL stream) of the plan's device has
+ * finished -- the wait that follows a stream-ordered fourier_hip_transform_batch_* for a caller that does not own a
+ * HIP runtime of its own (the Rust shim, a ctypes binding). */
+int fourier_hip_synchronize_float(const FOURIER_STRUCT fourier_fft_float *, void *stream);
+int fourier_hip_synchronize_double(const FOURIER_STRUCT fourier_fft_double *, void *stream);
+
 /* Batched `Fft::transform` on HOST memory -- what a caller of the reference holds (one slice per transform,
  * fourier-algorithms/src/fft.rs:48-61), `batch` of them contiguously.  The transforms are streamed through the
  * device in chunks (pinned staging; the host-to-device copy of one chunk, the kernels of the previous one and the
@@ -134,10 +140,12 @@ int fourier_hip_transform_batch_host_double(const FOURIER_STRUCT fourier_fft_dou
                                             const FOURIER_COMPLEX_DOUBLE_TYPE *in, FOURIER_COMPLEX_DOUBLE_TYPE *out,
                                             FOURIER_SIZE_TYPE batch, int transform);
 
-/* Status of the LAST call made on this handle (every entry point that takes a handle resets it to
- * FOURIER_HIP_OK on entry and records its own failure, if any) and the text of a status.  The legacy
- * `void` entry points of Part 1 report through this query; a successful call after a failed one reads
- * FOURIER_HIP_OK again. */
+/* Status of the LAST call that can fail made on this handle, and the text of a status.  The entry points that do
+ * work -- the four legacy `void` transforms of Part 1, fourier_hip_transform_batch[_host]_*, _reserve_*,
+ * _synchronize_*, _profile_* -- reset it to FOURIER_HIP_OK on entry and record their own failure, if any: a
+ * successful call after a failed one reads FOURIER_HIP_OK again, and the legacy `void` entry points report through
+ * this query only.  The pure queries (_size_*, _device_*, _describe_*, _model_bytes_*, _slot_names_*, _last_status_*
+ * itself) and _set_option_* (which returns its own status) leave it untouched. */
 int fourier_hip_last_status_float(const FOURIER_STRUCT fourier_fft_float *);
 int fourier_hip_last_status_double(const FOURIER_STRUCT fourier_fft_double *);
 const char *fourier_hip_status_string(int status);
@@ -149,16 +157,19 @@ const char *fourier_hip_status_string(int status);
  *                  0 = use the output buffer as intermediate when out of place (default)
  *   "xcd_swizzle"  1 (default) = XCD-aware workgroup->tile mapping (each XCD owns a contiguous run of transforms),
  *                  2 = XCDs interleaved over adjacent transforms, 3 = each XCD owns an eighth of every transform's
- *                  tiles (both measured slower, kept for experiments), 0 = plain blockIdx order
+ *                  tiles, 4 = contiguous transforms per XCD walked band-major (all measured slower or equal, kept
+ *                  for experiments), 0 = plain blockIdx order
  *   "bluestein_fusion" 1 (default where the inner FFT has >= 2 passes) = chirp steps fused into the inner passes
  *   "host_chunk_bytes" bytes of one chunk of fourier_hip_transform_batch_host_* (default 32 MiB, four in flight)
  *   "bluestein_conv"   1 (default with bluestein_fusion) = the forward inner FFT's last pass, the multiply by the
  *                  transformed chirp and the inverse inner FFT's first pass run as one launch
- *   "l2_fused"     1 = run both passes of a two-pass plan in ONE launch with the intermediate parked in the XCD's L2
- *                  (persistent workgroups, per-XCD work queues; f32 2^16..2^18, f64 2^15..2^17 only, INVALID_ARGUMENT
- *                  elsewhere).  Same results bit for bit; measured slower than the two-launch plan on MI355X
- *                  (DESIGN.md section 4), hence 0 by default.  "l2_fused_depth" (1..8 windows per XCD) and
- *                  "l2_fused_grid" (persistent workgroups) tune it. */
+ *   "l2_fused"     (builds with -DFOURIER_EXPERIMENTS only; INVALID_ARGUMENT in the product library) 1 = run both
+ *                  passes of a two-pass plan in ONE launch with the intermediate parked in the XCD's L2 (persistent
+ *                  workgroups, per-XCD work queues; f32 2^16..2^18, f64 2^15..2^17 only).  Same results bit for
+ *                  bit; measured 30-45 % slower than the two-launch plan on MI355X.  Calls
+ *                  under this option are synchronous: the kernel's bounded waits report a time-out through a flag
+ *                  that is read back before the call returns (FOURIER_HIP_RUNTIME_ERROR).  "l2_fused_depth" (1..8
+ *                  windows per XCD) and "l2_fused_grid" (persistent workgroups) tune it. */
 int fourier_hip_set_option_float(FOURIER_STRUCT fourier_fft_float *, const char *key, long long value);
 int fourier_hip_set_option_double(FOURIER_STRUCT fourier_fft_double *, const char *key, long long value);
 

@@ -13,10 +13,18 @@ OUT = os.path.join(HERE, "libfourier_emu.so")
 
 
 def build():
-    if os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
+    fresh = lambda: os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS)  # noqa: E731
+    if fresh():
         return OUT
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFOURIER_EMU", "-include", os.path.join(HERE, "hipemu.h"),
-                           "-shared", "-fPIC", "-pthread", "-o", OUT, SRC])
+    import fcntl
+
+    with open(OUT + ".lock", "w") as lock:  # pytest-xdist workers: one builds, the others wait and find it fresh
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not fresh():
+            tmp = OUT + f".{os.getpid()}.tmp"
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFOURIER_EMU", "-DFOURIER_EXPERIMENTS", "-include", os.path.join(HERE, "hipemu.h"),
+                                   "-shared", "-fPIC", "-pthread", "-o", tmp, SRC])
+            os.replace(tmp, OUT)
     return OUT
 
 

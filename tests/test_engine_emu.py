@@ -322,15 +322,15 @@ def test_chunking_and_scratch_options_do_not_change_results(fa):
         make(fa, n, np.complex64).set_option("no_such_option", 1)
     # the workgroup -> tile mappings are bijections: same bits whatever the mapping (two-pass, Bluestein conv and
     # one-launch plans; batch sizes that do and do not divide by the XCD count)
-    for n2, batch2 in ((1 << 16, 3), (1 << 16, 8), (40000, 2), (4096, 5)):
+    for n2, batch2 in ((1 << 16, 3), (1 << 16, 8), (1 << 16, 16), (40000, 2), (40000, 8), (4096, 5)):
         x2 = np.stack([hash_normal(400 + b, n2) for b in range(batch2)]).astype(np.complex64)
         base2 = run_batch(make(fa, n2, np.complex64), x2, 0)
-        for mode in (0, 1, 2, 3):
+        for mode in (0, 1, 2, 3, 4):  # 4 = band-major walk of each XCD's own transforms (batch a multiple of 8)
             plan = make(fa, n2, np.complex64)
             plan.set_option("xcd_swizzle", mode)
             assert np.array_equal(run_batch(plan, x2, 0), base2), (n2, batch2, mode)
     with pytest.raises(fa.FourierError):
-        make(fa, n, np.complex64).set_option("xcd_swizzle", 4)
+        make(fa, n, np.complex64).set_option("xcd_swizzle", 5)
 
 
 def test_out_of_memory_for_the_scratch_falls_back_to_smaller_chunks(fa, monkeypatch):

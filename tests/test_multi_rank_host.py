@@ -30,6 +30,8 @@ y = np.empty_like(x)
 plan.transform_batch_ptr(x.ctypes.data, y.ctypes.data, hi - lo, int(fa.Transform.Fft))
 rows = shard.gather_rows((lo, hi, y), dist)
 tmax = shard.reduce_max_seconds(0.25 * (rank + 1), dist)
+every = shard.gather_seconds(0.25 * (rank + 1), dist)
+assert every == [0.25 * (r + 1) for r in range(world)], every  # rank order, on every rank
 if rank == 0:
     full = np.concatenate([r[2] for r in sorted(rows, key=lambda r: r[0])])
     covered = sorted((r[0], r[1]) for r in rows)
