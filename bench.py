@@ -150,6 +150,18 @@ def quick_config(fourier_amd, torch, dev, key, reps=3):
     kernels = kernel_profile(plan, x.data_ptr(), y.data_ptr(), batch, stream, reps=1)
     alg = 2.0 * n * esz
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+    # HBM-side bytes per launch from the committed PMC passes (tools/gpu_r03_pmc.sh -> profiles/traffic_latest.json,
+    # "configs"): per kernel, with the ratio to the algorithmic bytes of one launch (batch x 2 x N x sizeof(complex))
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as f:
+            tk = json.load(f).get("configs", {}).get(key, {})
+        traffic = {k: {"hbm_side_bytes": v["hbm_side_bytes"], "over_algorithmic": round(v["hbm_side_bytes"] / (batch * alg), 3),
+                       "l2_hit_rate": None if v.get("l2_hit_rate") is None else round(v["l2_hit_rate"], 3)}
+                   for k, v in tk.get("kernels", {}).items() if k in kernels}
+        traffic = {"source": tk.get("source"), "kernels": traffic} if traffic else None
+    except Exception:
+        traffic = None
     out = {
         "workload": f"{c['name']}: {dtype} N={n} batch={batch}" + (" (one chunk of the 65536-transform job)" if key == "c5" else ""),
         "plan": plan.describe(), "ms_per_step": round(t * 1e3, 3),
@@ -158,6 +170,7 @@ def quick_config(fourier_amd, torch, dev, key, reps=3):
         "dominant_kernel": dom,
         "dominant_kernel_frac": round(batch * alg / (kernels[dom]["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
         "kernels_ms": {k: round(v["ms_per_step"], 3) for k, v in kernels.items()},
+        "traffic": traffic,
     }
     del x, y, plan
     torch.cuda.empty_cache()
@@ -210,20 +223,24 @@ def cpu_baseline(torch, plan, hx, n, dtype, dev, stream, cores):
     plan.transform_batch_ptr(xs.data_ptr(), ys.data_ptr(), sample, int(Transform.Fft), stream)
     torch.cuda.synchronize(dev)
     got = ys.cpu().numpy()
-    # one oracle plan per thread (plans are Send, not Sync).  The port is memory-bound well before all
-    # hardware threads are busy, so a few thread counts are timed and the best aggregate is reported,
-    # with the count that produced it.
+    # one oracle plan per thread (plans are Send, not Sync).  Persistent workers pinned across the affinity mask, each
+    # building its own plan and first-touching its slice of the staged input and of the output (oracle.OracleBatch); a
+    # warm-up pass over the WHOLE sample precedes the timed one, so the timed region holds transforms only -- no thread
+    # creation, no page faults, no remote-node tables.  Thread counts from all host threads down to 1/32 of them.
     ref = np.empty_like(hx)
-    tried = {}
-    for nt in sorted({max(1, cores >> k) for k in range(6)}, reverse=True):  # all, 1/2 ... 1/32 of the host threads
+    tried, pinned = {}, {}
+    for nt in sorted({max(1, cores >> k) for k in range(6)}, reverse=True):
         ob = O.OracleBatch(n, hx.dtype, nthreads=nt)
-        ob.run(hx[: min(sample, nt)], O.FFT, out=ref[: min(sample, nt)])  # warm-up (page faults)
+        ob.stage(hx)
+        ob.run_staged(ref, O.FFT)  # warm-up over everything
         t0 = time.perf_counter()
-        ob.run(hx, O.FFT, out=ref)
+        ob.run_staged(ref, O.FFT)
         tried[nt] = time.perf_counter() - t0
+        pinned[nt] = sum(1 for c in ob.cpus() if c >= 0)
         del ob
     used = min(tried, key=tried.get)
     cpu_s = tried[used]
+    all_s = tried[max(tried)]
     # the reference itself is single-threaded (one plan, one slice per call): the same port on ONE core, as the
     # reference's AVX clone (vector/avx.rs wide passes + radix_4_stride_1_avx_f32, what an AVX host runs; the
     # multi-thread legs above use it too) and as the generic scalar functions (what round 1 timed)
@@ -246,7 +263,12 @@ def cpu_baseline(torch, plan, hx, n, dtype, dev, stream, cores):
     base = {
         "value": round(sample * flops_per / cpu_s / 1e9, 2), "unit": "GFLOP/s", "cores": used,
         "host_threads_available": cores,
+        "all_threads": {"threads": max(tried), "value": round(sample * flops_per / all_s / 1e9, 2), "unit": "GFLOP/s",
+                        "pinned_workers": pinned[max(tried)]},
+        "best": {"threads": used, "value": round(sample * flops_per / cpu_s / 1e9, 2), "unit": "GFLOP/s"},
         "threads_tried_gflops": {str(k): round(sample * flops_per / v / 1e9, 2) for k, v in tried.items()},
+        "harness": "persistent pinned workers, one plan per worker built on its own CPU, input staged and output first "
+                   "touched slice by slice by the owning worker, one full warm-up pass before the timed pass",
         "kind": "port", "clone": "avx" if O.have_avx() else "generic",
         "sample": f"{sample} of the same transforms ({dtype} N={n}, out-of-place), "
                   f"one oracle plan per thread on {used} threads, {cpu_s:.2f} s wall",

@@ -21,8 +21,9 @@ EXT_SYMBOLS = [f"fourier_hip_{op}_{s}" for s in SUFFIXES
 ALL_SYMBOLS = LEGACY_SYMBOLS + EXT_SYMBOLS
 
 
-def bind(cdll):
-    """Attach argtypes/restypes for every entry point of include/fourier.h to a loaded CDLL."""
+def bind(cdll, strict=True):
+    """Attach argtypes/restypes for every entry point of include/fourier.h to a loaded CDLL.  strict=False (A/B tools that
+    load libraries built from older sources) tolerates entry points added since."""
     vp, sz, ci, ll, cp = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_longlong, ctypes.c_char_p
     for s in SUFFIXES:
         f = getattr(cdll, f"fourier_create_{s}"); f.restype = vp; f.argtypes = [sz]
@@ -35,7 +36,8 @@ def bind(cdll):
         f = getattr(cdll, f"fourier_hip_transform_batch_host_{s}"); f.restype = ci; f.argtypes = [vp, vp, vp, sz, ci]
         f = getattr(cdll, f"fourier_hip_reserve_{s}"); f.restype = ci; f.argtypes = [vp, sz, ci]
         f = getattr(cdll, f"fourier_hip_device_{s}"); f.restype = ci; f.argtypes = [vp]
-        f = getattr(cdll, f"fourier_hip_synchronize_{s}"); f.restype = ci; f.argtypes = [vp, vp]
+        if strict or hasattr(cdll, f"fourier_hip_synchronize_{s}"):
+            f = getattr(cdll, f"fourier_hip_synchronize_{s}"); f.restype = ci; f.argtypes = [vp, vp]
         f = getattr(cdll, f"fourier_hip_last_status_{s}"); f.restype = ci; f.argtypes = [vp]
         f = getattr(cdll, f"fourier_hip_set_option_{s}"); f.restype = ci; f.argtypes = [vp, cp, ll]
         f = getattr(cdll, f"fourier_hip_describe_{s}"); f.restype = cp; f.argtypes = [vp]

@@ -56,6 +56,16 @@
 #define FOURIER_MIN_WAVES(NT) ((NT) >= 1024 ? 4 : ((NT) >= 256 ? (NT) / 128 : 1))
 #endif
 
+// FOURIER_WAVES_EXACT(NT): additionally caps the waves per SIMD at the same figure (amdgpu_waves_per_eu(min, max)): the
+// occupancy of these kernels is fixed by their LDS tile (two 512-thread workgroups or one 1024-thread workgroup per CU),
+// so registers below the 128 that figure allows buy nothing -- hipcc then schedules for latency instead of for a
+// fifth wave that can never be resident.  A/B knob (tools/build_variants.py waves_exact).
+#if defined(FOURIER_AB_WAVES_EXACT) && !defined(FOURIER_EMU)
+#define FOURIER_WAVES_EXACT(NT) __attribute__((amdgpu_waves_per_eu(FOURIER_MIN_WAVES(NT), FOURIER_MIN_WAVES(NT))))
+#else
+#define FOURIER_WAVES_EXACT(NT)
+#endif
+
 namespace fourier_hip {
 
 template <typename T> struct cpx { T re, im; };
@@ -224,7 +234,8 @@ struct PassArgs {
   const void* mul;    // Bluestein kernels (conv / one-launch): the transformed chirp w, indexed like the M-point spectrum
   uint64_t n;         // elements per transform (batch stride)
   uint64_t cn;        // columns of this pass = n / L
-  uint64_t s;         // Stockham stride = product of the previous passes' lengths
+  uint64_t s;         // Stockham stride = product of the previous passes' lengths (a power of two for the tile passes)
+  uint32_t s_shift;   // log2(s)
   uint64_t tiles;     // column tiles per transform = cn / COLS
   uint64_t total_cols;  // ROWS mode: number of transforms in this launch
   uint32_t lo_bits;
@@ -495,21 +506,24 @@ __device__ __forceinline__ cpx<T> two_level_twiddle(const PassArgs& a, uint64_t 
 //   mode 3: every XCD owns a contiguous range of whole transforms (as mode 0) but walks it band-major: an eighth of the
 //           tile columns for ALL of its transforms, then the next eighth -- a per-transform table's band is re-read from
 //           the L2 by transform after transform while no transform or page is shared between XCDs
-__device__ __forceinline__ uint64_t xcd_remap(const PassArgs& a, uint64_t blk, uint64_t nwg) {
+// 32-bit arithmetic throughout (a grid has fewer than 2^31 blocks): the 64-bit form costs a few hundred scalar
+// instructions per tile, which a persistent workgroup pays once per tile.
+__device__ __forceinline__ uint32_t xcd_remap(const PassArgs& a, uint64_t blk64, uint64_t nwg64) {
+  const uint32_t blk = (uint32_t)blk64, nwg = (uint32_t)nwg64, tiles = (uint32_t)a.tiles;
   if (a.nxcd <= 1) return blk;
-  const uint64_t nx = a.nxcd, xcd = blk % nx, slot = blk / nx;
-  if (a.xcd_interleave == 1 && a.tiles > 0 && nwg % (nx * a.tiles) == 0)
-    return ((slot / a.tiles) * nx + xcd) * a.tiles + slot % a.tiles;
-  if (a.xcd_interleave == 2 && a.tiles > 0 && a.tiles % nx == 0) {
-    const uint64_t tpx = a.tiles / nx;
-    return (slot / tpx) * a.tiles + xcd * tpx + slot % tpx;
+  const uint32_t nx = a.nxcd, xcd = blk % nx, slot = blk / nx;
+  if (a.xcd_interleave == 1 && tiles > 0 && nwg % (nx * tiles) == 0)
+    return ((slot / tiles) * nx + xcd) * tiles + slot % tiles;
+  if (a.xcd_interleave == 2 && tiles > 0 && tiles % nx == 0) {
+    const uint32_t tpx = tiles / nx;
+    return (slot / tpx) * tiles + xcd * tpx + slot % tpx;
   }
-  if (a.xcd_interleave == 3 && a.tiles > 0 && a.tiles % 8 == 0 && nwg % (nx * a.tiles) == 0) {
-    const uint64_t tpb = a.tiles / 8, t_per_xcd = nwg / (nx * a.tiles), per_band = t_per_xcd * tpb;
-    const uint64_t band = slot / per_band, rem = slot % per_band;
-    return (xcd * t_per_xcd + rem / tpb) * a.tiles + band * tpb + rem % tpb;
+  if (a.xcd_interleave == 3 && tiles > 0 && tiles % 8 == 0 && nwg % (nx * tiles) == 0) {
+    const uint32_t tpb = tiles / 8, t_per_xcd = nwg / (nx * tiles), per_band = t_per_xcd * tpb;
+    const uint32_t band = slot / per_band, rem = slot % per_band;
+    return (xcd * t_per_xcd + rem / tpb) * tiles + band * tpb + rem % tpb;
   }
-  const uint64_t q = nwg / nx, r = nwg % nx;
+  const uint32_t q = nwg / nx, r = nwg % nx;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
@@ -630,9 +644,10 @@ struct NoHook {
 // `before_store` runs (on every thread) after the tile's arithmetic and before its first store: the XCD-fused kernel waits
 // there for its window slot, so that a tile's HBM loads and butterflies are not held up by the readers of the slot's
 // previous tenant.
-template <typename T, int L, int CG, int MODE, int IO, int LDPOL, int STPOL, int SPLIT = 0, typename Hook = NoHook>
+template <typename T, int L, int CG, int MODE, int IO, int LDPOL, int STPOL, int SPLIT = 0, typename Hook = NoHook, int PERSIST = 0>
 __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint64_t nblk, unsigned char* smem, const int tid,
                                           const Hook& before_store = Hook()) {
+  static_assert(PERSIST == 0 || MODE == MODE_LAST, "persistent workgroups: last pass only (no per-tile table in LDS)");
   static_assert(IO == IO_PLAIN || (IO == IO_BLU_IN && MODE == MODE_FIRST) || (IO == IO_BLU_OUT && MODE == MODE_LAST),
                 "Bluestein fusion: chirp-in on the first pass, chirp-out on the last pass");
   static_assert(SPLIT == 0 || (MODE == MODE_LAST && LDPOL != POL_SC1), "split tiles: last pass only");
@@ -653,17 +668,17 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
   // contiguous range of tiles (= whole transforms): each 2 MiB page and each DRAM row is then
   // touched by one XCD's L2/TLB instead of all eight (+11..16% on the strided tile pattern, measured
   // with tools/membench.py --xcd).  Bijective for any grid size; affects speed only.
-  uint64_t blk = xcd_remap(a, blk0, nblk);
+  uint32_t blk = xcd_remap(a, blk0, nblk);
   const int par = SPLIT ? (int)(blk & 1) : 0;
   if constexpr (SPLIT) blk >>= 1;
   const cpx<T>* __restrict__ in = (const cpx<T>*)a.in;
   cpx<T>* __restrict__ out = (cpx<T>*)a.out;
   uint64_t b = 0, c0 = 0, g0 = 0;
   if constexpr (IN_ROWS) {
-    g0 = blk * COLS;
+    g0 = (uint64_t)blk * COLS;
   } else {
-    b = blk / a.tiles;
-    c0 = (blk % a.tiles) * COLS;
+    b = blk / (uint32_t)a.tiles;
+    c0 = (uint64_t)(blk % (uint32_t)a.tiles) * COLS;
     g0 = b * a.cn + c0;
   }
   // Column-tile accesses (everything but the row-contiguous side of FIRST / ROWS) go through buffer descriptors: the
@@ -683,7 +698,7 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
         tabU[idx] = two_level_twiddle<T>(a, i * (uint64_t)(Q * (idx & 15)));
       }
     } else {
-      if (tid < 16) tabU[tid] = two_level_twiddle<T>(a, (c0 / a.s) * (uint64_t)(Q * tid));
+      if (tid < 16) tabU[tid] = two_level_twiddle<T>(a, (c0 >> a.s_shift) * (uint64_t)(Q * tid));
     }
   }
 
@@ -767,6 +782,9 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
   }
 
   // ---- in-tile DFT_L: register r <- row th + Q*r  ==>  register r holds output index k = th + Q*r
+  // (persistent workgroup: every wave has finished the LDS reads of the previous tile before this tile's first
+  // exchange; the barrier sits BEHIND the loads so that they are in flight while the previous tile's stores drain)
+  if constexpr (PERSIST != 0) __syncthreads();
   tile_core<T, L, CG, MODE>(x, th, cg, tid, smem, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw2);
   // now register r holds output index k = th + Q*r of columns (cg*VEC + v)
   // ---- inter-pass twiddle W_size^{i*k} = W^{i*th} * tabU[col][r]
@@ -775,7 +793,7 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
     const cpx<T>* tabU = (const cpx<T>*)(smem + C::TABU_OFF);
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-      const uint64_t i = (MODE == MODE_FIRST) ? c0 + (uint64_t)(cg * VEC + v) : c0 / a.s;
+      const uint64_t i = (MODE == MODE_FIRST) ? c0 + (uint64_t)(cg * VEC + v) : c0 >> a.s_shift;
       const cpx<T> base = two_level_twiddle<T>(a, i * (uint64_t)th);
       const cpx<T>* tu = (MODE == MODE_FIRST) ? tabU + (cg * VEC + v) * 16 : tabU;
 #pragma unroll
@@ -830,7 +848,7 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
     }
   } else {
     // output row of register r: j0 + s * (KM*L*i + KM*(th + Q*r) + par); uniform part in the descriptor base
-    const uint64_t i = c0 / a.s, j0 = c0 % a.s;
+    const uint64_t i = c0 >> a.s_shift, j0 = c0 & (a.s - 1);  // s is a power of two for every tile pass
     const uint64_t base = b * a.n + j0 + a.s * ((uint64_t)(KM * L) * i + (uint64_t)par);
     const uint32_t voff = (uint32_t)(((uint64_t)(cg * VEC) + a.s * (uint64_t)(KM * th)) * sizeof(cpx<T>));
     const uint64_t rows = a.s * (uint64_t)(KM * Q);  // elements between a thread's consecutive output rows
@@ -879,9 +897,27 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
 }
 
 template <typename T, int L, int CG, int MODE, int IO = IO_PLAIN>
-__global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG)) fft_pass_kernel(PassArgs a) {
+__global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG)) FOURIER_WAVES_EXACT((L / 16) * CG) fft_pass_kernel(PassArgs a) {
   FOURIER_DYN_SMEM(smem);
   pass_tile<T, L, CG, MODE, IO, PassPolicy<L, MODE, CG>::LD, PassPolicy<L, MODE, CG>::ST>(a, blockIdx.x, gridDim.x, smem, (int)threadIdx.x);
+}
+
+// The same pass with PERSISTENT workgroups: as many as are resident at once (one 1024-thread workgroup per CU at
+// L = 2048), each walking tiles blockIdx.x, blockIdx.x + gridDim.x, ... of the a.total_cols tiles of the launch.  With one
+// workgroup per CU nothing overlaps a tile's load, compute and store phases, and between two workgroups the CU idles
+// while the old one's stores drain (a wave's registers are released only then), the dispatcher places the new one and
+// its loads travel to HBM and back.  A persistent workgroup issues the next tile's loads right behind the current tile's
+// stores: dispatch disappears and the two latencies overlap.  gridDim.x is a multiple of 8, so a workgroup's tiles all
+// belong to the XCD it runs on (xcd_remap).
+template <typename T, int L, int CG, int MODE, int IO = IO_PLAIN>
+__global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG)) fft_pass_persistent_kernel(PassArgs a) {
+  FOURIER_DYN_SMEM(smem);
+  const uint64_t total = a.total_cols;
+  for (uint64_t blk = blockIdx.x; blk < total; blk += gridDim.x) {
+    int tid = (int)threadIdx.x;
+    FOURIER_LAUNDER(tid);  // per-tile lane offsets are recomputed per tile, not carried (and spilled) around the loop
+    pass_tile<T, L, CG, MODE, IO, PassPolicy<L, MODE, CG>::LD, PassPolicy<L, MODE, CG>::ST, 0, NoHook, 1>(a, blk, total, smem, tid);
+  }
 }
 
 
@@ -1062,14 +1098,14 @@ __global__ void __launch_bounds__((L1 / 16) * CG1, FOURIER_FUSED_MIN_WAVES) fft_
 // one write of the work array instead of two of each.  The inverse is swap . DFT . swap (mod.rs:366-387):
 // the leading swap happens here, the trailing one in the inverse plan's last pass.
 template <typename T, int L, int CG>
-__global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16) * CG)) fft_conv_kernel(PassArgs a) {
+__global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16) * CG)) FOURIER_WAVES_EXACT((L / 16) * CG) fft_conv_kernel(PassArgs a) {
   using C = TileCfg<T, L, CG>;
   constexpr int VEC = C::VEC, Q = C::Q, COLS = C::COLS;
   static_assert(Q > 1, "conv kernel: L >= 32");
   FOURIER_DYN_SMEM(smem);
   const int tid = (int)threadIdx.x;
-  const uint64_t blk = xcd_remap(a, blockIdx.x, gridDim.x);
-  const uint64_t b = blk / a.tiles, c0 = (blk % a.tiles) * COLS;
+  const uint32_t blk = xcd_remap(a, blockIdx.x, gridDim.x);
+  const uint64_t b = blk / (uint32_t)a.tiles, c0 = (uint64_t)(blk % (uint32_t)a.tiles) * COLS;
   const cpx<T>* __restrict__ in = (const cpx<T>*)a.in + b * a.n;
   cpx<T>* __restrict__ out = (cpx<T>*)a.out + b * a.n;
   // Everything a phase derives from the thread index is derived from a laundered copy taken AT that phase: hipcc
@@ -1369,7 +1405,7 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
 
 template <typename T, int L1, int L2>
 __global__ void __launch_bounds__(FOURIER_TWOLEVEL_NT(T, L1, L2), FOURIER_MIN_WAVES(FOURIER_TWOLEVEL_NT(T, L1, L2)))
-    fft_twolevel_kernel(PassArgs a) {
+    FOURIER_WAVES_EXACT(FOURIER_TWOLEVEL_NT(T, L1, L2)) fft_twolevel_kernel(PassArgs a) {
   constexpr int VEC = 16 / (2 * (int)sizeof(T));
   constexpr int CG1 = L2 / VEC, CG2 = L1 / VEC, Q1 = L1 / 16, Q2 = L2 / 16, N = L1 * L2;
   FOURIER_DYN_SMEM(smem);

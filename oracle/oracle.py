@@ -49,6 +49,10 @@ def lib():
             getattr(L, f"oracle_fourier_batch_destroy_{s}").argtypes = [vp]
             getattr(L, f"oracle_fourier_batch_run_{s}").restype = None
             getattr(L, f"oracle_fourier_batch_run_{s}").argtypes = [vp, vp, vp, sz, ci]
+            getattr(L, f"oracle_fourier_batch_stage_{s}").restype = ci
+            getattr(L, f"oracle_fourier_batch_stage_{s}").argtypes = [vp, vp, sz]
+            getattr(L, f"oracle_fourier_batch_cpu_{s}").restype = ci
+            getattr(L, f"oracle_fourier_batch_cpu_{s}").argtypes = [vp, ci]
         L.oracle_fourier_counts.restype = ci
         L.oracle_fourier_counts.argtypes = [sz, ctypes.POINTER(sz)]
         L.oracle_fourier_table_len.restype = sz
@@ -106,8 +110,9 @@ class OracleFft:
 class OracleBatch:
     """`nthreads` independent plans of one size; run() splits the batch contiguously over them.
 
-    Plan creation happens here, outside any timed region (fourier-bench times `transform` only,
-    fourier-bench/benches/fft_bench.rs:36).
+    The worker threads are persistent and pinned (spread over the process's affinity mask); each builds its own plan, so
+    tables and work buffers sit on the worker's NUMA node.  Plan creation, stage() and any warm-up run happen outside the
+    timed region (fourier-bench times `transform` only, fourier-bench/benches/fft_bench.rs:36).
     """
 
     def __init__(self, n, dtype=np.complex64, nthreads=1):
@@ -115,6 +120,7 @@ class OracleBatch:
         self.dtype = np.dtype(dtype)
         self.n = n
         self.nthreads = nthreads
+        self._staged = 0
         self._c = getattr(lib(), f"oracle_fourier_batch_create_{self._s}")(n, nthreads)
         if not self._c:
             raise ValueError(f"oracle: cannot create plans of size {n}")
@@ -126,6 +132,24 @@ class OracleBatch:
             out = np.empty_like(x)
         getattr(lib(), f"oracle_fourier_batch_run_{self._s}")(self._c, x.ctypes.data, out.ctypes.data, x.shape[0], transform)
         return out
+
+    def stage(self, x):
+        """Copy x into a context-owned input buffer, every worker copying (first-touching) the slice it will transform."""
+        x = np.ascontiguousarray(x, dtype=self.dtype)
+        assert x.ndim == 2 and x.shape[1] == self.n
+        if not getattr(lib(), f"oracle_fourier_batch_stage_{self._s}")(self._c, x.ctypes.data, x.shape[0]):
+            raise MemoryError("oracle: cannot stage the input")
+        self._staged = x.shape[0]
+
+    def run_staged(self, out, transform=FFT):
+        """Transform the staged input into `out` ((batch, n), C-contiguous)."""
+        assert out.dtype == self.dtype and out.flags.c_contiguous and out.shape == (self._staged, self.n)
+        getattr(lib(), f"oracle_fourier_batch_run_{self._s}")(self._c, None, out.ctypes.data, self._staged, transform)
+        return out
+
+    def cpus(self):
+        """CPU every worker is pinned to (-1 = not pinned)."""
+        return [getattr(lib(), f"oracle_fourier_batch_cpu_{self._s}")(self._c, t) for t in range(self.nthreads)]
 
     def __del__(self):
         c, self._c = getattr(self, "_c", None), None

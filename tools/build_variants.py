@@ -54,6 +54,7 @@ VARIANTS = {
     "stage_tw0": ["-DFOURIER_STAGE_TW_BATCH=0"],
     "stage_tw4": ["-DFOURIER_STAGE_TW_BATCH=4"],
     "blu_out_nt": ["-DFOURIER_BLU_OUT_ST_NT=1"],
+    "waves_exact": ["-DFOURIER_AB_WAVES_EXACT=1"],
     "abl1": ["-DFOURIER_ABLATE=1"],
     "abl2": ["-DFOURIER_ABLATE=2"],
     "abl3": ["-DFOURIER_ABLATE=3"],

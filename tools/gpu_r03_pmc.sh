@@ -9,7 +9,7 @@ mkdir -p gpurun_out
 R="$PWD"
 export TMPDIR=/tmp
 cd /tmp
-CFGS=${PMC_CFGS:-"c4 999983 512 f32 2;c5chunk 4194304 1024 f32 2;c3 1048576 4096 f64 2"}
+CFGS=${PMC_CFGS:-"c4 999983 512 f32 2;c5chunk 4194304 1024 f32 2;c3 1048576 4096 f64 2;c2 1048576 4096 f32 2"}
 IFS=';' read -ra LIST <<< "$CFGS"
 for cfg in "${LIST[@]}"; do
   set -- $cfg

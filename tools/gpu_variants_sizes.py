@@ -43,7 +43,7 @@ if __name__ == "__main__":
         x = torch.empty((batch, n), dtype=cdt, device="cuda"); torch.view_as_real(x).uniform_(0, 1); y = torch.empty_like(x)
         for rep in range(2):
             for name, path in libs:
-                _lib._lib = base if path is None else _lib.bind(ctypes.CDLL(path))
+                _lib._lib = base if path is None else _lib.bind(ctypes.CDLL(path), strict=False)
                 try:
                     run(name, tag, n, batch, real, x, y)
                 except Exception as e:
