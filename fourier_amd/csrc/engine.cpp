@@ -155,7 +155,6 @@ struct KernelInfo {
   PassKernel fn = nullptr;
   int L = 0, CG = 0, NT = 0, COLS = 0, R3 = 0;
   int split = 0;  // 1: two workgroups per tile (fft_last_split_kernel), grid = 2 x tiles
-  int persist = 0;  // 1: persistent workgroups (fft_pass_persistent_kernel), grid = resident workgroups
   size_t smem = 0;
 };
 
@@ -168,13 +167,6 @@ template <typename T, int L, int CG, int MODE, int IO = IO_PLAIN> static KernelI
   return k;
 }
 
-// the same pass with persistent workgroups (last passes only)
-template <typename T, int L, int CG, int IO = IO_PLAIN> static KernelInfo make_persist_info() {
-  KernelInfo k = make_info<T, L, CG, MODE_LAST, IO>();
-  k.fn = &fft_pass_persistent_kernel<T, L, CG, MODE_LAST, IO>;
-  k.persist = 1;
-  return k;
-}
 #ifdef FOURIER_EXPERIMENTS
 // last pass of length L on half tiles: the register tile (and the thread count) of a length-L/2 pass
 template <typename T, int L, int CG, int IO = IO_PLAIN> static KernelInfo make_split_info() {
@@ -209,13 +201,6 @@ template <typename T, int L, int CG, int IO = IO_PLAIN> static KernelInfo make_s
 #ifndef FOURIER_CG_4096
 #define FOURIER_CG_4096 2
 #endif
-// persistent variant of a last pass, where one exists: the one-workgroup-per-CU length (2048) and, for A/B, 1024
-template <typename T> static bool get_persist_kernel(int L, int io, KernelInfo& k) {
-  if (L == 2048) { k = io == IO_BLU_OUT ? make_persist_info<T, 2048, FOURIER_CG_2048, IO_BLU_OUT>() : make_persist_info<T, 2048, FOURIER_CG_2048>(); return true; }
-  if (L == 1024) { k = io == IO_BLU_OUT ? make_persist_info<T, 1024, FOURIER_CG_1024, IO_BLU_OUT>() : make_persist_info<T, 1024, FOURIER_CG_1024>(); return true; }
-  return false;
-}
-
 template <typename T> static KernelInfo get_kernel(int L, int mode, int io = IO_PLAIN) {
   // first pass of length 4096 on 32-byte-wide tiles (128 KiB, two workgroups per CU): 2^22 = 4096 x 1024
   if (L == 4096 && mode == MODE_FIRST && io == IO_PLAIN) return make_info<T, 4096, FOURIER_CG_4096, MODE_FIRST>();
@@ -449,9 +434,6 @@ template <typename T> class Pow2Engine {
     KernelInfo k;
     KernelInfo k_blu;  // IO_BLU_IN variant of a FIRST pass / IO_BLU_OUT variant of a LAST pass (lazy)
     bool has_blu = false;
-    KernelInfo k_per, k_blu_per;  // persistent-workgroup variants of a LAST pass (k / k_blu), where they exist
-    bool has_per = false, has_blu_per = false;
-    unsigned per_grid = 0, blu_per_grid = 0;  // resident workgroups of those kernels (a multiple of 8)
     StageTables<T>* st2 = nullptr;  // MODE_TWOLEVEL: stage tables of the second pass length
     OddKernel odd_fn = nullptr;     // MODE_ODD_LAST
     int odd_r = 0;
@@ -566,10 +548,6 @@ template <typename T> class Pow2Engine {
       }
       if (pass->mode == MODE_FIRST || pass->mode == MODE_MID) make_two_level(*pass, size);
       set_smem_attribute(pass->k);
-      if (pass->mode == MODE_LAST && !pass->k.split && get_persist_kernel<T>(L, IO_PLAIN, pass->k_per) && pass->k_per.CG == pass->k.CG) {
-        pass->has_per = true;
-        pass->per_grid = resident_grid(pass->k_per);
-      }
       passes_.push_back(std::move(pass));
       s *= (uint64_t)L;
       size /= (uint64_t)L;
@@ -605,20 +583,6 @@ template <typename T> class Pow2Engine {
     pass.tw_hi.upload(hi);
   }
   static void set_smem_attribute(const KernelInfo& k) { raise_smem_limit((const void*)k.fn, k.smem); }
-  // workgroups of `k` that are resident at once on the current device, rounded down to a multiple of 8 (XCDs): the grid
-  // of a persistent kernel
-  static unsigned resident_grid(const KernelInfo& k) {
-    set_smem_attribute(k);
-    int per_cu = 0, cus = 0, dev = 0;
-    HIP_CHECK(hipGetDevice(&dev));
-    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k.fn, k.NT, k.smem));
-    HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const unsigned g = (unsigned)std::max(1, per_cu) * (unsigned)std::max(1, cus);
-    return g >= 8 ? g - g % 8 : g;
-  }
-  // 0 = never, 1 (default) = the one-workgroup-per-CU last passes (L = 2048), 2 = every last pass that has the variant
-  void set_persistent(int v) { persistent_ = v; }
-  bool use_persistent(const KernelInfo& k) const { return persistent_ == 2 || (persistent_ == 1 && k.NT >= 1024); }
 
   // Whole-Bluestein-in-one-launch (bluestein_small_kernel) is available when this (inner) plan is a
   // one-launch two-level plan: it additionally needs the inter-pass table of the role-swapped L2 x L1 problem.
@@ -743,10 +707,6 @@ template <typename T> class Pow2Engine {
     l.k_blu = get_kernel<T>(l.k.L, MODE_LAST, IO_BLU_OUT);
     f.has_blu = l.has_blu = true;
     for (Pass* p : {&f, &l}) set_smem_attribute(p->k_blu);
-    if (!l.k_blu.split && get_persist_kernel<T>(l.k_blu.L, IO_BLU_OUT, l.k_blu_per) && l.k_blu_per.CG == l.k_blu.CG) {
-      l.has_blu_per = true;
-      l.blu_per_grid = resident_grid(l.k_blu_per);
-    }
   }
 
   size_t size() const { return n_; }
@@ -875,13 +835,7 @@ template <typename T> class Pow2Engine {
       if (blu_here) {
         a.blu_x = blu.xtab; a.blu_n = blu.n; a.blu_swap = blu.swap;
       }
-      const KernelInfo* kp = blu_here ? &ps.k_blu : &ps.k;
-      unsigned resident = 0;
-      if (blu_here ? (ps.has_blu_per && use_persistent(ps.k_blu_per)) : (ps.has_per && use_persistent(ps.k_per))) {
-        kp = blu_here ? &ps.k_blu_per : &ps.k_per;
-        resident = blu_here ? ps.blu_per_grid : ps.per_grid;
-      }
-      const KernelInfo& kk = *kp;
+      const KernelInfo& kk = blu_here ? ps.k_blu : ps.k;
       a.swap_in = (p == 0) && inverse;
       a.swap_out = (p + 1 == np) && inverse;
       a.scale = (p + 1 == np) ? scale : 1.0;
@@ -897,10 +851,6 @@ template <typename T> class Pow2Engine {
       } else {
         a.tiles = ps.cn / kk.COLS;
         grid = (uint64_t)batch * a.tiles * (kk.split ? 2 : 1);
-        if (kk.persist) {  // tiles of the launch; the resident workgroups share them round robin
-          a.total_cols = grid;
-          grid = std::min<uint64_t>(grid, resident);
-        }
       }
       if (grid > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");
       PROF_BEGIN(prof, slot);
@@ -959,7 +909,6 @@ template <typename T> class Pow2Engine {
  private:
   size_t n_;
   bool tiny_ = false;
-  int persistent_ = 1;
   int tl1_ = 0, tl2_ = 0;   // pass lengths of a one-launch (MODE_TWOLEVEL) plan
   KernelInfo blu_small_, conv_;
   StageTables<T>* conv_st_ = nullptr;
@@ -1199,11 +1148,6 @@ template <typename T> class Plan {
       return 0;
     }
     if (key == "bluestein_conv" && (v == 0 || v == 1)) { conv_ = (v == 1) && conv_ok_; return 0; }
-    if (key == "persistent" && v >= 0 && v <= 2 && eng_) {
-      eng_->set_persistent((int)v);
-      if (eng_inv_) eng_inv_->set_persistent((int)v);
-      return 0;
-    }
     if (key == "host_chunk_bytes" && v > 0) { host_chunk_bytes_ = (size_t)v; return 0; }
     // both passes in one launch with the intermediate in the XCD's L2 (2^16..2^18 f32, 2^15..2^17 f64); 0 where unavailable
     if (key == "l2_fused" && (v == 0 || v == 1)) {

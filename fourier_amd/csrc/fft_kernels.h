@@ -644,10 +644,9 @@ struct NoHook {
 // `before_store` runs (on every thread) after the tile's arithmetic and before its first store: the XCD-fused kernel waits
 // there for its window slot, so that a tile's HBM loads and butterflies are not held up by the readers of the slot's
 // previous tenant.
-template <typename T, int L, int CG, int MODE, int IO, int LDPOL, int STPOL, int SPLIT = 0, typename Hook = NoHook, int PERSIST = 0>
+template <typename T, int L, int CG, int MODE, int IO, int LDPOL, int STPOL, int SPLIT = 0, typename Hook = NoHook>
 __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint64_t nblk, unsigned char* smem, const int tid,
                                           const Hook& before_store = Hook()) {
-  static_assert(PERSIST == 0 || MODE == MODE_LAST, "persistent workgroups: last pass only (no per-tile table in LDS)");
   static_assert(IO == IO_PLAIN || (IO == IO_BLU_IN && MODE == MODE_FIRST) || (IO == IO_BLU_OUT && MODE == MODE_LAST),
                 "Bluestein fusion: chirp-in on the first pass, chirp-out on the last pass");
   static_assert(SPLIT == 0 || (MODE == MODE_LAST && LDPOL != POL_SC1), "split tiles: last pass only");
@@ -782,9 +781,6 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
   }
 
   // ---- in-tile DFT_L: register r <- row th + Q*r  ==>  register r holds output index k = th + Q*r
-  // (persistent workgroup: every wave has finished the LDS reads of the previous tile before this tile's first
-  // exchange; the barrier sits BEHIND the loads so that they are in flight while the previous tile's stores drain)
-  if constexpr (PERSIST != 0) __syncthreads();
   tile_core<T, L, CG, MODE>(x, th, cg, tid, smem, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw2);
   // now register r holds output index k = th + Q*r of columns (cg*VEC + v)
   // ---- inter-pass twiddle W_size^{i*k} = W^{i*th} * tabU[col][r]
@@ -900,24 +896,6 @@ template <typename T, int L, int CG, int MODE, int IO = IO_PLAIN>
 __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG)) FOURIER_WAVES_EXACT((L / 16) * CG) fft_pass_kernel(PassArgs a) {
   FOURIER_DYN_SMEM(smem);
   pass_tile<T, L, CG, MODE, IO, PassPolicy<L, MODE, CG>::LD, PassPolicy<L, MODE, CG>::ST>(a, blockIdx.x, gridDim.x, smem, (int)threadIdx.x);
-}
-
-// The same pass with PERSISTENT workgroups: as many as are resident at once (one 1024-thread workgroup per CU at
-// L = 2048), each walking tiles blockIdx.x, blockIdx.x + gridDim.x, ... of the a.total_cols tiles of the launch.  With one
-// workgroup per CU nothing overlaps a tile's load, compute and store phases, and between two workgroups the CU idles
-// while the old one's stores drain (a wave's registers are released only then), the dispatcher places the new one and
-// its loads travel to HBM and back.  A persistent workgroup issues the next tile's loads right behind the current tile's
-// stores: dispatch disappears and the two latencies overlap.  gridDim.x is a multiple of 8, so a workgroup's tiles all
-// belong to the XCD it runs on (xcd_remap).
-template <typename T, int L, int CG, int MODE, int IO = IO_PLAIN>
-__global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG)) fft_pass_persistent_kernel(PassArgs a) {
-  FOURIER_DYN_SMEM(smem);
-  const uint64_t total = a.total_cols;
-  for (uint64_t blk = blockIdx.x; blk < total; blk += gridDim.x) {
-    int tid = (int)threadIdx.x;
-    FOURIER_LAUNDER(tid);  // per-tile lane offsets are recomputed per tile, not carried (and spilled) around the loop
-    pass_tile<T, L, CG, MODE, IO, PassPolicy<L, MODE, CG>::LD, PassPolicy<L, MODE, CG>::ST, 0, NoHook, 1>(a, blk, total, smem, tid);
-  }
 }
 
 

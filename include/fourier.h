@@ -163,10 +163,6 @@ const char *fourier_hip_status_string(int status);
  *   "host_chunk_bytes" bytes of one chunk of fourier_hip_transform_batch_host_* (default 32 MiB, four in flight)
  *   "bluestein_conv"   1 (default with bluestein_fusion) = the forward inner FFT's last pass, the multiply by the
  *                  transformed chirp and the inverse inner FFT's first pass run as one launch
- *   "persistent"   1 (default) = last passes that fit only ONE workgroup per CU (length 2048) run as persistent
- *                  workgroups that walk the tiles of the launch, so that a tile's loads are issued right behind the
- *                  previous tile's stores; 2 = every last pass that has the variant (1024, 2048); 0 = one workgroup per
- *                  tile everywhere.  Same results bit for bit.
  *   "l2_fused"     (builds with -DFOURIER_EXPERIMENTS only; INVALID_ARGUMENT in the product library) 1 = run both
  *                  passes of a two-pass plan in ONE launch with the intermediate parked in the XCD's L2 (persistent
  *                  workgroups, per-XCD work queues; f32 2^16..2^18, f64 2^15..2^17 only).  Same results bit for

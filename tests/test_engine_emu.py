@@ -590,18 +590,6 @@ def test_l2048_narrow_first_pass_and_split_last_pass(fa, oracle, monkeypatch):
             assert rel_l2(ys, yo) < 3e-7 and np.array_equal(run_batch(split, x, 0, inplace=True), ys)
         else:
             assert np.array_equal(ys, yo)  # no last pass of length 2048 in this plan
-        # persistent workgroups for the last pass (default: length 2048 only; 2: length 1024 too; 0: never): same bits,
-        # also for a batch that leaves the resident workgroups an uneven number of tiles each
-        x3 = np.concatenate([x, x[:, ::-1], 2 * x])
-        base3 = None
-        for mode in (1, 0, 2):
-            plan = make(fa, n, np.complex64)
-            plan.set_option("persistent", mode)
-            y3 = run_batch(plan, x3, 0)
-            base3 = y3 if base3 is None else base3
-            assert np.array_equal(y3, base3), (n, mode)
-            assert np.array_equal(run_batch(plan, x3, 0, inplace=True), base3), (n, mode)
-        assert np.array_equal(base3[0], yn[0]), n
 
 
 def test_empty_batch_is_a_successful_no_op_for_every_plan_family(fa):

@@ -895,22 +895,3 @@ def test_million_transform_grids_of_the_small_n_kernels_are_value_checked(torch,
     assert bool(torch.isfinite(ey).all())
     assert float(((ey - n * ex).abs() / (n * ex)).max()) <= 2e-5, n
 
-
-@pytest.mark.parametrize("n,batch", [(1 << 22, 37), (1 << 21, 41), (999983, 13), (1 << 20, 67)])
-def test_persistent_last_pass_workgroups_give_the_same_bits(torch, fa, oracle, n, batch):
-    """Plan option "persistent": last passes as persistent workgroups that walk the tiles of the launch (default for the
-    one-workgroup-per-CU length 2048; 2 = length 1024 as well; 0 = one workgroup per tile).  Same arithmetic per tile,
-    so the results must be bit-identical whatever the option, in and out of place, for batches that do not divide over
-    the resident workgroups; the default is checked against the oracle."""
-    x = np.stack([hash_normal(7000 + b, n) for b in range(3)]).astype(np.complex64)
-    x = np.concatenate([x] * (batch // 3 + 1))[:batch]
-    outs = {}
-    for mode in (1, 0, 2):
-        plan = make(fa, n, np.complex64)
-        plan.set_option("persistent", mode)
-        outs[mode] = gpu_batch(torch, fa, plan, x, 0)
-        assert np.array_equal(gpu_batch(torch, fa, plan, x, 0, inplace=True), outs[mode]), (n, mode)
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[2], outs[1]), n
-    ref = oracle.transform_batch(x[:2], oracle.FFT)
-    assert rel_l2(outs[1][:2], ref) <= (2e-6 if n == 999983 else 1e-6)
-    assert np.array_equal(outs[1][3], outs[1][0])  # the same input further along the batch: another workgroup, same bits
