@@ -163,7 +163,7 @@ template <typename T, int L, int CG, int MODE, int IO = IO_PLAIN> static KernelI
   KernelInfo k;
   k.fn = &fft_pass_kernel<T, L, CG, MODE, IO>;
   k.L = L; k.CG = CG; k.NT = C::NT; k.COLS = C::COLS; k.R3 = C::R3;
-  k.smem = C::smem_bytes(MODE);
+  k.smem = C::smem_bytes(MODE) + (IO == IO_BLU_IN ? C::TABV_BYTES : 0);
   return k;
 }
 
@@ -697,6 +697,11 @@ template <typename T> class Pow2Engine {
     }
   }
 
+  static int kk_L(const Pass& ps) { return ps.k.L; }
+  // geometry of the first pass (chirp-in tables): length and columns
+  int first_len() const { return passes_.empty() ? 0 : passes_.front()->k.L; }
+  uint64_t first_cn() const { return passes_.empty() ? 0 : passes_.front()->cn; }
+
   // Bluestein fusion is available when the plan has separate first and last passes.
   bool can_fuse_bluestein() const { return !tiny_ && passes_.size() >= 2; }
   void enable_bluestein_fusion() {
@@ -737,6 +742,12 @@ template <typename T> class Pow2Engine {
     const void* xtab = nullptr;
     uint64_t n = 0;
     int swap = 0;
+    // chirp-in pass computing the chirp (PassArgs::blu_p ...); null = read xtab
+    const void* p_tab = nullptr;
+    const void* u_tab = nullptr;
+    const void* tn_lo = nullptr;
+    const void* tn_hi = nullptr;
+    uint32_t tn_bits = 0;
   };
 
   void run(const cpx<T>* in, cpx<T>* out, cpx<T>* scratch, size_t batch, bool inverse, double scale, const cpx<T>* mul,
@@ -834,6 +845,12 @@ template <typename T> class Pow2Engine {
       const bool blu_here = ps.has_blu && ((blu.io == IO_BLU_IN && p == 0) || (blu.io == IO_BLU_OUT && p + 1 == np));
       if (blu_here) {
         a.blu_x = blu.xtab; a.blu_n = blu.n; a.blu_swap = blu.swap;
+        if (blu.io == IO_BLU_IN && blu.p_tab) {
+          a.blu_p = blu.p_tab; a.blu_u = blu.u_tab; a.tn_lo = blu.tn_lo; a.tn_hi = blu.tn_hi; a.tn_bits = blu.tn_bits;
+          a.blu_cn_mod = (uint32_t)(ps.cn % blu.n);
+          a.blu_cnq_mod = (uint32_t)((ps.cn * (uint64_t)(kk_L(ps) / 16)) % blu.n);
+          a.blu_nd = (double)blu.n; a.blu_inv_nd = 1.0 / (double)blu.n;
+        }
       }
       const KernelInfo& kk = blu_here ? ps.k_blu : ps.k;
       a.swap_in = (p == 0) && inverse;
@@ -1131,7 +1148,7 @@ template <typename T> class Plan {
     // unfused: pre (n + table read, m write) + 2 inner FFTs + w table + post (n + table read, n write);
     // fused: the first / last inner pass read / write the n-point user array instead of an m-point sweep
     if (small_fused_) return (double)ELEM * 2.0 * n_;  // tables stay L2-resident
-    const double chirp_reads = 2.0 * n_;  // the n-entry chirp table, once per fused end pass
+    const double chirp_reads = (chirp_compute_ ? 1.0 : 2.0) * n_;  // the n-entry chirp table: the chirp-out pass reads it, the chirp-in pass only without bluestein_chirp_compute
     if (fused_ && conv_) return (double)ELEM * (2.0 * m_ * (2.0 * eng_->num_passes() - 1.0) - 2.0 * (m_ - n_) + m_ + chirp_reads);
     if (fused_) return (double)ELEM * (2.0 * 2.0 * m_ * eng_->num_passes() - 2.0 * (m_ - n_) + m_ + chirp_reads);
     return (double)ELEM * ((2.0 * n_ + m_) + 2.0 * 2.0 * m_ * eng_->num_passes() + m_ + 3.0 * n_);
@@ -1148,6 +1165,7 @@ template <typename T> class Plan {
       return 0;
     }
     if (key == "bluestein_conv" && (v == 0 || v == 1)) { conv_ = (v == 1) && conv_ok_; return 0; }
+    if (key == "bluestein_chirp_compute" && (v == 0 || v == 1)) { chirp_compute_ = (v == 1) && chirp_p_.p != nullptr; return 0; }
     if (key == "host_chunk_bytes" && v > 0) { host_chunk_bytes_ = (size_t)v; return 0; }
     // both passes in one launch with the intermediate in the XCD's L2 (2^16..2^18 f32, 2^15..2^17 f64); 0 where unavailable
     if (key == "l2_fused" && (v == 0 || v == 1)) {
@@ -1250,6 +1268,7 @@ template <typename T> class Plan {
         // (.) w, first inverse pass), last inverse pass (chirp-out fused); intermediates ping-pong work/scratch
         typename Pow2Engine<T>::BluIO bin, bout;
         bin.io = IO_BLU_IN; bin.xtab = xtab_.p; bin.n = n_; bin.swap = inverse;
+        if (chirp_compute_) { bin.p_tab = chirp_p_.p; bin.u_tab = chirp_u_.p; bin.tn_lo = tn_lo_.p; bin.tn_hi = tn_hi_.p; bin.tn_bits = tn_bits_; }
         bout.io = IO_BLU_OUT; bout.xtab = xtab_.p; bout.n = n_; bout.swap = inverse;
         const Pow2Engine<T>& inv = eng_inv_ ? *eng_inv_ : *eng_;
         cpx<T>* bufs[2] = {work, (cpx<T>*)scratch_.p};
@@ -1275,6 +1294,7 @@ template <typename T> class Plan {
         // the inverse inner FFT's last pass: no separate sweeps over the M-point work array
         typename Pow2Engine<T>::BluIO bin, bout;
         bin.io = IO_BLU_IN; bin.xtab = xtab_.p; bin.n = n_; bin.swap = inverse;
+        if (chirp_compute_) { bin.p_tab = chirp_p_.p; bin.u_tab = chirp_u_.p; bin.tn_lo = tn_lo_.p; bin.tn_hi = tn_hi_.p; bin.tn_bits = tn_bits_; }
         bout.io = IO_BLU_OUT; bout.xtab = xtab_.p; bout.n = n_; bout.swap = inverse;
         eng_->run(in + b0 * n_, work, (cpx<T>*)scratch_.p, nb, false, 1.0, (const cpx<T>*)wtab_.p, false, stream, prof, 1,
                   nxcd_, bin);
@@ -1424,6 +1444,36 @@ template <typename T> class Plan {
     std::vector<cpx<T>> x(n_);
     for (size_t k = 0; k < n_; ++k) x[k] = {(T)cr[k], (T)ci[k]};  // x_fwd, bluesteins.rs:51-61
     xtab_.upload(x);
+    if (fused_ && !small_fused_) {
+      // Tables for the chirp-in pass that computes the chirp instead of reading x (a quarter of that pass's traffic):
+      // index k = row*cn + b  =>  x[k] = W_2n^{(row*cn)^2} * W_2n^{b^2} * W_n^{cn*row*b}; exact exponents, f64 trig, cast.
+      const uint64_t cn = eng_->first_cn(), rows = (uint64_t)eng_->first_len() / 2;
+      std::vector<cpx<T>> pt(rows), ut(cn);
+      for (uint64_t r = 0; r < rows; ++r) {
+        const unsigned __int128 k = (unsigned __int128)r * cn;
+        double re, im;
+        unit_root((uint64_t)((k * k) % two_n), two_n, re, im);
+        pt[r] = {(T)re, (T)im};
+      }
+      for (uint64_t b = 0; b < cn; ++b) {
+        double re, im;
+        unit_root((uint64_t)(((unsigned __int128)b * b) % two_n), two_n, re, im);
+        ut[b] = {(T)re, (T)im};
+      }
+      chirp_p_.upload(pt);
+      chirp_u_.upload(ut);
+      tn_bits_ = (uint32_t)((ilog2(n_) + 1) / 2);
+      std::vector<cpx<T>> lo((size_t)1 << tn_bits_), hi((size_t)(n_ >> tn_bits_) + 1);
+      for (size_t e = 0; e < lo.size(); ++e) { double re, im; unit_root(e, n_, re, im); lo[e] = {(T)re, (T)im}; }
+      for (size_t h = 0; h < hi.size(); ++h) { double re, im; unit_root((uint64_t)h << tn_bits_, n_, re, im); hi[h] = {(T)re, (T)im}; }
+      tn_lo_.upload(lo);
+      tn_hi_.upload(hi);
+      // Default: only where it pays.  Measured (profiles/r03_s7_chirp_compute_ab.jsonl): C4 (N = 999983, first pass of length
+      // 2048 on 8-column tiles) 2.76-2.85 vs 2.92-3.08 ms per 512, f64 2.61 vs 2.88; N = 40000 / 65537 (the 0.3-0.5 MB table
+      // is L2-resident anyway) and N = 2200000 (first pass of length 256: 32-column tiles, eight times the per-tile table
+      // work) are 5-17 % SLOWER.  So: a long first pass and a table beyond an XCD's L2.
+      chirp_compute_ = eng_->first_len() >= 1024 && n_ * ELEM >= ((size_t)4 << 20);
+    }
     // w = FFT_M(conj chirp, mirrored) (bluesteins.rs:18-48), evaluated in f64 on the host, with the
     // inner IFFT's 1/M (bluesteins.rs:239 -> mod.rs:383) folded in.
     std::vector<double> wr(m_, 0.0), wi(m_, 0.0);
@@ -1495,6 +1545,9 @@ template <typename T> class Plan {
   std::unique_ptr<Pow2Engine<T>> eng_, eng_inv_;  // eng_inv_: mirrored inverse plan of a conv-fused Bluestein
   std::unique_ptr<MixedEngine<T>> mix_;
   DevBuf xtab_, wtab_;
+  DevBuf chirp_p_, chirp_u_, tn_lo_, tn_hi_;  // chirp-in pass computing the chirp (init_bluestein)
+  uint32_t tn_bits_ = 0;
+  bool chirp_compute_ = false;  // option "bluestein_chirp_compute"
   mutable DevBuf scratch_, work_, hostio_;
   mutable PinnedBuf pinned_;
   mutable hipStream_t legacy_stream_ = nullptr;  // legacy host-buffer calls (exec_host)

@@ -56,16 +56,6 @@
 #define FOURIER_MIN_WAVES(NT) ((NT) >= 1024 ? 4 : ((NT) >= 256 ? (NT) / 128 : 1))
 #endif
 
-// FOURIER_WAVES_EXACT(NT): additionally caps the waves per SIMD at the same figure (amdgpu_waves_per_eu(min, max)): the
-// occupancy of these kernels is fixed by their LDS tile (two 512-thread workgroups or one 1024-thread workgroup per CU),
-// so registers below the 128 that figure allows buy nothing -- hipcc then schedules for latency instead of for a
-// fifth wave that can never be resident.  A/B knob (tools/build_variants.py waves_exact).
-#if defined(FOURIER_AB_WAVES_EXACT) && !defined(FOURIER_EMU)
-#define FOURIER_WAVES_EXACT(NT) __attribute__((amdgpu_waves_per_eu(FOURIER_MIN_WAVES(NT), FOURIER_MIN_WAVES(NT))))
-#else
-#define FOURIER_WAVES_EXACT(NT)
-#endif
-
 namespace fourier_hip {
 
 template <typename T> struct cpx { T re, im; };
@@ -242,6 +232,18 @@ struct PassArgs {
   uint32_t nxcd;      // >1: remap blockIdx so that each XCD (blockIdx % nxcd) walks a contiguous tile range
   uint32_t xcd_interleave;  // block -> tile mapping mode, see xcd_remap()
   const void* blu_x;  // Bluestein chirp table x[0..blu_n) (IO_BLU_IN / IO_BLU_OUT)
+  // chirp-in pass WITHOUT the n-entry chirp table (a quarter of that pass's HBM-side traffic when read, PMC round 3):
+  // index k = row*cn + b, so x[k] = W_2n^{k^2} = blu_p[row] * blu_u[b] * W_n^{cn*row*b}; the cross term splits like the
+  // pass's own inter-pass twiddle into a per-thread factor and a per-tile LDS table, both from a two-level table of n-th
+  // roots with EXACT integer exponents (f64 products below 2^53).  blu_p == nullptr selects the table read.
+  const void* blu_p;     // [L/2]  W_2n^{(row*cn)^2 mod 2n}
+  const void* blu_u;     // [cn]   W_2n^{b^2 mod 2n}
+  const void* tn_lo;     // W_n^{e},            e < 2^tn_bits      } two-level table of n-th roots
+  const void* tn_hi;     // W_n^{h << tn_bits}, h <= n >> tn_bits  }
+  uint32_t tn_bits;
+  uint32_t blu_cn_mod;   // cn mod n
+  uint32_t blu_cnq_mod;  // (cn * Q) mod n
+  double blu_nd, blu_inv_nd;  // n and 1/n as doubles
   uint64_t blu_n;     // user transform length (batch stride of the user-side buffer)
   int blu_swap;       // user-level inverse: swap re/im of the user data
   int swap_in, swap_out;
@@ -356,6 +358,7 @@ template <typename T, int L, int CG> struct TileCfg {
   static constexpr size_t TABU_OFF = (EXCH_BYTES + 15) & ~(size_t)15;
   static constexpr size_t TABU_BYTES = (size_t)COLS * 16 * sizeof(cpx<T>);
   static constexpr size_t SMEM_FIRST = TABU_OFF + TABU_BYTES;
+  static constexpr size_t TABV_BYTES = (size_t)COLS * 8 * sizeof(cpx<T>);  // chirp-in first pass: cross-term table behind tabU
   static constexpr size_t SMEM_MID = TABU_OFF + 16 * sizeof(cpx<T>);
   static constexpr size_t SMEM_PLAIN = EXCH_BYTES;
   static __host__ __device__ constexpr size_t smem_bytes(int mode) {
@@ -527,11 +530,6 @@ __device__ __forceinline__ uint32_t xcd_remap(const PassArgs& a, uint64_t blk64,
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
-#ifdef FOURIER_AB_NO_FIRST_LAUNDER
-#define FOURIER_AB_LAUNDER(v)
-#else
-#define FOURIER_AB_LAUNDER(v) FOURIER_LAUNDER(v)
-#endif
 // ---- in-tile DFT of length L = 16 x R2 x R3 on a register tile (the body of every pass kernel) ----
 // In: thread (th, cg) holds rows th + Q*r of columns cg*VEC + v.  Out: register r holds output index
 // k = th + Q*r; for MODE_FIRST the last exchange also switches the thread mapping from cg-fastest ("A") to
@@ -559,7 +557,7 @@ __device__ __forceinline__ void tile_core(RegTile<T, L, CG>& x, int& th, int& cg
     {
       constexpr bool remap = (MODE == MODE_FIRST) && (R3 == 1);
       int tb = tid;
-      if constexpr (remap) FOURIER_AB_LAUNDER(tb);
+      if constexpr (remap) FOURIER_LAUNDER(tb);
       const int th_r = remap ? tb % Q : th, cg_r = remap ? tb / Q : cg;
       const int th_w = th;
       // both sides cg-fastest and split planes -> xor layout; anything row-contiguous -> skew layout
@@ -592,7 +590,7 @@ __device__ __forceinline__ void tile_core(RegTile<T, L, CG>& x, int& th, int& cg
       {
         constexpr bool remap = (MODE == MODE_FIRST);
         int tb = tid;
-        if constexpr (remap) FOURIER_AB_LAUNDER(tb);
+        if constexpr (remap) FOURIER_LAUNDER(tb);
         const int th_r = remap ? tb % Q : th, cg_r = remap ? tb / Q : cg;
         const int jw = th & 15, iw = th >> 4;
         __syncthreads();  // all reads of exchange 1 are done before the buffer is rewritten
@@ -635,6 +633,22 @@ template <typename T> __device__ __forceinline__ Unit16<T> ab_ones() { Unit16<T>
 #else
 #define FOURIER_AB_CHIRP_LOAD(rc, off) buf_load_unit<T>(rc, off)
 #endif
+// (x * y) mod n for x, y with x*y < 2^53, exactly: the f64 product and the fused remainder are exact, the quotient estimate
+// is off by at most one
+__device__ __forceinline__ uint32_t mulmod_n(uint32_t x, uint32_t y, double n, double inv_n) {
+  const double prod = (double)x * (double)y;
+  const double q = __builtin_floor(prod * inv_n);
+  double r = __builtin_fma(-q, n, prod);
+  r = r < 0.0 ? r + n : (r >= n ? r - n : r);
+  return (uint32_t)r;
+}
+// W_n^e, e < n, from the two-level table (one complex multiply)
+template <typename T> __device__ __forceinline__ cpx<T> root_n(const PassArgs& a, uint32_t e) {
+  const cpx<T>* lo = (const cpx<T>*)a.tn_lo;
+  const cpx<T>* hi = (const cpx<T>*)a.tn_hi;
+  return cmul(lo[e & ((1u << a.tn_bits) - 1u)], hi[e >> a.tn_bits]);
+}
+
 #ifndef FOURIER_BLU_OUT_ST_NT
 #define FOURIER_BLU_OUT_ST_NT 0
 #endif
@@ -696,6 +710,17 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
         const uint64_t i = c0 + (uint64_t)(idx >> 4);
         tabU[idx] = two_level_twiddle<T>(a, i * (uint64_t)(Q * (idx & 15)));
       }
+      if constexpr (IO == IO_BLU_IN) {
+        // computed chirp, cross term of column b and register r: tabV[col][r] = W_n^{(cn*Q*b*r) mod n}, r < 8
+        if (a.blu_p) {
+          cpx<T>* tabV = tabU + COLS * 16;
+          for (int idx = tid; idx < COLS * 8; idx += C::NT) {
+            const uint32_t bcol = (uint32_t)c0 + (uint32_t)(idx >> 3);
+            const uint32_t e = mulmod_n(mulmod_n(a.blu_cnq_mod, bcol, a.blu_nd, a.blu_inv_nd), (uint32_t)(idx & 7), a.blu_nd, a.blu_inv_nd);
+            tabV[idx] = root_n<T>(a, e);
+          }
+        }
+      }
     } else {
       if (tid < 16) tabU[tid] = two_level_twiddle<T>(a, (c0 >> a.s_shift) * (uint64_t)(Q * tid));
     }
@@ -721,20 +746,49 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
     const BufRsrc rd = make_rsrc(in + b * a.blu_n, nbytes), rc = make_rsrc(a.blu_x, nbytes);
     const uint32_t voff = (uint32_t)(((uint64_t)th * a.cn + c0 + (uint64_t)(cg * VEC)) * sizeof(cpx<T>));
     const uint32_t rowb = (uint32_t)((uint64_t)Q * a.cn * sizeof(cpx<T>));
-    Unit16<T> d[8], c[8];
+    Unit16<T> d[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) d[r] = buf_load_unit<T, LDAUX>(rd, voff + (uint32_t)r * rowb);
+    if (a.blu_p) {
+      // chirp computed, not read: x[k] = P[row] * (U[b] * W_n^{cn*b*th}) * tabV[col][r]   (see PassArgs)
+      const cpx<T>* pt = (const cpx<T>*)a.blu_p + th;
+      cpx<T> pr[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) c[r] = FOURIER_AB_CHIRP_LOAD(rc, voff + (uint32_t)r * rowb);
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
+      for (int r = 0; r < 8; ++r) pr[r] = pt[Q * r];
+      const Unit16<T> uu = *(const Unit16<T>*)((const cpx<T>*)a.blu_u + c0 + (uint64_t)(cg * VEC));
+      cpx<T> ub[VEC];
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
-        cpx<T> val{d[r].a[2 * v], d[r].a[2 * v + 1]};
-        if (a.blu_swap) val = {val.im, val.re};
-        x[v][r] = cmul(cpx<T>{c[r].a[2 * v], c[r].a[2 * v + 1]}, val);
-        x[v][r + 8] = cpx<T>{0, 0};
+        const uint32_t bcol = (uint32_t)c0 + (uint32_t)(cg * VEC + v);
+        const uint32_t e = mulmod_n(mulmod_n(a.blu_cn_mod, bcol, a.blu_nd, a.blu_inv_nd), (uint32_t)th, a.blu_nd, a.blu_inv_nd);
+        ub[v] = cmul(cpx<T>{uu.a[2 * v], uu.a[2 * v + 1]}, root_n<T>(a, e));
       }
+      __syncthreads();  // tabV
+      const cpx<T>* tabV = (const cpx<T>*)(smem + C::TABU_OFF) + COLS * 16;
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          cpx<T> val{d[r].a[2 * v], d[r].a[2 * v + 1]};
+          if (a.blu_swap) val = {val.im, val.re};
+          const cpx<T> c = cmul(cmul(pr[r], tabV[(cg * VEC + v) * 8 + r]), ub[v]);
+          x[v][r] = cmul(c, val);
+          x[v][r + 8] = cpx<T>{0, 0};
+        }
+    } else {
+      Unit16<T> c[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) c[r] = FOURIER_AB_CHIRP_LOAD(rc, voff + (uint32_t)r * rowb);
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          cpx<T> val{d[r].a[2 * v], d[r].a[2 * v + 1]};
+          if (a.blu_swap) val = {val.im, val.re};
+          x[v][r] = cmul(cpx<T>{c[r].a[2 * v], c[r].a[2 * v + 1]}, val);
+          x[v][r + 8] = cpx<T>{0, 0};
+        }
+    }
   } else if constexpr (SPLIT) {
     // rows n and n + L of the 2L-row tile; plain loads: the sibling workgroup's copy of each line comes from the L2
     const cpx<T>* p = in + b * a.n + (uint64_t)th * a.cn + c0 + (uint64_t)(cg * VEC);
@@ -764,11 +818,7 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
     const uint32_t voff = (uint32_t)(((uint64_t)th * a.cn + (uint64_t)(cg * VEC)) * sizeof(cpx<T>));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-#ifdef FOURIER_AB_PTR_LOADS  // A/B: per-lane 64-bit pointers (the round-2 form)
-      const Unit16<T> u = load_unit<T, LDPOL == POL_NT>((const char*)(p + (uint64_t)(Q * r) * a.cn) + voff);
-#else
       const Unit16<T> u = buf_load_unit<T, LDAUX>(make_rsrc(p + (uint64_t)(Q * r) * a.cn), voff);
-#endif
 #pragma unroll
       for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
     }
@@ -860,15 +910,14 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
         }
         u.a[2 * v] = y.re; u.a[2 * v + 1] = y.im;
       }
-#ifdef FOURIER_AB_PTR_STORES  // A/B: per-lane 64-bit pointers (the round-2 form)
-      store_unit<T, STPOL == POL_NT>((char*)(out + base + rows * (uint64_t)r) + voff, u);
-#else
       buf_store_unit<T, STAUX>(make_rsrc(out + base + rows * (uint64_t)r), voff, u);
-#endif
     }
   }
 }
 
+#ifndef FOURIER_NT_STORE_NARROW_2048
+#define FOURIER_NT_STORE_NARROW_2048 1  // streaming intermediate stores also for the narrow-tile (two workgroups per CU) first passes of length 2048 / 4096: -3..-6 % on that pass (profiles/r03_s8_*.jsonl); 0 = plain
+#endif
 // default cache policy of the stand-alone pass kernels (see the FOURIER_NT_* notes at the top of this file)
 template <int L, int MODE, int CG = 8> struct PassPolicy {
   static constexpr bool FINAL = (MODE == MODE_LAST || MODE == MODE_ROWS);
@@ -879,7 +928,7 @@ template <int L, int MODE, int CG = 8> struct PassPolicy {
   // MODE_ROWS: a wave's element stores only form whole lines for L >= 256; below that they rely on L2
   // write-combining and a non-temporal hint is a 2-6x loss (N = 16..64, r01 session 9)
   static constexpr int ST = (MODE == MODE_ROWS ? (FOURIER_NT_STORE != 0 && L >= 256)
-                             : (FINAL ? FOURIER_NT_STORE != 0 : (FOURIER_NT_STORE == 2 && L <= 1024))) ? POL_NT : POL_PLAIN;
+                             : (FINAL ? FOURIER_NT_STORE != 0 : (FOURIER_NT_STORE == 2 && (L <= 1024 || (FOURIER_NT_STORE_NARROW_2048 && CG < 8))))) ? POL_NT : POL_PLAIN;
 };
 
 // last pass of length 2L on half tiles (pass_tile, SPLIT = 1): grid = 2 x batch x tiles
@@ -893,7 +942,7 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
 }
 
 template <typename T, int L, int CG, int MODE, int IO = IO_PLAIN>
-__global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG)) FOURIER_WAVES_EXACT((L / 16) * CG) fft_pass_kernel(PassArgs a) {
+__global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG)) fft_pass_kernel(PassArgs a) {
   FOURIER_DYN_SMEM(smem);
   pass_tile<T, L, CG, MODE, IO, PassPolicy<L, MODE, CG>::LD, PassPolicy<L, MODE, CG>::ST>(a, blockIdx.x, gridDim.x, smem, (int)threadIdx.x);
 }
@@ -1076,7 +1125,7 @@ __global__ void __launch_bounds__((L1 / 16) * CG1, FOURIER_FUSED_MIN_WAVES) fft_
 // one write of the work array instead of two of each.  The inverse is swap . DFT . swap (mod.rs:366-387):
 // the leading swap happens here, the trailing one in the inverse plan's last pass.
 template <typename T, int L, int CG>
-__global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16) * CG)) FOURIER_WAVES_EXACT((L / 16) * CG) fft_conv_kernel(PassArgs a) {
+__global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16) * CG)) fft_conv_kernel(PassArgs a) {
   using C = TileCfg<T, L, CG>;
   constexpr int VEC = C::VEC, Q = C::Q, COLS = C::COLS;
   static_assert(Q > 1, "conv kernel: L >= 32");
@@ -1383,7 +1432,7 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
 
 template <typename T, int L1, int L2>
 __global__ void __launch_bounds__(FOURIER_TWOLEVEL_NT(T, L1, L2), FOURIER_MIN_WAVES(FOURIER_TWOLEVEL_NT(T, L1, L2)))
-    FOURIER_WAVES_EXACT(FOURIER_TWOLEVEL_NT(T, L1, L2)) fft_twolevel_kernel(PassArgs a) {
+    fft_twolevel_kernel(PassArgs a) {
   constexpr int VEC = 16 / (2 * (int)sizeof(T));
   constexpr int CG1 = L2 / VEC, CG2 = L1 / VEC, Q1 = L1 / 16, Q2 = L2 / 16, N = L1 * L2;
   FOURIER_DYN_SMEM(smem);

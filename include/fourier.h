@@ -163,6 +163,10 @@ const char *fourier_hip_status_string(int status);
  *   "host_chunk_bytes" bytes of one chunk of fourier_hip_transform_batch_host_* (default 32 MiB, four in flight)
  *   "bluestein_conv"   1 (default with bluestein_fusion) = the forward inner FFT's last pass, the multiply by the
  *                  transformed chirp and the inverse inner FFT's first pass run as one launch
+ *   "bluestein_chirp_compute" 1 = the fused chirp-in pass computes exp(-i*pi*k^2/N) (row table x column table x an
+ *                  exact-exponent cross term) instead of reading the N-entry chirp table, a quarter of that pass's
+ *                  memory traffic; default 1 where it was measured faster (first pass of length >= 1024 and a table
+ *                  of >= 4 MiB, e.g. N = 999983), else 0.  Same tolerance class, not the same bits.
  *   "l2_fused"     (builds with -DFOURIER_EXPERIMENTS only; INVALID_ARGUMENT in the product library) 1 = run both
  *                  passes of a two-pass plan in ONE launch with the intermediate parked in the XCD's L2 (persistent
  *                  workgroups, per-XCD work queues; f32 2^16..2^18, f64 2^15..2^17 only).  Same results bit for

@@ -55,6 +55,8 @@ mod hip {
                                                    batch: usize, t: c_int) -> c_int;
         fn fourier_hip_reserve_float(p: *const FourierFftFloat, batch: usize, in_place: c_int) -> c_int;
         fn fourier_hip_reserve_double(p: *const FourierFftDouble, batch: usize, in_place: c_int) -> c_int;
+        fn fourier_hip_synchronize_float(p: *const FourierFftFloat, stream: *mut c_void) -> c_int;
+        fn fourier_hip_synchronize_double(p: *const FourierFftDouble, stream: *mut c_void) -> c_int;
         fn fourier_hip_last_status_float(p: *const FourierFftFloat) -> c_int;
         fn fourier_hip_last_status_double(p: *const FourierFftDouble) -> c_int;
         fn fourier_hip_status_string(status: c_int) -> *const c_char;
@@ -87,7 +89,7 @@ mod hip {
 
     macro_rules! hip_plan {
         ($name:ident, $real:ty, $handle:ty, $create:ident, $create_dev:ident, $destroy:ident, $in_place:ident, $oop:ident,
-         $batch:ident, $batch_host:ident, $reserve:ident, $status:ident) => {
+         $batch:ident, $batch_host:ident, $reserve:ident, $status:ident, $sync:ident) => {
             /// One plan on one device.  `Send`, not `Sync`.
             pub struct $name {
                 handle: *mut $handle,
@@ -125,6 +127,13 @@ mod hip {
                 /// Pre-size the plan's device buffers so that later device batches of up to `batch` never allocate.
                 pub fn reserve(&self, batch: usize, in_place: bool) -> Result<(), HipError> {
                     check(unsafe { $reserve(self.handle, batch, in_place as c_int) })
+                }
+                /// Wait for everything queued on `stream` (null = the NULL stream) of the plan's device: the blocking half of
+                /// `transform_batch_device` for a caller that has no HIP runtime binding of its own.
+                /// # Safety
+                /// `stream` must be null or a live `hipStream_t` of the plan's device.
+                pub unsafe fn synchronize(&self, stream: *mut c_void) -> Result<(), HipError> {
+                    check($sync(self.handle, stream))
                 }
                 fn last_status(&self) -> c_int {
                     unsafe { $status(self.handle) }
@@ -166,10 +175,12 @@ mod hip {
 
     hip_plan!(HipFft32, f32, FourierFftFloat, fourier_create_float, fourier_hip_create_float, fourier_destroy_float,
               fourier_transform_in_place_float, fourier_transform_float, fourier_hip_transform_batch_float,
-              fourier_hip_transform_batch_host_float, fourier_hip_reserve_float, fourier_hip_last_status_float);
+              fourier_hip_transform_batch_host_float, fourier_hip_reserve_float, fourier_hip_last_status_float,
+              fourier_hip_synchronize_float);
     hip_plan!(HipFft64, f64, FourierFftDouble, fourier_create_double, fourier_hip_create_double, fourier_destroy_double,
               fourier_transform_in_place_double, fourier_transform_double, fourier_hip_transform_batch_double,
-              fourier_hip_transform_batch_host_double, fourier_hip_reserve_double, fourier_hip_last_status_double);
+              fourier_hip_transform_batch_host_double, fourier_hip_reserve_double, fourier_hip_last_status_double,
+              fourier_hip_synchronize_double);
 }
 
 #[cfg(feature = "hip")]

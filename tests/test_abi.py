@@ -108,7 +108,7 @@ def test_rust_shim_names_only_exported_symbols(libpath):
     block = src[src.index('extern "C" {'):]
     block = block[:block.index("\n    }")]
     names = set(re.findall(r"fn (fourier_\w+)\(", block))
-    assert len(names) == 19, sorted(names)
+    assert len(names) == 21, sorted(names)
     exported = set(subprocess.run(["nm", "-D", "--defined-only", libpath], capture_output=True, text=True).stdout.split())
     header = open(os.path.join(root, "include", "fourier.h")).read()
     for n in sorted(names):
@@ -118,9 +118,8 @@ def test_rust_shim_names_only_exported_symbols(libpath):
 
 def test_cmake_package_configures(tmp_path):
     """packaging/CMakeLists.txt (shared + static library from one object library, five ctest programs) must at least
-    configure with the ROCm toolchain of this image.  Building it compiles the engine once more (~2 min) and its
-    programs need a GPU, so the build + ctest run is a manual step; the same link lines are exercised
-    against the in-tree libraries by the `-m gpu` tests."""
+    configure with the ROCm toolchain of this image.  Building it compiles the engine once more (~2 min here) and its
+    programs need a GPU: the build + ctest run is tests/test_gpu_parity.py::test_cmake_package_builds_and_its_ctest_programs_pass."""
     import shutil
     import subprocess
 

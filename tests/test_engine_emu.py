@@ -239,6 +239,23 @@ def test_bluestein_conv_kernel_matches_separate_passes(fa, oracle):
             assert np.array_equal(run_batch(conv, x, code, inplace=True), a), (n, code)
 
 
+def test_bluestein_chirp_in_pass_computes_the_chirp(fa, oracle):
+    """The fused chirp-in first pass builds x[k] = exp(-i*pi*k^2/N) from a row table, a column table and an exact-exponent
+    cross term (option bluestein_chirp_compute, default on) instead of reading the N-entry table: both against the
+    oracle and against each other, forward and inverse, f32 and f64."""
+    for n, dtype, tol in ((40000, np.complex64, 2e-6), (70001, np.complex64, 2e-6), (40000, np.complex128, 5e-11)):
+        x = np.stack([hash_normal(600 + b, n) for b in range(2)]).astype(dtype)
+        comp, read = make(fa, n, dtype), make(fa, n, dtype)
+        comp.set_option("bluestein_chirp_compute", 1)  # default: on only for long first passes and tables beyond the L2
+        read.set_option("bluestein_chirp_compute", 0)
+        for code in (0, 1):
+            ref = oracle.transform_batch(x, code)
+            a, b = run_batch(comp, x, code), run_batch(read, x, code)
+            assert rel_l2(a, ref) <= tol and rel_l2(b, ref) <= tol, (n, code, rel_l2(a, ref), rel_l2(b, ref))
+            assert rel_l2(a, b) <= (3e-7 if dtype == np.complex64 else 1e-12), (n, code, rel_l2(a, b))
+            assert not np.array_equal(a, b) or dtype == np.complex128  # the two routes are really different code
+
+
 def test_bluestein_conv_three_pass_inner_plan(fa):
     # M = 2^23: forward 256x256x128, inverse mirrored 128x256x256, middle launch = last forward + first inverse
     n = 2200000

@@ -231,7 +231,7 @@ def test_bluestein_fusion_matches_unfused(torch, fa):
         plain.set_option("bluestein_fusion", 0)
         for code in (0, 1, 4):
             a, b = gpu_batch(torch, fa, fused, x, code), gpu_batch(torch, fa, plain, x, code)
-            assert rel_l2(a, b) <= 3e-7, (n, code, rel_l2(a, b))  # different factorisation order, same tolerance class
+            assert rel_l2(a, b) <= 4e-7, (n, code, rel_l2(a, b))  # different factorisation order, same tolerance class
             assert np.array_equal(gpu_batch(torch, fa, fused, x, code, inplace=True), a), (n, code)
 
 
@@ -895,3 +895,21 @@ def test_million_transform_grids_of_the_small_n_kernels_are_value_checked(torch,
     assert bool(torch.isfinite(ey).all())
     assert float(((ey - n * ex).abs() / (n * ex)).max()) <= 2e-5, n
 
+
+
+@pytest.mark.parametrize("n,dtype,tol", [(999983, np.complex64, 2e-6), (65537, np.complex64, 2e-6), (2200000, np.complex64, 2e-6),
+                                         (999983, np.complex128, 1e-9), (70001, np.complex128, 5e-11)])
+def test_bluestein_chirp_in_pass_computes_the_chirp(torch, fa, oracle, n, dtype, tol):
+    """Option bluestein_chirp_compute (default on): the chirp-in first pass builds exp(-i*pi*k^2/N) from a row table, a
+    column table and an exact-exponent cross term instead of reading the N-entry table (a quarter of that pass's
+    HBM-side traffic).  Against the oracle and against the table-reading route, forward and inverse."""
+    x = np.stack([hash_uniform(880 + b, n) for b in range(2)]).astype(dtype)
+    comp, read = make(fa, n, dtype), make(fa, n, dtype)
+    comp.set_option("bluestein_chirp_compute", 1)  # the default turns it on only for long first passes and large tables
+    read.set_option("bluestein_chirp_compute", 0)
+    for code in (0, 1, 3):
+        ref = oracle.transform_batch(x, code)
+        a, b = gpu_batch(torch, fa, comp, x, code), gpu_batch(torch, fa, read, x, code)
+        assert rel_l2(a, ref) <= tol and rel_l2(b, ref) <= tol, (n, code, rel_l2(a, ref), rel_l2(b, ref))
+        assert rel_l2(a, b) <= (4e-7 if dtype == np.complex64 else 1e-12), (n, code, rel_l2(a, b))
+        assert np.array_equal(gpu_batch(torch, fa, comp, x, code, inplace=True), a), (n, code)

@@ -44,17 +44,14 @@ VARIANTS = {
     "cg4096_4": ["-DFOURIER_CG_4096=4"],
     "split_nt": ["-DFOURIER_SPLIT_LD=POL_NT"],
     "tl_store_soff": ["-DFOURIER_TWOLEVEL_STORE_SOFF=1"],
-    "ptr_loads": ["-DFOURIER_AB_PTR_LOADS=1"],
-    "no_first_launder": ["-DFOURIER_AB_NO_FIRST_LAUNDER=1"],
-    "ptr_nolaunder": ["-DFOURIER_AB_PTR_LOADS=1", "-DFOURIER_AB_NO_FIRST_LAUNDER=1"],
     "no_chirp": ["-DFOURIER_AB_NO_CHIRP=1"],
     "no_w": ["-DFOURIER_AB_NO_W=1"],
-    "ptr_stores": ["-DFOURIER_AB_PTR_STORES=1"],
-    "ptr_both": ["-DFOURIER_AB_PTR_STORES=1", "-DFOURIER_AB_PTR_LOADS=1"],
     "stage_tw0": ["-DFOURIER_STAGE_TW_BATCH=0"],
     "stage_tw4": ["-DFOURIER_STAGE_TW_BATCH=4"],
     "blu_out_nt": ["-DFOURIER_BLU_OUT_ST_NT=1"],
-    "waves_exact": ["-DFOURIER_AB_WAVES_EXACT=1"],
+    "nt_narrow2048_off": ["-DFOURIER_NT_STORE_NARROW_2048=0"],
+    "conv_wb4": ["-DFOURIER_CONV_W_BATCH=4"],
+    "conv_wb16": ["-DFOURIER_CONV_W_BATCH=16"],
     "abl1": ["-DFOURIER_ABLATE=1"],
     "abl2": ["-DFOURIER_ABLATE=2"],
     "abl3": ["-DFOURIER_ABLATE=3"],

@@ -36,16 +36,14 @@ def run(tag, n, batch, real="f32", opts=(), check=True):
 
 if __name__ == "__main__":
     for rep in range(2):
-        for sw in (1, 4, 3):
-            run("C4", 999983, 512, opts=(("xcd_swizzle", sw),))
-    for sw in (1, 4):
-        run("C4 f64", 999983, 256, "f64", opts=(("xcd_swizzle", sw),))
-        run("N=65537", 65537, 8192, opts=(("xcd_swizzle", sw),))
-        run("N=40000", 40000, 8192, opts=(("xcd_swizzle", sw),))
-    run("C4 unfused", 999983, 512, opts=(("bluestein_fusion", 0),))
-    run("C4 noconv", 999983, 512, opts=(("bluestein_conv", 0),))
+        for cc in (1, 0):
+            run("C4", 999983, 512, opts=(("bluestein_chirp_compute", cc),))
+    for cc in (1, 0):
+        run("C4 f64", 999983, 256, "f64", opts=(("bluestein_chirp_compute", cc),))
+        run("N=65537", 65537, 8192, opts=(("bluestein_chirp_compute", cc),))
+        run("N=40000", 40000, 8192, opts=(("bluestein_chirp_compute", cc),))
+        run("N=2200000", 2200000, 128, opts=(("bluestein_chirp_compute", cc),))
     run("N=1021", 1021, 1 << 18)
     run("N=3125", 3125, 1 << 16)
     run("N=10007", 10007, 1 << 15)
     run("N=191", 191, 1 << 20)
-    run("N=1021 f64", 1021, 1 << 17, "f64")
