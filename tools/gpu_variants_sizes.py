@@ -12,7 +12,8 @@ CASES = [("2^20", 1 << 20, 2048, "f32"), ("2^20 f64", 1 << 20, 1024, "f64"), ("2
          ("2^14", 1 << 14, 1 << 15, "f32"), ("2^15", 1 << 15, 1 << 14, "f32"), ("1000", 1000, 1 << 18, "f32"),
          ("2^11", 2048, 1 << 18, "f32"), ("2^13", 8192, 1 << 16, "f32"), ("125", 125, 1 << 21, "f32"), ("3125", 3125, 1 << 16, "f32"),
          ("2^11 f64", 2048, 1 << 17, "f64"), ("1000 f64", 1000, 1 << 17, "f64"), ("2^8 f64", 256, 1 << 20, "f64"), ("2^6 f64", 64, 1 << 21, "f64"), ("2^5 f64", 32, 1 << 22, "f64"), ("2^7", 128, 1 << 21, "f32"),
-         ("2^7 f64", 128, 1 << 20, "f64"), ("2^10 f64", 1024, 1 << 18, "f64")]
+         ("2^7 f64", 128, 1 << 20, "f64"), ("2^10 f64", 1024, 1 << 18, "f64"),
+         ("2^14 big", 1 << 14, 1 << 16, "f32"), ("2^15 big", 1 << 15, 1 << 15, "f32"), ("2^12 big", 4096, 1 << 18, "f32"), ("2^14 f64", 1 << 14, 1 << 15, "f64"), ("2^13 f64", 1 << 13, 1 << 16, "f64")]
 
 
 def run(lib, tag, n, batch, real, x, y):
