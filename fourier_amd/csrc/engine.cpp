@@ -1052,6 +1052,90 @@ template <typename T> class MixedEngine {
 };
 
 // ---------------------------------------------------------------------------------------------
+// 2^a * 3^b with a < 12 beyond the LDS kernels' reach (3^10, 2^8*3^5, ...): the reference's Stockham autosort pass by pass in
+// global memory (autosort/mod.rs:203-284), radices 27 / 9 / 3 first, then 16 / 8 / 4 / 2; one HBM round trip per pass
+// instead of Bluestein's five over a padded power of two.  Intermediates ping-pong between the two halves of the
+// plan's scratch, the last pass writes the output (in place allowed).
+template <typename T> class GenericEngine {
+ public:
+  static constexpr size_t MAX_N = (size_t)1 << 26;
+  static bool handles(size_t n) {
+    if (n < 2 || n > MAX_N || dev_env("FOURIER_NO_GENERIC_MIXED")) return false;
+    size_t p = n;
+    while (p % 3 == 0) p /= 3;
+    return is_pow2(p) && p < 4096 && p != n;  // b >= 1, a < 12 (a >= 12 runs as tiled passes + odd passes)
+  }
+  explicit GenericEngine(size_t n) : n_(n) {
+    size_t p3 = 1, p2 = n;
+    while (p2 % 3 == 0) { p2 /= 3; p3 *= 3; }
+    std::vector<int> radices;
+    while (p3 > 1) { const int r = p3 % 27 == 0 ? 27 : (p3 % 9 == 0 ? 9 : 3); radices.push_back(r); p3 /= (size_t)r; }
+    while (p2 > 1) { const int r = p2 % 16 == 0 ? 16 : (p2 % 8 == 0 ? 8 : (p2 % 4 == 0 ? 4 : 2)); radices.push_back(r); p2 /= (size_t)r; }
+    size_t s = 1, size = n;
+    for (int r : radices) {
+      Pass ps;
+      ps.r = r; ps.s = (uint32_t)s; ps.m = (uint32_t)(size / (size_t)r);
+      ps.tw.reset(new DevBuf());
+      if (ps.m > 1) {  // W_size^{e}, e < size (f64 trig, cast: twiddle.rs:7-19)
+        std::vector<cpx<T>> tw(size);
+        for (size_t e = 0; e < size; ++e) { double re, im; unit_root(e, size, re, im); tw[e] = {(T)re, (T)im}; }
+        ps.tw->upload(tw);
+      }
+      switch (r) {
+        case 2: ps.fn = &stockham_pass_kernel<T, 2>; break;
+        case 3: ps.fn = &stockham_pass_kernel<T, 3>; break;
+        case 4: ps.fn = &stockham_pass_kernel<T, 4>; break;
+        case 8: ps.fn = &stockham_pass_kernel<T, 8>; break;
+        case 9: ps.fn = &stockham_pass_kernel<T, 9>; break;
+        case 16: ps.fn = &stockham_pass_kernel<T, 16>; break;
+        default: ps.fn = &stockham_pass_kernel<T, 27>; break;
+      }
+      ps.smem = s == 1 ? (size_t)r * 256 * sizeof(cpx<T>) : 0;  // first pass: the workgroup's outputs are staged in LDS
+      raise_smem_limit((const void*)ps.fn, ps.smem);
+      passes_.push_back(std::move(ps));
+      s *= (size_t)r; size /= (size_t)r;
+    }
+  }
+  size_t num_passes() const { return passes_.size(); }
+  std::string describe() const {
+    std::string d;
+    for (const Pass& p : passes_) d += (d.empty() ? "" : ".") + std::to_string(p.r);
+    return d;
+  }
+  // scratch: 2 * batch * n elements (two halves), unused when there is a single pass
+  void run(const cpx<T>* in, cpx<T>* out, cpx<T>* scratch, size_t batch, bool inverse, double scale, hipStream_t stream, Profiler* prof) const {
+    if (batch == 0) return;
+    const size_t np = passes_.size();
+    cpx<T>* half[2] = {scratch, scratch + batch * n_};
+    const cpx<T>* src = in;
+    for (size_t p = 0; p < np; ++p) {
+      const Pass& ps = passes_[p];
+      cpx<T>* dst = (p + 1 == np) ? out : half[p & 1];
+      GenArgs a;
+      std::memset(&a, 0, sizeof(a));
+      a.in = src; a.out = dst; a.tw = ps.m > 1 ? ps.tw->p : nullptr;
+      a.n = n_; a.s = ps.s; a.m = ps.m;
+      const uint64_t per = (uint64_t)ps.s * ps.m;
+      a.blocks_per = (uint32_t)((per + 255) / 256);
+      a.swap_in = (p == 0) && inverse; a.swap_out = (p + 1 == np) && inverse; a.final_pass = (p + 1 == np);
+      a.scale = (p + 1 == np) ? scale : 1.0;
+      for (int e = 0; e < ps.r && e < 27; ++e) unit_root((uint64_t)e, (uint64_t)ps.r, a.wr[e], a.wi[e]);
+      const uint64_t grid = (uint64_t)a.blocks_per * batch;
+      if (grid > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");
+      PROF_BEGIN(prof, (int)p);
+      FOURIER_LAUNCH(ps.fn, grid, 256, ps.smem, stream, a);
+      PROF_END(prof);
+      src = dst;
+    }
+  }
+
+ private:
+  struct Pass { int r = 0; uint32_t s = 0, m = 0; std::unique_ptr<DevBuf> tw; void (*fn)(GenArgs) = nullptr; size_t smem = 0; };
+  size_t n_;
+  std::vector<Pass> passes_;
+};
+
+// ---------------------------------------------------------------------------------------------
 // host f64 radix-2 FFT, used only at plan time for the Bluestein w table (bluesteins.rs:46-47)
 static void host_fft(std::vector<double>& re, std::vector<double>& im) {
   const size_t m = re.size();
@@ -1098,6 +1182,8 @@ template <typename T> class Plan {
       eng_.reset(new Pow2Engine<T>(n));
     } else if (MixedEngine<T>::handles(n)) {
       mix_.reset(new MixedEngine<T>(n));
+    } else if (GenericEngine<T>::handles(n)) {
+      gen_.reset(new GenericEngine<T>(n));
     } else {
       init_bluestein();
     }
@@ -1105,6 +1191,7 @@ template <typename T> class Plan {
   }
   void refresh_desc() {
     if (mix_) desc_ = "stockham mixed-radix " + mix_->describe();
+    else if (gen_) desc_ = "stockham global-pass " + gen_->describe();
     else if (blu_) desc_ = "bluestein M=" + std::to_string(m_) + " inner " + eng_->describe() + (small_fused_ ? " fused" : "");
     else desc_ = "stockham " + eng_->describe();
     desc_ += sizeof(T) == 4 ? " f32" : " f64";
@@ -1129,6 +1216,7 @@ template <typename T> class Plan {
   std::string slot_names() const {
     std::string d;
     if (mix_) return "mixed_radix";
+    if (gen_) { for (size_t p = 0; p < gen_->num_passes(); ++p) d += std::string(d.empty() ? "" : ",") + "pass" + std::to_string(p); return d; }
     auto passes = [&](const char* tag) {
       for (size_t p = 0; p < (blu_ ? eng_->num_passes() : eng_->hbm_round_trips()); ++p) d += std::string(d.empty() ? "" : ",") + tag + std::to_string(p);
     };
@@ -1144,6 +1232,7 @@ template <typename T> class Plan {
 
   double model_bytes() const {
     if (mix_) return 2.0 * n_ * ELEM;
+    if (gen_) return 2.0 * n_ * ELEM * gen_->num_passes();
     if (!blu_) return 2.0 * n_ * ELEM * eng_->hbm_round_trips();
     // unfused: pre (n + table read, m write) + 2 inner FFTs + w table + post (n + table read, n write);
     // fused: the first / last inner pass read / write the n-point user array instead of an m-point sweep
@@ -1186,6 +1275,19 @@ template <typename T> class Plan {
   // captured into a HIP graph.  Returns the number of transforms per chunk.
   size_t prepare(size_t batch, bool in_place) const {
     if (mix_ || batch == 0) return batch;
+    if (gen_) {  // two scratch halves of one chunk each; chunked so that a launch stays below 2^31 workgroups
+      size_t chunk = batch;
+      if (chunk_bytes_) chunk = std::max<size_t>(1, std::min<size_t>(batch, chunk_bytes_ / (n_ * ELEM)));
+      while (chunk > 1 && (double)chunk * (double)n_ / 256.0 > 2.0e9) chunk = (chunk + 1) / 2;
+      for (;;) {
+        try { scratch_.ensure(2 * chunk * n_ * ELEM); return chunk; }
+        catch (const EngineError& e) {
+          if (e.status != ::fourier::c::FOURIER_HIP_OUT_OF_MEMORY || chunk <= 1) throw;
+          (void)hipGetLastError();
+          chunk = (chunk + 1) / 2;
+        }
+      }
+    }
     const size_t per = (blu_ ? m_ : n_) * ELEM;
     size_t chunk = batch;
     if (chunk_bytes_) chunk = std::max<size_t>(1, std::min<size_t>(batch, chunk_bytes_ / per));
@@ -1246,6 +1348,13 @@ template <typename T> class Plan {
     }
     const size_t chunk = prepare(batch, in_place);
 
+    if (gen_) {
+      for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+        const size_t nb = std::min(chunk, batch - b0);
+        gen_->run(in + b0 * n_, out + b0 * n_, (cpx<T>*)scratch_.p, nb, inverse, scale, stream, prof);
+      }
+      return;
+    }
     if (!blu_) {
       for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const size_t nb = std::min(chunk, batch - b0);
@@ -1544,6 +1653,7 @@ template <typename T> class Plan {
   bool blu_ = false;
   std::unique_ptr<Pow2Engine<T>> eng_, eng_inv_;  // eng_inv_: mirrored inverse plan of a conv-fused Bluestein
   std::unique_ptr<MixedEngine<T>> mix_;
+  std::unique_ptr<GenericEngine<T>> gen_;  // 2^a*3^b, a < 12, beyond the LDS kernels
   DevBuf xtab_, wtab_;
   DevBuf chirp_p_, chirp_u_, tn_lo_, tn_hi_;  // chirp-in pass computing the chirp (init_bluestein)
   uint32_t tn_bits_ = 0;

@@ -26,6 +26,7 @@
 //   mixed_radix_kernel_ct<T, N>           2^a*3^b in LDS with the reference's schedule, one instantiation per length
 //   mixed_radix_kernel<T>                 the same, runtime-parameterised (A/B reference)
 //   odd_last_kernel<T, R>                 radix-3/9/27 passes (twiddled middle ones and the final one) of the large 2^a*3^b sizes
+//   stockham_pass_kernel<T, R>            one pass in global memory, any radix and stride: 2^a*3^b with a < 12 beyond the LDS limit
 //   blu_pre_kernel / blu_post_kernel      unfused chirp sweeps (option bluestein_fusion = 0)
 #pragma once
 #include <stdint.h>
@@ -1850,8 +1851,8 @@ template <typename T> __device__ __forceinline__ void dft3(cpx<T>& a, cpx<T>& b,
   c = {m.re - r.re, m.im - r.im};
 }
 // natural-order DFT of R = 3^b points at x[0], x[STRIDE], ... using the table W_RT^e (RT = top-level radix)
-template <typename T, int R, int RT, int STRIDE>
-__device__ __forceinline__ void dft_pow3(cpx<T>* x, const OddArgs& a) {
+template <typename T, int R, int RT, int STRIDE, typename Args>
+__device__ __forceinline__ void dft_pow3(cpx<T>* x, const Args& a) {
   if constexpr (R == 3) {
     dft3(x[0], x[STRIDE], x[2 * STRIDE]);
   } else {
@@ -2115,6 +2116,67 @@ __global__ void __launch_bounds__(256) odd_last_kernel(OddArgs a) {
     if (last) store_unit<T, FOURIER_NT_STORE != 0>(out + (uint64_t)k * a.s, v);
     else store_unit<T, false>(out + (uint64_t)k * a.s, v);
   }
+}
+
+// ---- one Stockham pass in global memory, any radix R in {2,3,4,8,9,16,27}, any stride: the 2^a*3^b lengths with a < 12
+// that do not fit the LDS kernels (3^10, 2^8*3^5, ...).  The reference's pass verbatim (autosort/mod.rs:203-284):
+//   out[j + R*s*i + s*k] = W_size^{i*k} * DFT_R(in[j + s*i + s*m*k'])_k,   i < m, j < s, size = R*m,
+// one thread per butterfly e = j + s*i: for a fixed k' the reads in[e + s*m*k'] are contiguous over the threads whatever
+// the stride; the writes are contiguous in runs of s.  Passes are scheduled odd radices first (27, 9, 3), then 16, 8, 4, 2
+// (GenericEngine); every pass is one HBM round trip.
+struct GenArgs {
+  const void* in; void* out;
+  const void* tw;             // W_size^{e}, e < size (null when m == 1: the last pass has no twiddle, mod.rs:238)
+  uint64_t n;                 // transform length (batch stride)
+  uint32_t s, m;              // stride, butterflies per stride group; s * m = n / R
+  uint32_t blocks_per;        // workgroups per transform
+  int swap_in, swap_out, final_pass;
+  double scale;
+  double wr[27], wi[27];      // W_R^e for the radix-3^b butterflies
+};
+template <typename T, int R>
+__global__ void __launch_bounds__(256) stockham_pass_kernel(GenArgs a) {
+  const uint32_t per = a.s * a.m;
+  const uint32_t b = blockIdx.x / a.blocks_per;                                     // wave-uniform: scalar division
+  const uint32_t e0 = (blockIdx.x - b * a.blocks_per) * 256u, e = e0 + threadIdx.x;
+  const bool valid = e < per;
+  const uint32_t i = e / a.s, j = e - i * a.s;
+  const cpx<T>* in = (const cpx<T>*)a.in + (uint64_t)b * a.n + e;
+  cpx<T> x[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    x[k] = valid ? in[(uint64_t)per * k] : cpx<T>{0, 0};
+    if (a.swap_in) x[k] = {x[k].im, x[k].re};
+  }
+  if constexpr (R == 3 || R == 9 || R == 27) dft_pow3<T, R, R, 1>(x, a);
+  else dft_r<T, R>(x);
+  const cpx<T>* tw = (const cpx<T>*)a.tw;
+  const T scale = (T)a.scale;
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    if (tw && k > 0 && valid) x[k] = cmul(x[k], tw[(uint64_t)i * k]);
+    if (a.final_pass) {
+      if (a.swap_out) x[k] = {x[k].im, x[k].re};
+      x[k] = {x[k].re * scale, x[k].im * scale};
+    }
+  }
+  if (a.s == 1) {
+    // first pass: thread i owns out[R*i .. R*i + R), a lane stride of R elements -- every store instruction would touch 64
+    // different lines.  The workgroup's 256 * R outputs are one contiguous run: stage them in LDS, store them linearly.
+    FOURIER_DYN_SMEM(smem);
+    cpx<T>* stage = (cpx<T>*)smem;
+#pragma unroll
+    for (int k = 0; k < R; ++k) stage[(uint32_t)R * threadIdx.x + (uint32_t)k] = x[k];
+    __syncthreads();
+    const uint32_t left = per - e0, count = (uint32_t)R * (left < 256u ? left : 256u);
+    cpx<T>* out = (cpx<T>*)a.out + (uint64_t)b * a.n + (uint64_t)R * e0;
+    for (uint32_t idx = threadIdx.x; idx < count; idx += 256u) out[idx] = stage[idx];
+    return;
+  }
+  if (!valid) return;
+  cpx<T>* out = (cpx<T>*)a.out + (uint64_t)b * a.n + j + (uint64_t)R * a.s * i;
+#pragma unroll
+  for (int k = 0; k < R; ++k) out[(uint64_t)a.s * k] = x[k];
 }
 
 // ---- Bluestein chirp-z pointwise steps (reference: fourier-algorithms/src/bluesteins.rs:229-258) ----

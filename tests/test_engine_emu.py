@@ -181,6 +181,28 @@ def test_large_mixed_radix_sizes_run_natively(fa, oracle):
     assert "bluestein" in make(fa, 9 * 2048, np.complex128).describe()   # f64 18432: beyond both native routes
 
 
+def test_mixed_radix_sizes_beyond_the_lds_limit_with_a_small_power_of_two_run_pass_by_pass(fa, oracle, monkeypatch):
+    """2^a * 3^b with a < 12 above 18432 (f32) / 9216 (f64) points used to fall to Bluestein (missing
+    #4); the reference runs them in its Stockham path (autosort/mod.rs:104-116).  Now: one global-memory Stockham pass
+    per radix (27 / 9 / 3, then 16 / 8 / 4 / 2).  All five codes, in and out of place, ragged batch, against the oracle
+    and (experiments build) against the Bluestein route they replace."""
+    for n, dtype, tol in ((59049, np.complex64, 1e-6), (62208, np.complex64, 1e-6), (39366, np.complex64, 1e-6),
+                          (55296, np.complex64, 1e-6), (20736, np.complex64, 1e-6), (10368, np.complex128, 5e-14),
+                          (13122, np.complex128, 5e-14)):
+        plan = make(fa, n, dtype)
+        assert "global-pass" in plan.describe(), plan.describe()
+        x = np.stack([hash_normal(900 + b, n) for b in range(3)]).astype(dtype)
+        for code in range(5):
+            ref = oracle.transform_batch(x, code)
+            assert rel_l2(run_batch(plan, x, code), ref) <= tol, (n, code)
+            assert rel_l2(run_batch(plan, x, code, inplace=True), ref) <= tol, (n, code, "in place")
+    monkeypatch.setenv("FOURIER_NO_GENERIC_MIXED", "1")
+    blu = make(fa, 62208, np.complex64)
+    assert "bluestein" in blu.describe()
+    x = hash_normal(5, 62208).astype(np.complex64)[None, :]
+    assert rel_l2(run_batch(blu, x, 0), run_batch(make(fa, 62208, np.complex64), x, 0)) <= 2e-6
+
+
 def test_bluestein_fusion_matches_unfused(fa):
     """The fused Bluestein forms (whole chirp-z in one launch for M <= 2^15; chirp steps fused into the
     inner passes above) give the same values, to rounding, as the separate blu_pre / blu_post sweeps
@@ -519,6 +541,28 @@ def test_last_status_is_the_status_of_the_last_call(fa):
 
     L = _lib.lib()
     assert L.fourier_hip_last_status_float(plan._h) == 0
+    # the contract of include/fourier.h, entry point by entry point (round-2 advisor): the ones that do work reset the
+    # status on entry -- the legacy `void` transforms included, which report ONLY through this query (the Rust shim's
+    # `assert!(status == 0)` after them depends on it) -- and the pure queries leave it untouched
+    bad = lambda: L.fourier_hip_transform_batch_float(plan._h, x.ctypes.data, y.ctypes.data, 1, 9, None)  # noqa: E731
+    assert bad() != 0 and L.fourier_hip_last_status_float(plan._h) != 0
+    for query in (lambda: L.fourier_hip_size_float(plan._h), lambda: L.fourier_hip_device_float(plan._h),
+                  lambda: L.fourier_hip_describe_float(plan._h), lambda: L.fourier_hip_model_bytes_float(plan._h),
+                  lambda: L.fourier_hip_slot_names_float(plan._h), lambda: L.fourier_hip_last_status_float(plan._h)):
+        query()
+        assert L.fourier_hip_last_status_float(plan._h) != 0  # still the failed call's status
+    for work in (lambda: L.fourier_transform_float(plan._h, x.ctypes.data, y.ctypes.data, 0),
+                 lambda: L.fourier_transform_in_place_float(plan._h, y.ctypes.data, 1),
+                 lambda: L.fourier_hip_reserve_float(plan._h, 4, 1),
+                 lambda: L.fourier_hip_synchronize_float(plan._h, None),
+                 lambda: L.fourier_hip_transform_batch_host_float(plan._h, x.ctypes.data, y.ctypes.data, 1, 0)):
+        assert bad() != 0 and L.fourier_hip_last_status_float(plan._h) != 0
+        work()
+        assert L.fourier_hip_last_status_float(plan._h) == 0
+    # an unknown code through a legacy `void` entry point is a silent no-op (fourier-ffi/src/lib.rs:10) and not an error
+    y[:] = 7
+    L.fourier_transform_float(plan._h, x.ctypes.data, y.ctypes.data, 9)
+    assert L.fourier_hip_last_status_float(plan._h) == 0 and (y == 7).all()
 
 
 def test_reserve_presizes_the_scratch_so_that_calls_do_not_allocate(fa):

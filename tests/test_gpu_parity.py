@@ -504,6 +504,38 @@ def test_two_devices_driven_from_two_host_threads_in_one_process(torch, fa, orac
         pytest.skip("one GPU visible: ran both shards on cuda:0 (two plans, two threads, two streams)")
 
 
+def test_sharded_driver_orders_against_the_callers_stream_and_returns_when_done(torch, fa):
+    """DeviceShardedFft (round-2 advisor): (1) inputs produced on the CALLER's non-default stream are waited for -- the
+    worker threads look up nothing thread-local; (2) the raw (pointer, batch) form has finished when transform() returns
+    (it synchronises through fourier_hip_synchronize_*): a copy on an unrelated non-blocking stream right after must see
+    complete results.  Large enough that an unordered launch would run ahead of the producer / the copy."""
+    from fourier_amd import shard
+
+    n, per = 1 << 20, 96  # 2 x 768 MiB per shard: tens of milliseconds of kernels
+    drv = shard.DeviceShardedFft(n, "f32", [0, 0])
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ins = []
+        for g in range(2):
+            x = torch.zeros((per, n), dtype=torch.complex64, device="cuda")
+            for _ in range(4):
+                x.add_(0.25)  # the producer is still running on `side` when transform() is called
+            ins.append(x)
+        outs = [torch.full_like(x, float("nan")) for x in ins]
+        drv.transform(ins, outs, fa.Transform.Fft)  # current stream of THIS thread = side
+    for o in outs:  # a constant input: X[0] = n, everything else 0
+        assert torch.allclose(o[:, 0].real, torch.full((per,), float(n), device="cuda")) and float(o[:, 1:].abs().max()) < 1e-2
+    torch.cuda.synchronize()
+    raw_out = [torch.full_like(x, float("nan")) for x in ins]
+    drv.transform([(x.data_ptr(), per) for x in ins], [(o.data_ptr(), per) for o in raw_out], fa.Transform.Fft)
+    other = torch.cuda.Stream()  # non-blocking: no implicit ordering with the NULL stream the raw form runs on
+    with torch.cuda.stream(other):
+        copies = [o.clone() for o in raw_out]
+    other.synchronize()
+    for c, o in zip(copies, outs):
+        assert torch.equal(torch.view_as_real(c), torch.view_as_real(o))
+
+
 def test_bench_strong_scaling_path_with_two_ranks(torch, fa, tmp_path):
     """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one rank per GPU): BASELINE
     configs[4] with the global batch split over the ranks, "scaling": "strong", one JSON line from rank 0.  With two
@@ -913,3 +945,20 @@ def test_bluestein_chirp_in_pass_computes_the_chirp(torch, fa, oracle, n, dtype,
         assert rel_l2(a, ref) <= tol and rel_l2(b, ref) <= tol, (n, code, rel_l2(a, ref), rel_l2(b, ref))
         assert rel_l2(a, b) <= (4e-7 if dtype == np.complex64 else 1e-12), (n, code, rel_l2(a, b))
         assert np.array_equal(gpu_batch(torch, fa, comp, x, code, inplace=True), a), (n, code)
+
+
+@pytest.mark.parametrize("n,dtype,tol", [(59049, np.complex64, 1e-6), (62208, np.complex64, 1e-6), (39366, np.complex64, 1e-6),
+                                         (55296, np.complex64, 1e-6), (20736, np.complex64, 1e-6), (2 * 3 ** 13, np.complex64, 1e-6),
+                                         (10368, np.complex128, 5e-14), (13122, np.complex128, 5e-14), (2048 * 3 ** 9, np.complex128, 5e-14)])
+def test_mixed_radix_sizes_beyond_the_lds_limit_with_a_small_power_of_two(torch, fa, oracle, n, dtype, tol):
+    """2^a * 3^b with a < 12 above the LDS kernels' 18432 (f32) / 9216 (f64) points: the reference's Stockham pass by pass
+    in global memory (stockham_pass_kernel, radices 27 / 9 / 3 then 16 / 8 / 4 / 2) instead of Bluestein.  All five
+    codes, in and out of place, a ragged batch, against the oracle."""
+    plan = make(fa, n, dtype)
+    assert "global-pass" in plan.describe(), plan.describe()
+    batch = 5 if n < 1 << 20 else 2
+    x = np.stack([hash_normal(1900 + b, n) for b in range(batch)]).astype(dtype)
+    for code in range(5):
+        ref = oracle.transform_batch(x, code)
+        assert rel_l2(gpu_batch(torch, fa, plan, x, code), ref) <= tol, (n, code)
+        assert rel_l2(gpu_batch(torch, fa, plan, x, code, inplace=True), ref) <= tol, (n, code, "in place")
