@@ -552,7 +552,9 @@ template <typename T> class Pow2Engine {
       s *= (uint64_t)L;
       size /= (uint64_t)L;
     }
-    if (p3 == 1 && lens.size() == 2 && !mirror) init_l2fused(k);
+    // only a plan that is used as a whole transform may fuse its two passes: the inner engine of a Bluestein plan runs
+    // its passes one by one with chirp / conv fusion (and `needs_scratch` must not be switched off under it)
+    if (p3 == 1 && lens.size() == 2 && !mirror && plain) init_l2fused(k);
     // odd part 3^b as radix-27 passes plus one of radix 3 / 9 / 27: twiddled middle passes, then the final one
     // (the reference's order, radix 3 after the powers of two: RADICES = [4,8,4,3,2], autosort/mod.rs:21)
     while (p3 > 1) {

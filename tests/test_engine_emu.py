@@ -141,7 +141,7 @@ def test_mixed_radix_sizes_are_bit_identical_to_the_oracle(fa, oracle):
                 assert np.array_equal(run_batch(plan, x.astype(dtype), code, inplace=True), ref), (n, dtype, code)
     assert "mixed-radix" in make(fa, 18432, np.complex64).describe()  # one in-place LDS buffer of 144 KiB
     assert "mixed-radix" in make(fa, 9216, np.complex128).describe()
-    assert "bluestein" in make(fa, 10368, np.complex128).describe()   # f64: above the LDS-resident limit (9216)
+    assert "global-pass" in make(fa, 10368, np.complex128).describe()   # f64: above the LDS-resident limit (9216): pass by pass in global memory
     assert "x3" in make(fa, 12288, np.complex64).describe()           # 3*2^12: tiled passes + odd pass, not the LDS kernel
     for n, dtype in ((6144, np.complex64), (9216, np.complex64), (18432, np.complex64), (13122, np.complex64),
                      (4608, np.complex128), (9216, np.complex128), (6561, np.complex128)):
@@ -178,7 +178,7 @@ def test_large_mixed_radix_sizes_run_natively(fa, oracle):
                 assert rel_l2(run_batch(plan, x.astype(dtype), code, inplace=True), ref) <= tl2, (n, code)
     assert make(fa, 729 * 4096, np.complex64).describe().startswith("stockham 64x64x27x27")
     assert "mixed-radix" in make(fa, 3 * 2048, np.complex128).describe()  # too little 2^a for two tiled passes: LDS kernel
-    assert "bluestein" in make(fa, 9 * 2048, np.complex128).describe()   # f64 18432: beyond both native routes
+    assert "global-pass" in make(fa, 9 * 2048, np.complex128).describe()   # f64 18432: beyond the LDS and the tiled routes: global-memory passes
 
 
 def test_mixed_radix_sizes_beyond_the_lds_limit_with_a_small_power_of_two_run_pass_by_pass(fa, oracle, monkeypatch):
