@@ -279,7 +279,9 @@ template <typename T, int L1, int L2> static KernelInfo make_twolevel_info() {
   KernelInfo k;
   k.fn = &fft_twolevel_kernel<T, L1, L2>;
   k.L = L1; k.CG = L2 / VEC; k.NT = CA::NT; k.COLS = L2; k.R3 = 1;
-  k.smem = CA::EXCH_BYTES > CB::EXCH_BYTES ? CA::EXCH_BYTES : CB::EXCH_BYTES;
+  // the two in-tile exchanges and the transposes between them share one buffer (both role orders: the one-launch chirp-z
+  // runs the L2 x L1 problem behind the L1 x L2 one)
+  k.smem = std::max({CA::EXCH_BYTES, CB::EXCH_BYTES, TwolevelTr<T, L1, L2>::BYTES, TwolevelTr<T, L2, L1>::BYTES});
   return k;
 }
 // single-launch plans: 2^11 = 64x32 (72 % of the HBM peak vs 57 % for the row kernel), 2^12 = 64x64,

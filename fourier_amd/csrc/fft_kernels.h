@@ -1242,6 +1242,22 @@ __device__ __forceinline__ void two_stage_fft(RegTile<T, L, CG>& x, int th, int 
     }
 }
 
+// LDS layout of the in-workgroup transpose between the two passes of a one-launch plan: element (row i of the L2 x L1
+// matrix, column k1) lives in unit (k1 / VEC) * (L2 + 1) + pi(i), pi(i) = i / VEC + (i % VEC) * (L2 / VEC) -- column-group
+// major, one unit of padding per column group, rows de-interleaved by parity.  A writer's lanes walk the rows i = cg*VEC + v
+// at a fixed k1 and v: adjacent units after pi (2-way on ds_write_b32 = free; row-major, or column-group-major without
+// pi, put them on 8 of the 32 banks: 4-way, SQ_LDS_BANK_CONFLICT = 40 % of the LDS cycles of the 2^14 / 2^15 kernels in
+// profiles/r03_s15_sq_breakdown.json).  A reader's lanes walk the column groups at a fixed row: stride L2 + 1 units, an
+// odd number of 8-byte bank pairs, conflict-free for ds_read_b64 / b128.
+template <int L2, int VEC> __device__ __forceinline__ constexpr int twolevel_tr_unit(int row, int colgroup) {
+  return colgroup * (L2 + 1) + row / VEC + (row % VEC) * (L2 / VEC);
+}
+template <typename T, int L1, int L2> struct TwolevelTr {
+  static constexpr int VEC = 16 / (2 * (int)sizeof(T));
+  static constexpr bool SPLIT = TileCfg<T, L2, L1 / VEC>::SPLIT;
+  static constexpr size_t BYTES = (size_t)(L1 / VEC) * (L2 + 1) * (SPLIT ? 8 : 16);
+};
+
 #ifndef FOURIER_TWOLEVEL_TW_BATCH
 #define FOURIER_TWOLEVEL_TW_BATCH(NT) ((NT) <= 128 ? 4 : 8)  // loads of the inter-pass twiddle table in flight per thread (2-wave workgroups live on occupancy: stay under 128 VGPRs)
 #endif
@@ -1289,7 +1305,7 @@ __device__ __forceinline__ void twolevel_core(cpx<T> (*x)[16], int tid, unsigned
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int k1 = th + Q1 * r;
-          const int unit = CB::template unit_index<0>(i, k1 / VEC);
+          const int unit = twolevel_tr_unit<L2, VEC>(i, k1 / VEC);
           if constexpr (SPLIT) {
             T* p = (T*)(smem + (size_t)unit * 8) + (k1 % VEC);
             LDS_NOTE(p, sizeof(T), true, site + 8 + plane);
@@ -1304,7 +1320,7 @@ __device__ __forceinline__ void twolevel_core(cpx<T> (*x)[16], int tid, unsigned
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int unit = CB::template unit_index<0>(th2 + Q2 * r, cg2);
+        const int unit = twolevel_tr_unit<L2, VEC>(th2 + Q2 * r, cg2);
         if constexpr (SPLIT) {
           const Unit8<T>* p = (const Unit8<T>*)smem + unit;
           LDS_NOTE(p, 8, false, site + 10 + plane);
