@@ -962,3 +962,42 @@ def test_mixed_radix_sizes_beyond_the_lds_limit_with_a_small_power_of_two(torch,
         ref = oracle.transform_batch(x, code)
         assert rel_l2(gpu_batch(torch, fa, plan, x, code), ref) <= tol, (n, code)
         assert rel_l2(gpu_batch(torch, fa, plan, x, code, inplace=True), ref) <= tol, (n, code, "in place")
+
+
+@pytest.mark.parametrize("dtype,log2n", [(np.complex64, 29), (np.complex128, 28)])
+def test_a_single_transform_of_4_gib_addresses_correctly(torch, fa, dtype, log2n):
+    """One transform of 4 GiB (f32 2^29, f64 2^28; three passes): every byte offset beyond 32 bits.  The column-tile
+    accesses go through buffer descriptors whose 64-bit base carries the row and whose lane offset stays below
+    n * sizeof(complex) / 16 (fft_kernels.h, pass_tile), so no size limit applies -- checked with a known answer: two
+    complex tones give two spectral lines (N and N/2 high) and nothing else, in and out of place, forward and back."""
+    n = 1 << log2n
+    cdt = torch.complex64 if dtype == np.complex64 else torch.complex128
+    rdt = torch.float32 if dtype == np.complex64 else torch.float64
+    f1, f2 = 123456789 % n, n - 7
+    x = torch.empty(n, dtype=cdt, device="cuda")
+    xr = torch.view_as_real(x)
+    step = 1 << 24
+    for lo in range(0, n, step):  # exact phases: (f * k mod n) / n in f64
+        k = torch.arange(lo, lo + step, device="cuda", dtype=torch.int64)
+        p1 = ((k * f1) % n).double() * (2.0 * np.pi / n)
+        p2 = ((k * f2) % n).double() * (2.0 * np.pi / n)
+        xr[lo:lo + step, 0] = (torch.cos(p1) + 0.5 * torch.cos(p2)).to(rdt)
+        xr[lo:lo + step, 1] = (torch.sin(p1) + 0.5 * torch.sin(p2)).to(rdt)
+    del k, p1, p2
+    plan = make(fa, n, dtype)
+    assert plan.describe().count("x") == 2, plan.describe()  # three passes
+    y = torch.empty_like(x)
+    plan.transform(x.view(1, n), y.view(1, n), fa.Transform.Fft)
+    torch.cuda.synchronize()
+    eps = 2e-5 if dtype == np.complex64 else 1e-11
+    for out in (y,):
+        mag = out.abs()
+        assert abs(float(mag[f1]) / n - 1.0) < eps and abs(float(mag[f2]) / n - 0.5) < eps
+        mag[f1] = 0
+        mag[f2] = 0
+        assert float(mag.max()) / n < eps, float(mag.max()) / n
+        del mag
+    plan.transform(y.view(1, n), y.view(1, n), fa.Transform.Ifft)  # in place (through the plan's scratch), back to the tones
+    torch.cuda.synchronize()
+    err = float((torch.view_as_real(y) - xr).abs().max())
+    assert err < (2e-5 if dtype == np.complex64 else 1e-12), err
