@@ -2,14 +2,13 @@
 //
 // Purpose: this build container has no GPU.  Compiling fourier_amd/csrc/engine.cpp with
 // `g++ -DFOURIER_EMU -include tests/emu/hipemu.h` runs the *same* kernel source on the CPU
-// (one ucontext fiber per GPU thread, __syncthreads() = yield), so kernel index arithmetic,
+// (one fiber per GPU thread, __syncthreads() = yield), so kernel index arithmetic,
 // plan logic and the C-ABI are checked before any GPU minute is spent.  It also counts LDS
 // bank conflicts (see lds_trace below).
 //
 // This is NOT a product path and NOT a fallback: it lives under tests/, is built only by
 // tests/emu/build_emu.py, and the product package (fourier_amd) never loads it.
 #pragma once
-#include <ucontext.h>
 
 #include <algorithm>
 #include <atomic>
@@ -49,8 +48,8 @@ struct Tls {
   dim3 tid, bid, bdim, gdim;
   unsigned char* smem = nullptr;
   int* shfl = nullptr;  // one slot per thread of the block: cross-lane shuffles
-  ucontext_t* sched = nullptr;
-  ucontext_t* self = nullptr;
+  void** sched = nullptr;  // where the scheduler's stack pointer is parked while a fiber runs
+  void** self = nullptr;   // where the running fiber's stack pointer is parked while it waits
 };
 inline Tls& tls() {
   static thread_local Tls t;
@@ -112,21 +111,85 @@ inline unsigned lds_cost(const uint32_t* addr, int nl, unsigned bytes, bool is_w
 
 inline unsigned char* smem() { return tls().smem; }
 
+// Fiber switch without a system call (swapcontext saves and restores the signal mask: two rt_sigprocmask calls per
+// switch, and a barrier of a 1024-thread block is 1024 switches -- the CPU test suite spent more time in the kernel than
+// in the emulated kernels).  x86-64 System V: the callee-saved registers and the stack pointer are the whole context.
+#if !defined(__x86_64__)
+#error "tests/emu/hipemu.h: the fiber switch is written for x86-64"
+#endif
+extern "C" {
+__attribute__((naked, noinline, used)) static void hipemu_switch(void** /*save_sp: rdi*/, void* /*load_sp: rsi*/) {
+  asm volatile(
+      "pushq %rbp\n\tpushq %rbx\n\tpushq %r12\n\tpushq %r13\n\tpushq %r14\n\tpushq %r15\n\t"
+      "movq %rsp, (%rdi)\n\t"
+      "movq %rsi, %rsp\n\t"
+      "popq %r15\n\tpopq %r14\n\tpopq %r13\n\tpopq %r12\n\tpopq %rbx\n\tpopq %rbp\n\t"
+      "ret\n\t");
+}
+}
+
 inline void syncthreads() {
   Tls& t = tls();
-  swapcontext(t.self, t.sched);
+  hipemu_switch(t.self, *t.sched);
 }
 
 struct FiberArg {
   std::function<void()>* body;
   bool done;
 };
-inline void fiber_entry(unsigned lo, unsigned hi) {
-  FiberArg* fa = (FiberArg*)(((uintptr_t)hi << 32) | lo);
+extern "C" {
+__attribute__((noinline, used)) static void hipemu_fiber_main(FiberArg* fa) {
   (*fa->body)();
   fa->done = true;
-  Tls& t = tls();
-  swapcontext(t.self, t.sched);
+  for (;;) {  // a finished fiber is never resumed; park it
+    Tls& t = tls();
+    hipemu_switch(t.self, *t.sched);
+  }
+}
+// first activation of a fiber: hipemu_switch "returns" here with the FiberArg in r12 (see fiber_prepare)
+__attribute__((naked, noinline, used)) static void hipemu_trampoline() {
+  asm volatile("movq %r12, %rdi\n\tcallq hipemu_fiber_main\n\tud2\n\t");
+}
+}
+// lay out a fresh stack so that the first hipemu_switch into it pops the callee-saved registers (r12 = the argument) and
+// returns into the trampoline with a 16-byte aligned stack pointer
+// Fiber stacks come from a pool that outlives the launches: a value-initialised vector of nthreads * 128 KiB per worker
+// and launch was a 128 MiB memset (and as many page faults) each time.
+struct StackPool {
+  static std::mutex& mu() { static std::mutex m; return m; }
+  static std::vector<std::pair<unsigned char*, size_t>>& free_list() { static std::vector<std::pair<unsigned char*, size_t>> v; return v; }
+  struct Lease {
+    unsigned char* p = nullptr;
+    size_t bytes = 0;
+    explicit Lease(size_t need) {
+      {
+        std::lock_guard<std::mutex> g(mu());
+        auto& fl = free_list();
+        for (size_t i = 0; i < fl.size(); ++i)
+          if (fl[i].second >= need) { p = fl[i].first; bytes = fl[i].second; fl.erase(fl.begin() + (long)i); break; }
+      }
+      if (!p) { p = (unsigned char*)malloc(need); bytes = need; }
+      if (!p) { fprintf(stderr, "hipemu: out of memory for fiber stacks\n"); abort(); }
+    }
+    ~Lease() {
+      std::lock_guard<std::mutex> g(mu());
+      free_list().push_back({p, bytes});
+    }
+    unsigned char* data() const { return p; }
+  };
+};
+
+inline void* fiber_prepare(unsigned char* stack, size_t bytes, FiberArg* fa) {
+  uintptr_t top = ((uintptr_t)(stack + bytes)) & ~(uintptr_t)15;
+  void** sp = (void**)(top - 16 - 56);
+  sp[0] = nullptr;                       // r15
+  sp[1] = nullptr;                       // r14
+  sp[2] = nullptr;                       // r13
+  sp[3] = (void*)fa;                     // r12
+  sp[4] = nullptr;                       // rbx
+  sp[5] = nullptr;                       // rbp
+  sp[6] = (void*)&hipemu_trampoline;     // return address
+  return (void*)sp;
 }
 
 template <typename K, typename A>
@@ -139,14 +202,14 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, K kernel, A arg) {
   std::atomic<unsigned> next{0};
   auto worker = [&]() {
     const size_t STACK = 128 * 1024;
-    std::vector<unsigned char> stacks((size_t)nthreads * STACK);
-    std::vector<ucontext_t> ctx(nthreads);
+    StackPool::Lease stacks((size_t)nthreads * STACK);  // reused across launches: no zeroing, no fresh page faults
+    std::vector<void*> ctx(nthreads);  // parked stack pointers of the fibers
     std::vector<FiberArg> fargs(nthreads);
     std::vector<unsigned char> smem_buf(smem_bytes + 64);
     std::vector<int> shfl_buf(nthreads);
     std::vector<size_t> log_mark(nthreads);
     std::vector<std::vector<LdsAccess>> tlog(nthreads);
-    ucontext_t sched;
+    void* sched = nullptr;             // parked stack pointer of this scheduler
     std::function<void()> body = [&]() { kernel(arg); };
     for (;;) {
       unsigned b = next.fetch_add(1);
@@ -159,13 +222,8 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, K kernel, A arg) {
       t.sched = &sched;
       std::memset(smem_buf.data(), 0xCD, smem_buf.size());  // poison: catches reads of unwritten LDS
       for (unsigned i = 0; i < nthreads; ++i) {
-        getcontext(&ctx[i]);
-        ctx[i].uc_stack.ss_sp = stacks.data() + (size_t)i * STACK;
-        ctx[i].uc_stack.ss_size = STACK;
-        ctx[i].uc_link = nullptr;
         fargs[i] = {&body, false};
-        uintptr_t p = (uintptr_t)&fargs[i];
-        makecontext(&ctx[i], (void (*)())fiber_entry, 2, (unsigned)(p & 0xffffffffu), (unsigned)(p >> 32));
+        ctx[i] = fiber_prepare(stacks.data() + (size_t)i * STACK, STACK, &fargs[i]);
       }
       unsigned remaining = nthreads;
       while (remaining) {
@@ -175,7 +233,7 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, K kernel, A arg) {
           t.tid = dim3(i % block.x, (i / block.x) % block.y, i / (block.x * block.y));
           t.self = &ctx[i];
           if (lds_trace_on()) lds_log().clear();
-          swapcontext(&sched, &ctx[i]);
+          hipemu_switch(&sched, ctx[i]);
           if (lds_trace_on()) tlog[i] = lds_log();
           ++ran;
           if (fargs[i].done) ++finished;
