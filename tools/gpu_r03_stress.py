@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Round 3 one-off stress: every 2^a*3^b up to 6e6 (LDS, global-pass and tiled routes), random other sizes, random codes,
+in and out of place, f32 and f64, against the oracle.  Prints one line per failure and a summary."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import fourier_amd as fa
+from oracle import oracle as O
+
+O.build()
+rng = np.random.default_rng(int(os.environ.get("STRESS_SEED", "12345")))
+smooth = sorted({(2 ** a) * (3 ** b) for a in range(0, 23) for b in range(0, 15) if (2 ** a) * (3 ** b) <= 6_000_000})
+others = sorted({int(v) for v in np.concatenate([rng.integers(2, 5000, 150), rng.integers(5000, 200000, 80), rng.integers(200000, 3000000, 25)])})
+worst = {}
+fails = 0
+t0 = time.time()
+count = 0
+for n in smooth + others:
+    for dtype, tol in ((np.complex64, 2e-6), (np.complex128, 1e-9 if n > 100000 else 5e-11)):
+        if dtype == np.complex128 and rng.random() < 0.5:
+            continue
+        batch = int(rng.integers(1, 4)) if n > 4096 else int(rng.integers(1, 70))
+        x = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(dtype)
+        code = int(rng.integers(0, 5))
+        inplace = bool(rng.integers(0, 2))
+        plan = fa.create_fft_f32(n) if dtype == np.complex64 else fa.create_fft_f64(n)
+        d = torch.from_numpy(x).cuda()
+        o = d if inplace else torch.empty_like(d)
+        plan.transform(d, o, fa.Transform(code))
+        torch.cuda.synchronize()
+        got = o.cpu().numpy()
+        ref = O.transform_batch(x, code)
+        err = float(np.linalg.norm(got.astype(np.complex128) - ref) / max(np.linalg.norm(ref), 1e-300))
+        fam = plan.describe().split()[0] + " " + plan.describe().split()[1][:12]
+        worst[(fam, dtype.__name__)] = max(worst.get((fam, dtype.__name__), 0.0), err)
+        count += 1
+        if not (err <= tol):
+            fails += 1
+            print(json.dumps(dict(FAIL=True, n=n, dtype=dtype.__name__, batch=batch, code=code, inplace=inplace, plan=plan.describe(), rel_l2=err)), flush=True)
+        del plan, d, o
+print(json.dumps(dict(cases=count, failures=fails, seconds=round(time.time() - t0, 1), worst_rel_l2_by_family={f"{k[0]} {k[1]}": v for k, v in sorted(worst.items())})))
