@@ -944,28 +944,98 @@ template <typename T> class Pow2Engine {
 };
 
 // ---------------------------------------------------------------------------------------------
-// small mixed-radix sizes (2^a * 3^b, b > 0, N <= 4096): the reference's own schedule and tables
+// small mixed-radix sizes in LDS: 2^a * 3^b (b > 0) on the reference's own schedule and tables; lengths with factors 5..13 on the same pass
 template <typename T> class MixedEngine {
  public:
-  // both LDS ping-pong buffers of one transform must fit a workgroup: 2 * N * sizeof(complex) <= 144 KiB
-  // one LDS buffer of one transform must fit a workgroup (the per-length kernels run their passes in place):
-  // N * sizeof(complex) <= 144 KiB
+  // one LDS buffer of one transform must fit a workgroup (the passes run in place): N * sizeof(complex) <= 144 KiB
   static constexpr size_t MAX_N = (144 * 1024) / sizeof(cpx<T>);  // 18432 (f32), 9216 (f64)
-  // autosort/mod.rs:104-116: one radix-4 first when divisible, then greedily 8, 4, 3, 2
-  static bool factor(size_t size, uint32_t counts[5]) {
-    static const size_t radices[5] = {4, 8, 4, 3, 2};
-    size_t cur = size;
-    for (int r = 0; r < 5; ++r) counts[r] = 0;
-    if (cur == 0) return false;
-    if (cur % 4 == 0) { cur /= 4; counts[0] = 1; }
-    for (int r = 1; r < 5; ++r)
-      while (cur % radices[r] == 0) { cur /= radices[r]; counts[r] += 1; }
-    return cur == 1;
+  // autosort/mod.rs:104-116: one radix-4 first when divisible, then greedily 8, 4, 3, 2 -- and, beyond the reference (which
+  // sends such lengths to Bluestein, fourier/src/lib.rs:38-42), the same pass with prime radices 5, 7, 11, 13
+  static bool factor(size_t size, std::vector<uint32_t>& radices) {
+    radices.clear();
+    if (size == 0 || size > MAX_N) return false;
+    for (size_t cur = size; cur > 1;) {
+      const uint32_t r = mix_next_radix((uint32_t)size, (uint32_t)cur, cur == size);  // the kernels' own schedule
+      if (cur % r) return false;
+      radices.push_back(r);
+      cur /= r;
+    }
+    return true;
+  }
+  struct Kernel { void (*fn)(MixArgs); uint32_t group; size_t nbuf; uint32_t threads; };
+  // the per-length kernel where one is instantiated (every 2^a*3^b up to MAX_N, and the common lengths with factors
+  // 5 / 7), else the runtime-parameterised kernel
+  static Kernel pick_kernel(size_t n) {
+    // runtime-parameterised: about 1024 points per workgroup up to 1024 points, then one transform per workgroup -- 256 threads
+    // x 4 / 8 points up to 2048 points, 512 x 8 up to 4096, 1024 x 8 up to 8192 (1024 x 4 for 2049..4096 measured slower than
+    // 256 x 16: 3125 f32 19 % against 24 %, r03_s22)
+    Kernel k{nullptr, (uint32_t)std::max<size_t>(1, 1024 / n), 1, 256};
+    const int maxp = (n % 11 == 0 || n % 13 == 0) ? 13 : ((n % 5 == 0 || n % 7 == 0) ? 7 : 3);
+    const size_t pts = k.group * n;
+#define FOURIER_MIX_RT(P, NT) (maxp == 13 ? &mixed_radix_kernel<T, 13, P, NT> : (maxp == 7 ? &mixed_radix_kernel<T, 7, P, NT> : &mixed_radix_kernel<T, 3, P, NT>))
+    if (pts <= 1024) k.fn = FOURIER_MIX_RT(4, 256);
+    else if (pts <= 2048) k.fn = FOURIER_MIX_RT(8, 256);
+    else if (sizeof(T) == 8 && maxp == 13) {}  // f64 with a radix-13 butterfly does not fit 128 registers (spills; 4095 f64: 20 % against Bluestein's 25 %)
+    else if (pts <= 4096) { k.fn = FOURIER_MIX_RT(8, 512); k.threads = 512; }
+    else if (pts <= 8192) { k.fn = FOURIER_MIX_RT(8, 1024); k.threads = 1024; }
+#undef FOURIER_MIX_RT
+    if (dev_env("FOURIER_MIX_GENERIC") && k.fn) return k;
+#define FOURIER_MIX_CT(NN)                                                      \
+  case NN:                                                                      \
+    if constexpr ((size_t)NN <= MAX_N) k = Kernel{&mixed_radix_kernel_ct<T, NN>, mix_group<T>(NN), mix_inplace<T>(NN) ? (size_t)1 : (size_t)2, mix_threads<T>(NN)}; \
+    break;
+    switch (n) {  // every 2^a * 3^b (b >= 1) the engine runs in LDS: 3 ... 18432 (f32) / 9216 (f64)
+      FOURIER_MIX_CT(3) FOURIER_MIX_CT(6) FOURIER_MIX_CT(9) FOURIER_MIX_CT(12) FOURIER_MIX_CT(18) FOURIER_MIX_CT(24)
+      FOURIER_MIX_CT(27) FOURIER_MIX_CT(36) FOURIER_MIX_CT(48) FOURIER_MIX_CT(54) FOURIER_MIX_CT(72) FOURIER_MIX_CT(81)
+      FOURIER_MIX_CT(96) FOURIER_MIX_CT(108) FOURIER_MIX_CT(144) FOURIER_MIX_CT(162) FOURIER_MIX_CT(192) FOURIER_MIX_CT(216)
+      FOURIER_MIX_CT(243) FOURIER_MIX_CT(288) FOURIER_MIX_CT(324) FOURIER_MIX_CT(384) FOURIER_MIX_CT(432) FOURIER_MIX_CT(486)
+      FOURIER_MIX_CT(576) FOURIER_MIX_CT(648) FOURIER_MIX_CT(729) FOURIER_MIX_CT(768) FOURIER_MIX_CT(864) FOURIER_MIX_CT(972)
+      FOURIER_MIX_CT(1152) FOURIER_MIX_CT(1296) FOURIER_MIX_CT(1458) FOURIER_MIX_CT(1536) FOURIER_MIX_CT(1728) FOURIER_MIX_CT(1944)
+      FOURIER_MIX_CT(2187) FOURIER_MIX_CT(2304) FOURIER_MIX_CT(2592) FOURIER_MIX_CT(2916) FOURIER_MIX_CT(3072) FOURIER_MIX_CT(3456)
+      FOURIER_MIX_CT(3888) FOURIER_MIX_CT(4374) FOURIER_MIX_CT(4608) FOURIER_MIX_CT(5184) FOURIER_MIX_CT(5832) FOURIER_MIX_CT(6144)
+      FOURIER_MIX_CT(6561) FOURIER_MIX_CT(6912) FOURIER_MIX_CT(7776) FOURIER_MIX_CT(8748) FOURIER_MIX_CT(9216) FOURIER_MIX_CT(10368)
+      FOURIER_MIX_CT(11664) FOURIER_MIX_CT(13122) FOURIER_MIX_CT(13824) FOURIER_MIX_CT(15552) FOURIER_MIX_CT(17496)
+      FOURIER_MIX_CT(18432)
+      // beyond the reference: every 2^a * 3^b * 5^c (c >= 1) up to MAX_N -- among them the reference's own benchmark lengths
+      // 5^3 .. 5^5 (fft_bench.rs:156) -- and the powers of 7; other lengths with factors 7, 11, 13 take the runtime kernel
+      FOURIER_MIX_CT(10) FOURIER_MIX_CT(25) FOURIER_MIX_CT(100) FOURIER_MIX_CT(125) FOURIER_MIX_CT(625) FOURIER_MIX_CT(1000)
+      FOURIER_MIX_CT(3125) FOURIER_MIX_CT(5000) FOURIER_MIX_CT(8000) FOURIER_MIX_CT(10000) FOURIER_MIX_CT(15625) FOURIER_MIX_CT(49) FOURIER_MIX_CT(343) FOURIER_MIX_CT(16807)
+#ifndef FOURIER_EMU  // the CPU emulation build keeps the subset above (compile time); its other lengths run the runtime kernel
+      FOURIER_MIX_CT(5) FOURIER_MIX_CT(15) FOURIER_MIX_CT(20) FOURIER_MIX_CT(30) FOURIER_MIX_CT(40) FOURIER_MIX_CT(45)
+      FOURIER_MIX_CT(50) FOURIER_MIX_CT(60) FOURIER_MIX_CT(75) FOURIER_MIX_CT(80) FOURIER_MIX_CT(90) FOURIER_MIX_CT(120)
+      FOURIER_MIX_CT(135) FOURIER_MIX_CT(150) FOURIER_MIX_CT(160) FOURIER_MIX_CT(180) FOURIER_MIX_CT(200) FOURIER_MIX_CT(225)
+      FOURIER_MIX_CT(240) FOURIER_MIX_CT(250) FOURIER_MIX_CT(270) FOURIER_MIX_CT(300) FOURIER_MIX_CT(320) FOURIER_MIX_CT(360)
+      FOURIER_MIX_CT(375) FOURIER_MIX_CT(400) FOURIER_MIX_CT(405) FOURIER_MIX_CT(450) FOURIER_MIX_CT(480) FOURIER_MIX_CT(500)
+      FOURIER_MIX_CT(540) FOURIER_MIX_CT(600) FOURIER_MIX_CT(640) FOURIER_MIX_CT(675) FOURIER_MIX_CT(720) FOURIER_MIX_CT(750)
+      FOURIER_MIX_CT(800) FOURIER_MIX_CT(810) FOURIER_MIX_CT(900) FOURIER_MIX_CT(960) FOURIER_MIX_CT(1080) FOURIER_MIX_CT(1125)
+      FOURIER_MIX_CT(1200) FOURIER_MIX_CT(1215) FOURIER_MIX_CT(1250) FOURIER_MIX_CT(1280) FOURIER_MIX_CT(1350)
+      FOURIER_MIX_CT(1440) FOURIER_MIX_CT(1500) FOURIER_MIX_CT(1600) FOURIER_MIX_CT(1620) FOURIER_MIX_CT(1800)
+      FOURIER_MIX_CT(1875) FOURIER_MIX_CT(1920) FOURIER_MIX_CT(2000) FOURIER_MIX_CT(2025) FOURIER_MIX_CT(2160)
+      FOURIER_MIX_CT(2250) FOURIER_MIX_CT(2400) FOURIER_MIX_CT(2430) FOURIER_MIX_CT(2500) FOURIER_MIX_CT(2560)
+      FOURIER_MIX_CT(2700) FOURIER_MIX_CT(2880) FOURIER_MIX_CT(3000) FOURIER_MIX_CT(3200) FOURIER_MIX_CT(3240)
+      FOURIER_MIX_CT(3375) FOURIER_MIX_CT(3600) FOURIER_MIX_CT(3645) FOURIER_MIX_CT(3750) FOURIER_MIX_CT(3840)
+      FOURIER_MIX_CT(4000) FOURIER_MIX_CT(4050) FOURIER_MIX_CT(4320) FOURIER_MIX_CT(4500) FOURIER_MIX_CT(4800)
+      FOURIER_MIX_CT(4860) FOURIER_MIX_CT(5120) FOURIER_MIX_CT(5400) FOURIER_MIX_CT(5625) FOURIER_MIX_CT(5760)
+      FOURIER_MIX_CT(6000) FOURIER_MIX_CT(6075) FOURIER_MIX_CT(6250) FOURIER_MIX_CT(6400) FOURIER_MIX_CT(6480)
+      FOURIER_MIX_CT(6750) FOURIER_MIX_CT(7200) FOURIER_MIX_CT(7290) FOURIER_MIX_CT(7500) FOURIER_MIX_CT(7680)
+      FOURIER_MIX_CT(8100) FOURIER_MIX_CT(8640) FOURIER_MIX_CT(9000) FOURIER_MIX_CT(9375) FOURIER_MIX_CT(9600)
+      FOURIER_MIX_CT(9720) FOURIER_MIX_CT(10125) FOURIER_MIX_CT(10240) FOURIER_MIX_CT(10800) FOURIER_MIX_CT(10935)
+      FOURIER_MIX_CT(11250) FOURIER_MIX_CT(11520) FOURIER_MIX_CT(12000) FOURIER_MIX_CT(12150) FOURIER_MIX_CT(12500)
+      FOURIER_MIX_CT(12800) FOURIER_MIX_CT(12960) FOURIER_MIX_CT(13500) FOURIER_MIX_CT(14400) FOURIER_MIX_CT(14580)
+      FOURIER_MIX_CT(15000) FOURIER_MIX_CT(15360) FOURIER_MIX_CT(16000) FOURIER_MIX_CT(16200) FOURIER_MIX_CT(16875)
+      FOURIER_MIX_CT(17280) FOURIER_MIX_CT(18000) FOURIER_MIX_CT(18225) FOURIER_MIX_CT(2401)
+#endif
+      default: break;
+    }
+#undef FOURIER_MIX_CT
+    return k;
   }
   static bool handles(size_t n) {
-    uint32_t c[5];
+    std::vector<uint32_t> c;
     const char* cap = dev_env("FOURIER_MIX_MAX_N");  // development switch: A/B against the Bluestein / odd-pass routes
-    return n <= (cap ? std::min<size_t>(MAX_N, (size_t)atoll(cap)) : MAX_N) && !is_pow2(n) && factor(n, c);
+    if (n > (cap ? std::min<size_t>(MAX_N, (size_t)atoll(cap)) : MAX_N) || is_pow2(n) || !factor(n, c)) return false;
+    if (dev_env("FOURIER_MIX_REFERENCE_RADICES") && mix_extended((uint32_t)n)) return false;  // A/B against Bluestein
+    return pick_kernel(n).fn != nullptr;  // no per-length kernel and beyond the runtime kernel's 8192 points: Bluestein
   }
   // twiddle.rs:7-19 verbatim: theta = (index*2) as f64 * PI / size as f64; (cos, -sin) cast to T.
   // cos and sin stay two separate libm calls, as in Rust (a merged sincos() differs in the last bit).
@@ -977,55 +1047,30 @@ template <typename T> class MixedEngine {
   }
 
   explicit MixedEngine(size_t n) : n_(n) {
-    factor(n, counts_);
-    static const size_t radices[5] = {4, 8, 4, 3, 2};
+    factor(n, radices_);
     std::vector<cpx<T>> tw;
     size_t cur = n;
-    for (int r = 0; r < 5; ++r)
-      for (uint32_t c = 0; c < counts_[r]; ++c) {  // mod.rs:24-46
-        const size_t R = radices[r], m = cur / R;
-        for (size_t i = 0; i < m; ++i) {
-          tw.push_back({(T)1, (T)0});
-          for (size_t j = 1; j < R; ++j) tw.push_back(ref_twiddle(i * j, cur));
-        }
-        cur /= R;
+    for (const size_t R : radices_) {  // mod.rs:24-46
+      const size_t m = cur / R;
+      for (size_t i = 0; i < m; ++i) {
+        tw.push_back({(T)1, (T)0});
+        for (size_t j = 1; j < R; ++j) tw.push_back(ref_twiddle(i * j, cur));
       }
+      cur /= R;
+    }
     if (tw.empty()) tw.push_back({(T)1, (T)0});
     tw_.upload(tw);
     // transforms per workgroup: about 1024 points (16 KiB of LDS in f32: several workgroups per CU; larger groups that
     // fill the 256 threads better lose more in occupancy than they gain, r01 session 9)
-    group_ = (uint32_t)std::max<size_t>(1, 1024 / n);
-    fn_ = &mixed_radix_kernel<T>;
-    if (!dev_env("FOURIER_MIX_GENERIC")) {  // lengths with a compile-time specialisation (same arithmetic, constant index math)
-#define FOURIER_MIX_CT(NN)                                                      \
-  case NN:                                                                      \
-    if constexpr ((size_t)NN <= MAX_N) { fn_ = &mixed_radix_kernel_ct<T, NN>; group_ = mix_group<T>(NN); nbuf_ = mix_inplace<T>(NN) ? 1 : 2; } \
-    break;
-      switch (n) {  // every 2^a * 3^b (b >= 1) the engine runs in LDS: 3 ... 18432 (f32) / 9216 (f64)
-        FOURIER_MIX_CT(3) FOURIER_MIX_CT(6) FOURIER_MIX_CT(9) FOURIER_MIX_CT(12) FOURIER_MIX_CT(18) FOURIER_MIX_CT(24)
-        FOURIER_MIX_CT(27) FOURIER_MIX_CT(36) FOURIER_MIX_CT(48) FOURIER_MIX_CT(54) FOURIER_MIX_CT(72) FOURIER_MIX_CT(81)
-        FOURIER_MIX_CT(96) FOURIER_MIX_CT(108) FOURIER_MIX_CT(144) FOURIER_MIX_CT(162) FOURIER_MIX_CT(192) FOURIER_MIX_CT(216)
-        FOURIER_MIX_CT(243) FOURIER_MIX_CT(288) FOURIER_MIX_CT(324) FOURIER_MIX_CT(384) FOURIER_MIX_CT(432) FOURIER_MIX_CT(486)
-        FOURIER_MIX_CT(576) FOURIER_MIX_CT(648) FOURIER_MIX_CT(729) FOURIER_MIX_CT(768) FOURIER_MIX_CT(864) FOURIER_MIX_CT(972)
-        FOURIER_MIX_CT(1152) FOURIER_MIX_CT(1296) FOURIER_MIX_CT(1458) FOURIER_MIX_CT(1536) FOURIER_MIX_CT(1728) FOURIER_MIX_CT(1944)
-        FOURIER_MIX_CT(2187) FOURIER_MIX_CT(2304) FOURIER_MIX_CT(2592) FOURIER_MIX_CT(2916) FOURIER_MIX_CT(3072) FOURIER_MIX_CT(3456)
-        FOURIER_MIX_CT(3888) FOURIER_MIX_CT(4374) FOURIER_MIX_CT(4608) FOURIER_MIX_CT(5184) FOURIER_MIX_CT(5832) FOURIER_MIX_CT(6144)
-        FOURIER_MIX_CT(6561) FOURIER_MIX_CT(6912) FOURIER_MIX_CT(7776) FOURIER_MIX_CT(8748) FOURIER_MIX_CT(9216) FOURIER_MIX_CT(10368)
-        FOURIER_MIX_CT(11664) FOURIER_MIX_CT(13122) FOURIER_MIX_CT(13824) FOURIER_MIX_CT(15552) FOURIER_MIX_CT(17496)
-        FOURIER_MIX_CT(18432)
-        default: break;
-      }
-#undef FOURIER_MIX_CT
-    }
+    const Kernel k = pick_kernel(n);
+    fn_ = k.fn; group_ = k.group; nbuf_ = k.nbuf; threads_ = k.threads;
     smem_ = nbuf_ * (size_t)group_ * n * sizeof(cpx<T>);
     if (smem_ > 144 * 1024) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "mixed-radix length needs the per-length kernel");
     raise_smem_limit((const void*)fn_, smem_);
   }
   std::string describe() const {
-    static const int radices[5] = {4, 8, 4, 3, 2};
     std::string d;
-    for (int r = 0; r < 5; ++r)
-      for (uint32_t c = 0; c < counts_[r]; ++c) d += (d.empty() ? "" : ".") + std::to_string(radices[r]);
+    for (const uint32_t r : radices_) d += (d.empty() ? "" : ".") + std::to_string(r);
     return d;
   }
   void run(const cpx<T>* in, cpx<T>* out, size_t batch, bool forward, bool scaled, double scale, hipStream_t stream,
@@ -1034,22 +1079,24 @@ template <typename T> class MixedEngine {
     MixArgs a;
     std::memset(&a, 0, sizeof(a));
     a.in = in; a.out = out; a.tw = tw_.p; a.batch = batch; a.n = (uint32_t)n_; a.group = group_;
-    for (int r = 0; r < 5; ++r) a.counts[r] = counts_[r];
+    a.npass = (uint32_t)radices_.size();
+    for (size_t r = 0; r < radices_.size(); ++r) a.radix[r] = (uint8_t)radices_[r];
     a.forward = forward; a.scaled = scaled; a.scale = scale;
     const cpx<T> w3 = ref_twiddle(1, 3), w8 = ref_twiddle(1, 8);  // butterfly.rs:12,50
     a.w3re = w3.re; a.w3im = w3.im; a.w8re = w8.re; a.w8im = w8.im;
     const uint64_t grid = (batch + group_ - 1) / group_;
     if (grid > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");
     PROF_BEGIN(prof, 0);
-    FOURIER_LAUNCH(fn_, grid, 256, smem_, stream, a);
+    FOURIER_LAUNCH(fn_, grid, threads_, smem_, stream, a);
     PROF_END(prof);
   }
 
  private:
   size_t n_;
-  uint32_t counts_[5];
+  std::vector<uint32_t> radices_;
+  uint32_t threads_ = 256;
   void (*fn_)(MixArgs) = nullptr;
-  size_t nbuf_ = 2;  // LDS buffers of `group_` transforms: 2 = ping-pong, 1 = in-place passes
+  size_t nbuf_ = 1;  // LDS buffers of `group_` transforms: 1 = in-place passes (2 = ping-pong, FOURIER_MIX_INPLACE_BYTES builds)
   uint32_t group_ = 1;
   size_t smem_ = 0;
   DevBuf tw_;

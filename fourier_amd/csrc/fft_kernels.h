@@ -24,7 +24,7 @@
 //   bluestein_small_kernel / bluestein_rows_kernel   whole chirp-z in one launch for M <= 2^15
 //   tiny_shfl_kernel<T, N>                N <= 16 (f32: 32): one lane per transform, wave-shuffle unit transpose
 //   mixed_radix_kernel_ct<T, N>           2^a*3^b in LDS with the reference's schedule, one instantiation per length
-//   mixed_radix_kernel<T>                 the same, runtime-parameterised (A/B reference)
+//   mixed_radix_kernel<T, MAXP, PPT>      the same, runtime-parameterised: lengths with factors 5..13 that have no per-length kernel
 //   odd_last_kernel<T, R>                 radix-3/9/27 passes (twiddled middle ones and the final one) of the large 2^a*3^b sizes
 //   stockham_pass_kernel<T, R>            one pass in global memory, any radix and stride: 2^a*3^b with a < 12 beyond the LDS limit
 //   blu_pre_kernel / blu_post_kernel      unfused chirp sweeps (option bluestein_fusion = 0)
@@ -1702,11 +1702,28 @@ __global__ void __launch_bounds__(256) tiny_dft_kernel(TinyArgs a) {
 // (mod.rs:203-284), butterflies in the reference's operation order (autosort/butterfly.rs:3-65,
 // vector/generic.rs:22-44) with FMA contraction off (Rust never fuses), then the scale pass (mod.rs:381-399).
 // Same tables, same order, same roundings: results are bit-identical to the CPU restatement.
+// The radix of the next pass of an n-point plan with `cur` points left to factor.  2^a*3^b: the reference's schedule,
+// one radix 4 first when divisible, then greedily 8, 4, 3, 2 (autosort/mod.rs:20-21,104-116).  Lengths with a prime factor
+// 5, 7, 11 or 13 are not the reference's to schedule (it sends them to Bluestein): odd radices first, largest first -- a
+// stride-1 pass writes with a lane stride of R elements, which only an odd R spreads over all LDS banks -- then greedily
+// 8, 4, 2, which never takes more passes than the reference's rule and one fewer when 2^a is a power of 8.
+#ifndef FOURIER_MIX_PRIMES_FIRST
+#define FOURIER_MIX_PRIMES_FIRST 1
+#endif
+constexpr bool mix_extended(uint32_t n) { return n % 5 == 0 || n % 7 == 0 || n % 11 == 0 || n % 13 == 0; }
+constexpr uint32_t mix_next_radix(uint32_t n, uint32_t cur, bool first) {
+  if (FOURIER_MIX_PRIMES_FIRST && mix_extended(n))
+    return cur % 13 == 0 ? 13u : (cur % 11 == 0 ? 11u : (cur % 7 == 0 ? 7u : (cur % 5 == 0 ? 5u : (cur % 3 == 0 ? 3u :
+           (cur % 8 == 0 ? 8u : (cur % 4 == 0 ? 4u : 2u))))));
+  return (first && cur % 4 == 0) ? 4u : (cur % 8 == 0 ? 8u : (cur % 4 == 0 ? 4u : (cur % 3 == 0 ? 3u : (cur % 2 == 0 ? 2u :
+         (cur % 5 == 0 ? 5u : (cur % 7 == 0 ? 7u : (cur % 11 == 0 ? 11u : 13u)))))));
+}
 struct MixArgs {
   const void* in; void* out; const void* tw;  // tw: forward table, Sum(size_cur) entries
   uint64_t batch;
   uint32_t n, group;      // transform length, transforms per workgroup
-  uint32_t counts[5];     // passes per radix of {4, 8, 4, 3, 2}
+  uint32_t npass;         // passes, and the radix of each (mix_next_radix)
+  uint8_t radix[20];
   int forward, scaled;
   double scale, w3re, w3im, w8re, w8im;  // compute_twiddle(1,3,true), compute_twiddle(1,8,true) as T values
 };
@@ -1763,82 +1780,185 @@ template <typename T> __device__ __forceinline__ void ref_bf8(cpx<T>* x, bool fw
   for (int k = 0; k < 4; ++k) { x[k] = a1[k]; x[4 + k] = b1[k]; }
 }
 
-template <typename T, int R>
-__device__ __forceinline__ void mixed_pass(const cpx<T>* __restrict__ src, cpx<T>* __restrict__ dst, const cpx<T>* __restrict__ tw,
-                                           uint32_t n, uint32_t nb, uint32_t size, uint32_t stride, bool fwd, cpx<T> w3,
-                                           cpx<T> w8) {
-  const uint32_t m = size / R, nbf = n / R;
-  // q / nbf and e / stride without integer division: operands stay below 2^16 (a workgroup holds <= 9216 points), so
-  // the float quotient is off by at most one and a compare fixes it
-  const float inv_nbf = 1.0f / (float)nbf, inv_stride = 1.0f / (float)stride;
-  for (uint32_t q = threadIdx.x; q < nb * nbf; q += blockDim.x) {
-    uint32_t g = (uint32_t)((float)q * inv_nbf);
-    g -= (g * nbf > q); g += ((g + 1) * nbf <= q);
-    const uint32_t e = q - g * nbf;
-    uint32_t i = (uint32_t)((float)e * inv_stride);
-    i -= (i * stride > e); i += ((i + 1) * stride <= e);
-    const uint32_t j = e - i * stride;
-    const cpx<T>* in = src + g * n + j + stride * i;
-    cpx<T> x[R];
+// ---- beyond the reference: butterflies of prime radix 5, 7, 11, 13 ----
+// The reference sends every length with a prime factor above 3 to Bluestein (fourier/src/lib.rs:38-42).  Lengths whose
+// prime factors stop at 13 run here instead, on the same Stockham pass (mod.rs:203-284) with the radix list continued
+// [4, 8, 4, 3, 2, 5, 7, 11, 13]: one LDS-resident launch instead of two padded power-of-two transforms, and closer to the
+// exact DFT than the chirp-z route (the results agree with the reference's within the Bluestein tolerance, they are not
+// bit-identical -- there is no reference arithmetic for these radices to be identical to).
+// DFT of prime length R by symmetry: with a_q = x_q + x_{R-q}, d_q = x_q - x_{R-q} (q = 1 .. (R-1)/2)
+//   y_k, y_{R-k} = x_0 + sum_q cos(2 pi k q / R) a_q  -/+  i * sum_q sin(2 pi k q / R) d_q     (forward; inverse swaps the signs)
+template <int R> struct PrimeTab { double c[R], s[R]; };   // cos / sin (2 pi j / R), j < R
+template <int R> constexpr PrimeTab<R> prime_tab();
+template <> constexpr PrimeTab<5> prime_tab<5>() {
+  return {{1.0, 0.3090169943749474241, -0.8090169943749474241, -0.8090169943749474241, 0.3090169943749474241},
+          {0.0, 0.95105651629515357212, 0.58778525229247312917, -0.58778525229247312917, -0.95105651629515357212}};
+}
+template <> constexpr PrimeTab<7> prime_tab<7>() {
+  return {{1.0, 0.62348980185873353053, -0.22252093395631440429, -0.90096886790241912624, -0.90096886790241912624, -0.22252093395631440429, 0.62348980185873353053},
+          {0.0, 0.78183148246802980871, 0.97492791218182360702, 0.43388373911755812048, -0.43388373911755812048, -0.97492791218182360702, -0.78183148246802980871}};
+}
+template <> constexpr PrimeTab<11> prime_tab<11>() {
+  return {{1.0, 0.84125353283118116886, 0.41541501300188642553, -0.14231483827328514044, -0.65486073394528506406, -0.95949297361449738989, -0.95949297361449738989, -0.65486073394528506406, -0.14231483827328514044, 0.41541501300188642553, 0.84125353283118116886},
+          {0.0, 0.54064081745559758211, 0.90963199535451837141, 0.98982144188093273238, 0.75574957435425828377, 0.28173255684142969771, -0.28173255684142969771, -0.75574957435425828377, -0.98982144188093273238, -0.90963199535451837141, -0.54064081745559758211}};
+}
+template <> constexpr PrimeTab<13> prime_tab<13>() {
+  return {{1.0, 0.8854560256532098959, 0.56806474673115580251, 0.12053668025532305335, -0.35460488704253562597, -0.74851074817110109863, -0.97094181742605202716, -0.97094181742605202716, -0.74851074817110109863, -0.35460488704253562597, 0.12053668025532305335, 0.56806474673115580251, 0.8854560256532098959},
+          {0.0, 0.46472317204376854566, 0.82298386589365639458, 0.9927088740980539928, 0.93501624268541482344, 0.66312265824079520238, 0.23931566428755776715, -0.23931566428755776715, -0.66312265824079520238, -0.93501624268541482344, -0.9927088740980539928, -0.82298386589365639458, -0.46472317204376854566}};
+}
+template <typename T, int R> __device__ __forceinline__ void dft_prime(cpx<T>* x, bool fwd) {
+  constexpr PrimeTab<R> tab = prime_tab<R>();
+  constexpr int H = (R - 1) / 2;
+  cpx<T> a[H], d[H];
+  cpx<T> y0 = x[0];
 #pragma unroll
-    for (int k = 0; k < R; ++k) x[k] = in[stride * m * k];
-    if constexpr (R == 2) ref_bf2(x[0], x[1]);
-    else if constexpr (R == 3) ref_bf3(x, w3);
-    else if constexpr (R == 4) ref_bf4(x, fwd);
-    else ref_bf8(x, fwd, w8);
-    if (size != (uint32_t)R) {  // mod.rs:238,272
-#pragma unroll
-      for (int k = 1; k < R; ++k) {
-        cpx<T> w = tw[i * R + k];
-        if (!fwd) w.im = -w.im;  // inverse table = conj (twiddle.rs:14-18)
-        x[k] = ref_mul(x[k], w);
-      }
-    }
-    cpx<T>* out = dst + g * n + j + R * stride * i;
-#pragma unroll
-    for (int k = 0; k < R; ++k) out[stride * k] = x[k];
+  for (int q = 1; q <= H; ++q) {
+    a[q - 1] = {x[q].re + x[R - q].re, x[q].im + x[R - q].im};
+    d[q - 1] = {x[q].re - x[R - q].re, x[q].im - x[R - q].im};
+    y0 = {y0.re + a[q - 1].re, y0.im + a[q - 1].im};
   }
+  const T sg = fwd ? (T)1 : (T)-1;
+  const cpx<T> x0 = x[0];
+#pragma unroll
+  for (int k = 1; k <= H; ++k) {
+    cpx<T> m = x0, n = {(T)0, (T)0};
+#pragma unroll
+    for (int q = 1; q <= H; ++q) {
+      const T c = (T)tab.c[(k * q) % R], sn = (T)tab.s[(k * q) % R];
+      m = {m.re + c * a[q - 1].re, m.im + c * a[q - 1].im};
+      n = {n.re + sn * d[q - 1].re, n.im + sn * d[q - 1].im};
+    }
+    const cpx<T> r = {sg * n.im, -sg * n.re};  // -i*n forward, +i*n inverse
+    x[k] = {m.re + r.re, m.im + r.im};
+    x[R - k] = {m.re - r.re, m.im - r.im};
+  }
+  x[0] = y0;
 }
 
-template <typename T>
-__global__ void __launch_bounds__(256) mixed_radix_kernel(MixArgs a) {
+template <typename T, int R> __device__ __forceinline__ void ref_butterfly(cpx<T>* x, bool fwd, cpx<T> w3, cpx<T> w8) {
+  if constexpr (R == 2) ref_bf2(x[0], x[1]);
+  else if constexpr (R == 3) ref_bf3(x, w3);
+  else if constexpr (R == 4) ref_bf4(x, fwd);
+  else if constexpr (R == 8) ref_bf8(x, fwd, w8);
+  else dft_prime<T, R>(x, fwd);
+}
+
+// One pass of the runtime-parameterised kernel, IN PLACE on one LDS buffer: a thread computes up to ROUNDS butterflies,
+// keeps their outputs in registers across a barrier and writes them back to the buffer it read from (the per-length
+// kernels below do the same with every index a constant).  PPT = points per thread the instantiation is sized for.
+template <typename T, int R, int PPT, int NT>
+__device__ __forceinline__ void mixed_pass(cpx<T>* __restrict__ buf, const cpx<T>* __restrict__ tw, uint32_t n, uint32_t nb,
+                                           uint32_t size, uint32_t stride, bool fwd, cpx<T> w3, cpx<T> w8) {
+  constexpr int ROUNDS = (PPT + R - 1) / R;
+  const uint32_t m = size / R, nbf = n / R, total = nb * nbf;
+  // q / nbf and e / stride without integer division: operands stay below 2^16 (a workgroup holds <= 8192 points), so
+  // the float quotient is off by at most one and a compare fixes it
+  const float inv_nbf = 1.0f / (float)nbf, inv_stride = 1.0f / (float)stride;
+  cpx<T> y[ROUNDS][R];
+  uint32_t off[ROUNDS];
+#pragma unroll
+  for (int rd = 0; rd < ROUNDS; ++rd) {
+    const uint32_t q = threadIdx.x + (uint32_t)NT * rd;
+    if (q < total) {
+      uint32_t g = (uint32_t)((float)q * inv_nbf);
+      g -= (g * nbf > q); g += ((g + 1) * nbf <= q);
+      const uint32_t e = q - g * nbf;
+      uint32_t i = (uint32_t)((float)e * inv_stride);
+      i -= (i * stride > e); i += ((i + 1) * stride <= e);
+      const uint32_t j = e - i * stride;
+      const cpx<T>* in = buf + g * n + j + stride * i;
+#pragma unroll
+      for (int k = 0; k < R; ++k) y[rd][k] = in[stride * m * k];
+      ref_butterfly<T, R>(y[rd], fwd, w3, w8);
+      if (size != (uint32_t)R) {  // mod.rs:238,272
+#pragma unroll
+        for (int k = 1; k < R; ++k) {
+          cpx<T> w = tw[i * R + k];
+          if (!fwd) w.im = -w.im;  // inverse table = conj (twiddle.rs:14-18)
+          y[rd][k] = ref_mul(y[rd][k], w);
+        }
+      }
+      off[rd] = g * n + j + R * stride * i;
+    }
+  }
+  __syncthreads();  // every input of the pass has been read
+#pragma unroll
+  for (int rd = 0; rd < ROUNDS; ++rd) {
+    if (threadIdx.x + (uint32_t)NT * rd < total) {
+#pragma unroll
+      for (int k = 0; k < R; ++k) buf[off[rd] + stride * k] = y[rd][k];
+    }
+  }
+  __syncthreads();
+}
+
+// The runtime-parameterised kernel: lengths with factors 5..13 that have no per-length kernel (and, in experiments builds,
+// every length for A/B).  MAXP: the largest prime radix this instantiation carries (3: the reference's list; 7, 13: the
+// continued list) -- the radix-13 butterfly's 26 live values would otherwise set the register allocation of every length.
+// NT threads, PPT points per thread: group * n <= NT * PPT (256 x 4 / 256 x 8 up to 2048 points, 512 x 8 up to 4096, 1024 x 8 up to 8192).
+template <typename T, int MAXP, int PPT, int NT>
+__global__ void __launch_bounds__(NT) mixed_radix_kernel(MixArgs a) {
   FOURIER_DYN_SMEM(smem);
-  cpx<T>* buf0 = (cpx<T>*)smem;
-  cpx<T>* buf1 = buf0 + (size_t)a.group * a.n;
+  cpx<T>* buf = (cpx<T>*)smem;
   const uint64_t b0 = (uint64_t)blockIdx.x * a.group;
   const uint32_t nb = (uint32_t)((a.batch - b0) < a.group ? (a.batch - b0) : a.group);
   const uint32_t total = nb * a.n;
   const cpx<T>* in = (const cpx<T>*)a.in + b0 * a.n;
   cpx<T>* out = (cpx<T>*)a.out + b0 * a.n;
-  for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) buf0[idx] = in[idx];
+  // global <-> LDS in 16-byte units (see mixed_radix_kernel_ct)
+  constexpr uint32_t VEC = 16 / (2 * (uint32_t)sizeof(T));
+  const uint32_t units = total / VEC;
+  if constexpr (VEC == 1) {
+    for (uint32_t idx = threadIdx.x; idx < total; idx += NT) buf[idx] = in[idx];
+  } else {
+    for (uint32_t u = threadIdx.x; u < units; u += NT) *(Unit16<T>*)(buf + u * VEC) = load_unit_a8<T>(in + u * VEC);
+    if ((total % VEC) && threadIdx.x == 0) buf[total - 1] = in[total - 1];
+  }
   __syncthreads();
   const bool fwd = a.forward != 0;
   cpx<T> w3{(T)a.w3re, (T)a.w3im}, w8{(T)a.w8re, (T)a.w8im};
   if (!fwd) { w3.im = -w3.im; w8.im = -w8.im; }
   const cpx<T>* tw = (const cpx<T>*)a.tw;
-  cpx<T>* src = buf0;
-  cpx<T>* dst = buf1;
   uint32_t size = a.n, stride = 1;
-  const uint32_t radices[5] = {4, 8, 4, 3, 2};
-  for (int ri = 0; ri < 5; ++ri) {
-    for (uint32_t c = 0; c < a.counts[ri]; ++c) {
-      const uint32_t R = radices[ri];
-      if (R == 8) mixed_pass<T, 8>(src, dst, tw, a.n, nb, size, stride, fwd, w3, w8);
-      else if (R == 4) mixed_pass<T, 4>(src, dst, tw, a.n, nb, size, stride, fwd, w3, w8);
-      else if (R == 3) mixed_pass<T, 3>(src, dst, tw, a.n, nb, size, stride, fwd, w3, w8);
-      else mixed_pass<T, 2>(src, dst, tw, a.n, nb, size, stride, fwd, w3, w8);
-      __syncthreads();
-      tw += size;  // each pass consumes `size` entries (mod.rs:357,377)
-      size /= R;
-      stride *= R;
-      cpx<T>* t = src; src = dst; dst = t;
+  for (uint32_t ps = 0; ps < a.npass; ++ps) {
+    const uint32_t R = a.radix[ps];
+    if (R == 8) mixed_pass<T, 8, PPT, NT>(buf, tw, a.n, nb, size, stride, fwd, w3, w8);
+    else if (R == 4) mixed_pass<T, 4, PPT, NT>(buf, tw, a.n, nb, size, stride, fwd, w3, w8);
+    else if (R == 3) mixed_pass<T, 3, PPT, NT>(buf, tw, a.n, nb, size, stride, fwd, w3, w8);
+    else if (R == 2) mixed_pass<T, 2, PPT, NT>(buf, tw, a.n, nb, size, stride, fwd, w3, w8);
+    else if constexpr (MAXP >= 5) {
+      if (R == 5) mixed_pass<T, 5, PPT, NT>(buf, tw, a.n, nb, size, stride, fwd, w3, w8);
+      else if (R == 7) mixed_pass<T, 7, PPT, NT>(buf, tw, a.n, nb, size, stride, fwd, w3, w8);
+      else if constexpr (MAXP >= 11) {
+        if (R == 11) mixed_pass<T, 11, PPT, NT>(buf, tw, a.n, nb, size, stride, fwd, w3, w8);
+        else mixed_pass<T, 13, PPT, NT>(buf, tw, a.n, nb, size, stride, fwd, w3, w8);
+      }
     }
+    tw += size;  // each pass consumes `size` entries (mod.rs:357,377)
+    size /= R;
+    stride *= R;
   }
-  const T scale = (T)a.scale;
-  for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
-    cpx<T> y = src[idx];
-    if (a.scaled) y = {y.re * scale, y.im * scale};  // mod.rs:387-393
-    out[idx] = y;
+  const T scale = a.scaled ? (T)a.scale : (T)1;  // mod.rs:387-393 (the unscaled codes skip the multiply: x * 1 is exact)
+  if constexpr (VEC == 1) {
+    for (uint32_t idx = threadIdx.x; idx < total; idx += NT) {
+      cpx<T> y = buf[idx];
+      if (a.scaled) y = {y.re * scale, y.im * scale};
+      out[idx] = y;
+    }
+  } else {
+    for (uint32_t u = threadIdx.x; u < units; u += NT) {
+      Unit16<T> v = *(const Unit16<T>*)(buf + u * VEC);
+      if (a.scaled) {
+#pragma unroll
+        for (uint32_t c = 0; c < 2 * VEC; ++c) v.a[c] = v.a[c] * scale;
+      }
+      store_unit_a8<T>(out + u * VEC, v);
+    }
+    if ((total % VEC) && threadIdx.x == 0) {
+      cpx<T> y = buf[total - 1];
+      if (a.scaled) y = {y.re * scale, y.im * scale};
+      out[total - 1] = y;
+    }
   }
 }
 
@@ -1892,12 +2012,6 @@ __device__ __forceinline__ void dft_pow3(cpx<T>* x, const Args& a) {
   }
 }
 
-template <typename T, int R> __device__ __forceinline__ void ref_butterfly(cpx<T>* x, bool fwd, cpx<T> w3, cpx<T> w8) {
-  if constexpr (R == 2) ref_bf2(x[0], x[1]);
-  else if constexpr (R == 3) ref_bf3(x, w3);
-  else if constexpr (R == 4) ref_bf4(x, fwd);
-  else ref_bf8(x, fwd, w8);
-}
 // ---- the same kernel with the transform length fixed at compile time ----
 // For the sizes the reference itself benchmarks (3^5, 3^6, 3^7, fft_bench.rs:153-159) and the common 3*2^k / 9*2^k
 // lengths: schedule, sizes, strides and table offsets are constants, so the per-butterfly index arithmetic
@@ -1908,13 +2022,36 @@ template <typename T, int R> __device__ __forceinline__ void ref_butterfly(cpx<T
 #ifndef FOURIER_MIX_PAIR_MIN_N_F64
 #define FOURIER_MIX_PAIR_MIN_N_F64 1024u
 #endif
-template <typename T> constexpr bool mix_pairs(uint32_t n) { return n % 9 == 0 && (sizeof(T) == 4 || n >= FOURIER_MIX_PAIR_MIN_N_F64); }
+// fused (5,5) pairs (lengths beyond the reference's), 25 points per work item: built and measured, off -- too few work
+// items per pass and 50+ live registers (f32 5000: 53 % of the HBM peak without, 33 % with; 10000: 48 / 33 %; f64 5000:
+// 55 / 31 %; only 12500 / 15625 gain, 33 -> 35-36 %; r03_s22)
+#ifndef FOURIER_MIX_PAIR5_MIN_N_F32
+#define FOURIER_MIX_PAIR5_MIN_N_F32 0xffffffffu
+#endif
+#ifndef FOURIER_MIX_PAIR5_MIN_N_F64
+#define FOURIER_MIX_PAIR5_MIN_N_F64 0xffffffffu
+#endif
+template <typename T> constexpr bool mix_pairs(uint32_t n, uint32_t r) {
+  return r == 3 ? (n % 9 == 0 && (sizeof(T) == 4 || n >= FOURIER_MIX_PAIR_MIN_N_F64))
+                : (r == 5 && n % 25 == 0 && n >= (sizeof(T) == 4 ? FOURIER_MIX_PAIR5_MIN_N_F32 : FOURIER_MIX_PAIR5_MIN_N_F64));
+}
 // transforms per workgroup: about 1024 points (16 KiB of LDS in f32).  More points per workgroup fill the 256
 // threads better but lose more in resident workgroups than they gain (N=243 f32: 49 % at 1152 points, 40 % at
 // 2304, 27 % at 4608; r01 session 13)
 template <typename T> constexpr uint32_t mix_group(uint32_t n) { return 1024 / n ? 1024 / n : 1; }
-constexpr uint32_t mix_next_radix(uint32_t cur, bool first) {  // autosort/mod.rs:104-116
-  return (first && cur % 4 == 0) ? 4u : (cur % 8 == 0 ? 8u : (cur % 4 == 0 ? 4u : (cur % 3 == 0 ? 3u : 2u)));
+// threads per workgroup: 256, and 1024 for one long transform per workgroup -- at 256 threads such a transform keeps 16+
+// points per thread live across the in-place barrier and one 4-wave workgroup per CU cannot hide the LDS latency.  Same
+// arithmetic, same bits.  2^a*3^b: above 4096 points (f32 9216: 29 -> 44 % of the HBM peak, 18432: 18 -> 34 %, f64 9216:
+// 22 -> 35 %; below, f64 2187 loses 45 -> 34 %).  Lengths with factors 5..13: above 32 KiB per transform (f32 10000: 28 -> 48 %;
+// f64 3125: 43 -> 57 %, 2500: 49 -> 57 %, but 2401: 45 -> 38 %; f32 from 16 KiB loses, 3125: 46 -> 28 %).  r03_s22.
+#ifndef FOURIER_MIX_WIDE_MIN_BYTES
+#define FOURIER_MIX_WIDE_MIN_BYTES 32768u
+#endif
+#ifndef FOURIER_MIX_WIDE_MIN_N
+#define FOURIER_MIX_WIDE_MIN_N 4096u
+#endif
+template <typename T> constexpr uint32_t mix_threads(uint32_t n) {
+  return (mix_extended(n) ? n * 2u * (uint32_t)sizeof(T) > FOURIER_MIX_WIDE_MIN_BYTES : n > FOURIER_MIX_WIDE_MIN_N) ? 1024u : 256u;
 }
 // Every pass runs IN PLACE on one LDS buffer: a thread keeps the outputs of all its butterflies of a pass in
 // registers across a barrier, then writes them back to the buffer it read from.  Same arithmetic as the ping-pong
@@ -1929,16 +2066,16 @@ template <typename T> constexpr bool mix_inplace(uint32_t n) {
 }
 
 template <typename T, uint32_t N, uint32_t SIZE, uint32_t STRIDE, uint32_t TWOFF, bool FIRST_PASS> struct MixPassesCT {
-  static constexpr uint32_t R = mix_next_radix(SIZE, FIRST_PASS), M = SIZE / R;
-  static constexpr bool PAIR = (R == 3 && SIZE >= 9 && (SIZE / 3) % 3 == 0 && mix_pairs<T>(N));
-  // two consecutive radix-3 passes on one LDS round trip: the three butterflies (i + M2*k2, j), k2 < 3, of this pass
-  // write exactly the inputs of the three butterflies (i, j + STRIDE*k), k < 3, of the next one, so a thread that
-  // loads those nine points keeps them in registers in between -- same operations in the same order as two single
+  static constexpr uint32_t R = mix_next_radix(N, SIZE, FIRST_PASS), M = SIZE / R, NT = mix_threads<T>(N);
+  static constexpr bool PAIR = ((R == 3 || R == 5) && SIZE >= R * R && (SIZE / R) % R == 0 && mix_pairs<T>(N, R));
+  // two consecutive radix-R passes (R = 3, 5) on one LDS round trip: the R butterflies (i + M2*k2, j), k2 < R, of this pass
+  // write exactly the inputs of the R butterflies (i, j + STRIDE*k), k < R, of the next one, so a thread that
+  // loads those R*R points keeps them in registers in between -- same operations in the same order as two single
   // passes (mod.rs:203-284 twice), half the LDS traffic, barriers and index arithmetic
-  static constexpr uint32_t SIZE2 = SIZE / 3, M2 = SIZE2 / 3;
-  static constexpr uint32_t PTS = PAIR ? 9 : R;          // points one work item reads and writes
+  static constexpr uint32_t SIZE2 = SIZE / R, M2 = SIZE2 / R;
+  static constexpr uint32_t PTS = PAIR ? R * R : R;      // points one work item reads and writes
   static constexpr uint32_t NBF = N / PTS;               // work items per transform
-  static constexpr uint32_t OUT_SIZE = PAIR ? SIZE2 / 3 : SIZE / R, OUT_STRIDE = STRIDE * PTS;
+  static constexpr uint32_t OUT_SIZE = PAIR ? SIZE2 / R : SIZE / R, OUT_STRIDE = STRIDE * PTS;
   static constexpr uint32_t OUT_TWOFF = PAIR ? TWOFF + SIZE + SIZE2 : TWOFF + SIZE;
   static constexpr bool LAST = (OUT_SIZE == 1);
 
@@ -1951,35 +2088,37 @@ template <typename T, uint32_t N, uint32_t SIZE, uint32_t STRIDE, uint32_t TWOFF
     out_off = g * N + j + PTS * STRIDE * i;
     if constexpr (PAIR) {
       const cpx<T>* __restrict__ t2 = tw + TWOFF + SIZE;
-      cpx<T> x[3][3];
+      cpx<T> x[R][R];
 #pragma unroll
-      for (uint32_t k2 = 0; k2 < 3; ++k2)
+      for (uint32_t k2 = 0; k2 < R; ++k2)
 #pragma unroll
-        for (uint32_t k1 = 0; k1 < 3; ++k1) x[k2][k1] = in[STRIDE * (M2 * k2 + M * k1)];
+        for (uint32_t k1 = 0; k1 < R; ++k1) x[k2][k1] = in[STRIDE * (M2 * k2 + M * k1)];
 #pragma unroll
-      for (uint32_t k2 = 0; k2 < 3; ++k2) {
-        ref_bf3(x[k2], w3);
+      for (uint32_t k2 = 0; k2 < R; ++k2) {
+        ref_butterfly<T, (int)R>(x[k2], fwd, w3, w8);
 #pragma unroll
-        for (uint32_t k = 1; k < 3; ++k) {
-          cpx<T> w = t[(i + M2 * k2) * 3 + k];
+        for (uint32_t k = 1; k < R; ++k) {
+          cpx<T> w = t[(i + M2 * k2) * R + k];
           if (!fwd) w.im = -w.im;
           x[k2][k] = ref_mul(x[k2][k], w);
         }
       }
 #pragma unroll
-      for (uint32_t k = 0; k < 3; ++k) {
-        cpx<T> z[3] = {x[0][k], x[1][k], x[2][k]};
-        ref_bf3(z, w3);
-        if constexpr (SIZE2 != 3) {
+      for (uint32_t k = 0; k < R; ++k) {
+        cpx<T> z[R];
 #pragma unroll
-          for (uint32_t k2 = 1; k2 < 3; ++k2) {
-            cpx<T> w = t2[i * 3 + k2];
+        for (uint32_t k2 = 0; k2 < R; ++k2) z[k2] = x[k2][k];
+        ref_butterfly<T, (int)R>(z, fwd, w3, w8);
+        if constexpr (SIZE2 != R) {
+#pragma unroll
+          for (uint32_t k2 = 1; k2 < R; ++k2) {
+            cpx<T> w = t2[i * R + k2];
             if (!fwd) w.im = -w.im;
             z[k2] = ref_mul(z[k2], w);
           }
         }
 #pragma unroll
-        for (uint32_t k2 = 0; k2 < 3; ++k2) y[k + 3 * k2] = z[k2];  // output slot STRIDE * (k + 3*k2)
+        for (uint32_t k2 = 0; k2 < R; ++k2) y[k + R * k2] = z[k2];  // output slot STRIDE * (k + R*k2)
       }
     } else {
 #pragma unroll
@@ -1999,19 +2138,19 @@ template <typename T, uint32_t N, uint32_t SIZE, uint32_t STRIDE, uint32_t TWOFF
   static __device__ __forceinline__ const cpx<T>* run(const cpx<T>* src, cpx<T>* dst, const cpx<T>* tw, uint32_t nb, bool fwd,
                                                      cpx<T> w3, cpx<T> w8) {
     if constexpr (mix_inplace<T>(N)) {
-      constexpr uint32_t ROUNDS = (mix_group<T>(N) * NBF + 255) / 256;
+      constexpr uint32_t ROUNDS = (mix_group<T>(N) * NBF + NT - 1) / NT;
       cpx<T> y[ROUNDS][PTS];
       uint32_t off[ROUNDS];
 #pragma unroll
       for (uint32_t rd = 0; rd < ROUNDS; ++rd) {
-        const uint32_t q = threadIdx.x + 256 * rd;
+        const uint32_t q = threadIdx.x + NT * rd;
         if (q < nb * NBF) compute(src, tw, q, fwd, w3, w8, y[rd], off[rd]);
       }
       __syncthreads();  // every input of the pass has been read
       cpx<T>* buf = const_cast<cpx<T>*>(src);
 #pragma unroll
       for (uint32_t rd = 0; rd < ROUNDS; ++rd) {
-        const uint32_t q = threadIdx.x + 256 * rd;
+        const uint32_t q = threadIdx.x + NT * rd;
         if (q < nb * NBF) {
 #pragma unroll
           for (uint32_t k = 0; k < PTS; ++k) buf[off[rd] + STRIDE * k] = y[rd][k];
@@ -2021,7 +2160,7 @@ template <typename T, uint32_t N, uint32_t SIZE, uint32_t STRIDE, uint32_t TWOFF
       if constexpr (LAST) return src;
       else return MixPassesCT<T, N, OUT_SIZE, OUT_STRIDE, OUT_TWOFF, false>::run(src, dst, tw, nb, fwd, w3, w8);
     } else {
-      for (uint32_t q = threadIdx.x; q < nb * NBF; q += 256) {
+      for (uint32_t q = threadIdx.x; q < nb * NBF; q += NT) {
         cpx<T> y[PTS];
         uint32_t off;
         compute(src, tw, q, fwd, w3, w8, y, off);
@@ -2035,7 +2174,8 @@ template <typename T, uint32_t N, uint32_t SIZE, uint32_t STRIDE, uint32_t TWOFF
   }
 };
 template <typename T, uint32_t N>
-__global__ void __launch_bounds__(256) mixed_radix_kernel_ct(MixArgs a) {
+__global__ void __launch_bounds__(mix_threads<T>(N)) mixed_radix_kernel_ct(MixArgs a) {
+  constexpr uint32_t NT = mix_threads<T>(N);
   FOURIER_DYN_SMEM(smem);
   constexpr uint32_t GROUP = mix_group<T>(N);
   cpx<T>* buf0 = (cpx<T>*)smem;
@@ -2050,9 +2190,9 @@ __global__ void __launch_bounds__(256) mixed_radix_kernel_ct(MixArgs a) {
   constexpr uint32_t VEC = 16 / (2 * (uint32_t)sizeof(T));
   const uint32_t units = total / VEC;
   if constexpr (VEC == 1) {
-    for (uint32_t idx = threadIdx.x; idx < total; idx += 256) buf0[idx] = in[idx];
+    for (uint32_t idx = threadIdx.x; idx < total; idx += NT) buf0[idx] = in[idx];
   } else {
-    for (uint32_t u = threadIdx.x; u < units; u += 256) *(Unit16<T>*)(buf0 + u * VEC) = load_unit_a8<T>(in + u * VEC);
+    for (uint32_t u = threadIdx.x; u < units; u += NT) *(Unit16<T>*)(buf0 + u * VEC) = load_unit_a8<T>(in + u * VEC);
     if ((total % VEC) && threadIdx.x == 0) buf0[total - 1] = in[total - 1];
   }
   __syncthreads();
@@ -2062,13 +2202,13 @@ __global__ void __launch_bounds__(256) mixed_radix_kernel_ct(MixArgs a) {
   const cpx<T>* res = MixPassesCT<T, N, N, 1, 0, true>::run(buf0, buf1, (const cpx<T>*)a.tw, nb, fwd, w3, w8);
   const T scale = a.scaled ? (T)a.scale : (T)1;  // mod.rs:387-393 (the unscaled codes skip the multiply: x * 1 is exact)
   if constexpr (VEC == 1) {
-    for (uint32_t idx = threadIdx.x; idx < total; idx += 256) {
+    for (uint32_t idx = threadIdx.x; idx < total; idx += NT) {
       cpx<T> y = res[idx];
       if (a.scaled) y = {y.re * scale, y.im * scale};
       out[idx] = y;
     }
   } else {
-    for (uint32_t u = threadIdx.x; u < units; u += 256) {
+    for (uint32_t u = threadIdx.x; u < units; u += NT) {
       Unit16<T> v = *(const Unit16<T>*)(res + u * VEC);
       if (a.scaled) {
 #pragma unroll

@@ -69,7 +69,7 @@ def test_sweep_1_255_like_reference(fa, oracle, dtype, eps, forward):
 
 @pytest.mark.parametrize("dtype,eps", [(np.complex64, F32_EPS), (np.complex128, F64_EPS)])
 def test_reference_golden_vector_through_engine(fa, dtype, eps):
-    x, y = load_ref10()  # integrity.rs:48-72; N=10 -> Bluestein, M=32
+    x, y = load_ref10()  # integrity.rs:48-72; N=10: Bluestein (M=32) in the reference, radix 2.5 here
     plan = make(fa, 10, dtype)
     got = np.empty(10, dtype)
     plan.fft(x.astype(dtype), got)
@@ -112,7 +112,7 @@ def test_n4096_against_committed_spectrum(fa):
         assert rel_l2(got, g["y"]) <= tl2
 
 
-@pytest.mark.parametrize("n", [7, 96, 100, 1000, 1025, 2500])
+@pytest.mark.parametrize("n", [7, 17, 96, 100, 1000, 1003, 1025, 2500])
 def test_bluestein_and_mixed_radix_sizes(fa, oracle, n):
     x = np.stack([hash_normal(40 + b, n) for b in range(2)])
     for dtype, tl2 in ((np.complex64, 2e-6), (np.complex128, 2e-12)):
@@ -121,6 +121,31 @@ def test_bluestein_and_mixed_radix_sizes(fa, oracle, n):
             ref = oracle.transform_batch(x.astype(dtype), code)
             assert rel_l2(run_batch(plan, x.astype(dtype), code), ref) <= tl2, (n, code)
             assert rel_l2(run_batch(plan, x.astype(dtype), code, inplace=True), ref) <= tl2, (n, code)
+
+
+def test_lengths_with_prime_factors_5_to_13_run_as_stockham_passes(fa, oracle):
+    """Beyond the reference (which sends them to Bluestein, fourier/src/lib.rs:38-42): lengths whose prime factors stop at
+    13 run the Stockham pass with the radix list continued [4,8,4,3,2,5,7,11,13] -- per-length kernels for the reference's
+    own 5^k benchmark lengths and round decimal lengths, the runtime-parameterised kernel for the rest.  Every transform
+    code, in and out of place, ragged batches; within the Bluestein tolerance of the oracle and tighter against f64 truth."""
+    for n, batch in ((5, 300), (35, 70), (125, 19), (143, 9), (625, 5), (1000, 3), (1001, 3), (3125, 2), (4095, 2)):
+        x = np.stack([hash_normal(500 + b, n) for b in range(batch)])
+        for dtype, tl2, ttruth in ((np.complex64, 2e-6, 4e-7), (np.complex128, 2e-12, 2e-15)):
+            plan = make(fa, n, dtype)
+            if dtype == np.complex128 and n > 2048 and (n % 11 == 0 or n % 13 == 0):
+                assert "bluestein" in plan.describe()  # f64 radix 11 / 13 beyond the 256-thread kernels: does not fit the registers
+                continue
+            assert plan.describe().startswith("stockham mixed-radix"), plan.describe()
+            xs = x.astype(dtype)
+            for code in range(5):
+                ref = oracle.transform_batch(xs, code)
+                got = run_batch(plan, xs, code)
+                assert rel_l2(got, ref) <= tl2, (n, code, rel_l2(got, ref))
+                assert np.array_equal(run_batch(plan, xs, code, inplace=True), got), (n, code)
+            assert rel_l2(run_batch(plan, xs, 0), np.fft.fft(xs.astype(np.complex128), axis=1)) <= ttruth, n
+    assert "bluestein" in make(fa, 17 * 64, np.complex64).describe()      # a factor above 13
+    assert "bluestein" in make(fa, 20000, np.complex64).describe()        # beyond the LDS kernels (for now)
+    assert "bluestein" in make(fa, 9100, np.complex64).describe()         # no per-length kernel, beyond the runtime kernel's 8192 points
 
 
 MIXED_SIZES = sorted({(2 ** a) * (3 ** b) for a in range(13) for b in range(1, 8) if (2 ** a) * (3 ** b) <= 4096})
@@ -206,7 +231,7 @@ def test_bluestein_fusion_matches_unfused(fa):
     """The fused Bluestein forms (whole chirp-z in one launch for M <= 2^15; chirp steps fused into the
     inner passes above) give the same values, to rounding, as the separate blu_pre / blu_post sweeps
     (bluesteins.rs:229-258), for every transform code, in and out of place."""
-    for n in (10, 100, 439, 1025, 3000, 40000):
+    for n in (17, 102, 439, 1025, 3001, 40000):  # no prime factor below 17 (or too long for LDS): Bluestein
         x = np.stack([hash_normal(70 + b, n) for b in range(2)]).astype(np.complex64)
         fused, plain = make(fa, n, np.complex64), make(fa, n, np.complex64)
         plain.set_option("bluestein_fusion", 0)
@@ -214,7 +239,7 @@ def test_bluestein_fusion_matches_unfused(fa):
             a, b = run_batch(fused, x, code), run_batch(plain, x, code)
             assert rel_l2(a, b) <= 3e-7, (n, code, rel_l2(a, b))
             assert np.array_equal(run_batch(fused, x, code, inplace=True), a), (n, code)
-    assert "fused" in make(fa, 3000, np.complex64).describe()
+    assert "fused" in make(fa, 3001, np.complex64).describe()
 
 
 def test_lane_per_transform_and_small_row_kernels_with_ragged_batches(fa):
@@ -462,14 +487,14 @@ def test_profile_hook_reports_every_kernel(fa):
     y1 = np.empty_like(x1)
     assert [p[0] for p in one.profile_batch_ptr(x1.ctypes.data, y1.ctypes.data, 1, 0)] == ["pass0"]
     assert rel_l2(y[0], np.fft.fft(x[0].astype(np.complex128))) <= 1e-6
-    planb = make(fa, 100, np.complex64)  # M = 256; with fusion off: separate chirp kernels around the inner FFT
+    planb = make(fa, 102, np.complex64)  # M = 256; with fusion off: separate chirp kernels around the inner FFT
     planb.set_option("bluestein_fusion", 0)
-    xb = hash_normal(1, 100).astype(np.complex64)[None, :]
+    xb = hash_normal(1, 102).astype(np.complex64)[None, :]
     yb = np.empty_like(xb)
     names = [p[0] for p in planb.profile_batch_ptr(xb.ctypes.data, yb.ctypes.data, 1, 0)]
     assert names == ["blu_pre", "fwd_pass0", "inv_pass0", "blu_post"]
-    planc = make(fa, 1000, np.complex64)  # M = 2048: the whole chirp-z in one launch
-    xc = hash_normal(1, 1000).astype(np.complex64)[None, :]
+    planc = make(fa, 1003, np.complex64)  # M = 2048: the whole chirp-z in one launch
+    xc = hash_normal(1, 1003).astype(np.complex64)[None, :]
     yc = np.empty_like(xc)
     assert [p[0] for p in planc.profile_batch_ptr(xc.ctypes.data, yc.ctypes.data, 1, 0)] == ["bluestein_one_launch"]
     assert rel_l2(yc[0], np.fft.fft(xc[0].astype(np.complex128))) <= 2e-6

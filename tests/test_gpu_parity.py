@@ -144,7 +144,7 @@ def test_pow2_all_codes_vs_oracle(torch, fa, oracle, n, dtype, tl2, tmax):
             assert rel_l2(got, ref) <= tl2 and max_rel(got, ref) <= tmax, (n, code, inplace, rel_l2(got, ref))
 
 
-@pytest.mark.parametrize("n", [3, 7, 12, 73, 96, 100, 255, 1000, 1025, 2500, 10007, 65537])
+@pytest.mark.parametrize("n", [3, 7, 12, 17, 73, 96, 100, 255, 1000, 1003, 1025, 2500, 4095, 10007, 65537])
 def test_bluestein_and_mixed_radix_vs_oracle(torch, fa, oracle, n):
     x = np.stack([hash_normal(40 + b, n) for b in range(3)])
     for dtype, tl2 in ((np.complex64, 2e-6), (np.complex128, 5e-11)):
@@ -225,7 +225,7 @@ def test_large_mixed_radix_sizes_vs_oracle(torch, fa, oracle, n):
 
 
 def test_bluestein_fusion_matches_unfused(torch, fa):
-    for n in (10, 125, 439, 1025, 3125, 10007, 999983):  # one-launch chirp-z (M <= 2^15) and pass-fused (M = 2^21)
+    for n in (17, 127, 439, 1025, 3127, 10007, 999983):  # one-launch chirp-z (M <= 2^15) and pass-fused (M = 2^21)
         x = np.stack([hash_uniform(70 + b, n) for b in range(2)]).astype(np.complex64)
         fused, plain = make(fa, n, np.complex64), make(fa, n, np.complex64)
         plain.set_option("bluestein_fusion", 0)
@@ -854,7 +854,7 @@ def test_error_behaviour(torch, fa):
     with pytest.raises(TypeError):
         plan.fft_in_place(torch.zeros(8, dtype=torch.complex128, device="cuda"))
     # empty batch: a successful no-op for every plan family
-    for n, opts in ((8, ()), (4096, ()), (1 << 16, ()), (96, ()), (3 * 4096, ()), (100, ()), (40000, ())):
+    for n, opts in ((8, ()), (4096, ()), (1 << 16, ()), (96, ()), (3 * 4096, ()), (100, ()), (102, ()), (40000, ())):
         p = fa.create_fft_f32(n)
         for k, v in opts:
             p.set_option(k, v)
@@ -962,6 +962,37 @@ def test_mixed_radix_sizes_beyond_the_lds_limit_with_a_small_power_of_two(torch,
         ref = oracle.transform_batch(x, code)
         assert rel_l2(gpu_batch(torch, fa, plan, x, code), ref) <= tol, (n, code)
         assert rel_l2(gpu_batch(torch, fa, plan, x, code, inplace=True), ref) <= tol, (n, code, "in place")
+
+
+@pytest.mark.parametrize("n", [5, 35, 125, 143, 625, 1000, 1001, 2401, 3125, 4095, 5005, 9100, 10000, 15625, 16807])
+def test_lengths_with_prime_factors_5_to_13_run_as_stockham_passes(torch, fa, oracle, n):
+    """Beyond the reference (which sends them to Bluestein, fourier/src/lib.rs:38-42): lengths whose prime factors stop at
+    13 run the LDS Stockham kernel with the radix list continued [4,8,4,3,2,5,7,11,13] -- per-length kernels for the
+    reference's own 5^k benchmark lengths and round decimal lengths, the runtime-parameterised kernel otherwise.  All
+    codes, in and out of place, a ragged batch over many workgroups; within the Bluestein tolerance of the oracle and,
+    being a direct factorisation, tighter against f64 truth."""
+    batch = max(3, min(4099, (1 << 19) // n)) | 1
+    x = np.stack([hash_normal(2100 + (b % 7), n) for b in range(7)])
+    for dtype, tl2, ttruth in ((np.complex64, 2e-6, 4e-7), (np.complex128, 5e-11, 3e-15)):
+        plan = make(fa, n, dtype)
+        m = n
+        while m % 2 == 0 or m % 3 == 0 or m % 5 == 0:
+            m //= 2 if m % 2 == 0 else (3 if m % 3 == 0 else 5)
+        per_length = (m == 1 or n in (49, 343, 2401, 16807)) and n * np.dtype(dtype).itemsize <= 144 * 1024  # 2^a*3^b*5^c, 7^k
+        f64_wide_13 = dtype == np.complex128 and n > 2048 and (n % 11 == 0 or n % 13 == 0)  # does not fit the registers
+        if not per_length and (n > 8192 or f64_wide_13):  # the runtime-parameterised kernel stops at 8192 points
+            assert "bluestein" in plan.describe(), plan.describe()
+            continue
+        assert plan.describe().startswith("stockham mixed-radix"), plan.describe()
+        xs = np.tile(x.astype(dtype), ((batch + 6) // 7, 1))[:batch]
+        truth = np.fft.fft(x.astype(np.complex128), axis=1)
+        for code in range(5):
+            ref = oracle.transform_batch(xs[:7], code)
+            got = gpu_batch(torch, fa, plan, xs, code)
+            assert rel_l2(got[:7], ref) <= tl2, (n, code, rel_l2(got[:7], ref))
+            assert all(np.array_equal(got[b], got[b % 7]) for b in range(7, batch)), (n, code)  # every workgroup, same bits
+            assert np.array_equal(gpu_batch(torch, fa, plan, xs, code, inplace=True), got), (n, code)
+        assert rel_l2(gpu_batch(torch, fa, plan, xs[:7], 0), truth) <= ttruth, n
 
 
 @pytest.mark.parametrize("dtype,log2n", [(np.complex64, 29), (np.complex128, 28)])

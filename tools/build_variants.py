@@ -52,6 +52,11 @@ VARIANTS = {
     "nt_narrow2048_off": ["-DFOURIER_NT_STORE_NARROW_2048=0"],
     "conv_wb4": ["-DFOURIER_CONV_W_BATCH=4"],
     "conv_wb16": ["-DFOURIER_CONV_W_BATCH=16"],
+    "mix_ref_order": ["-DFOURIER_MIX_PRIMES_FIRST=0"],
+    "mix_pair5_none": ["-DFOURIER_MIX_PAIR5_MIN_N_F32=1000000u", "-DFOURIER_MIX_PAIR5_MIN_N_F64=1000000u"],
+    "mix_pair5_all": ["-DFOURIER_MIX_PAIR5_MIN_N_F32=25u", "-DFOURIER_MIX_PAIR5_MIN_N_F64=25u"],
+    "mix_wide_16k": ["-DFOURIER_MIX_WIDE_MIN_BYTES=16384u"],
+    "mix_wide_none": ["-DFOURIER_MIX_WIDE_MIN_BYTES=0xffffffffu", "-DFOURIER_MIX_WIDE_MIN_N=0xffffffffu"],
     "abl1": ["-DFOURIER_ABLATE=1"],
     "abl2": ["-DFOURIER_ABLATE=2"],
     "abl3": ["-DFOURIER_ABLATE=3"],

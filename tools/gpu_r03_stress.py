@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Round 3 one-off stress: every 2^a*3^b up to 6e6 (LDS, global-pass and tiled routes), random other sizes, random codes,
+"""Round 3 one-off stress: every 2^a*3^b up to 6e6 (LDS, global-pass and tiled routes), every length up to 18432 whose prime
+factors stop at 13 (the radix-5/7/11/13 LDS kernels), random other sizes, random codes,
 in and out of place, f32 and f64, against the oracle.  Prints one line per failure and a summary."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,12 +13,18 @@ from oracle import oracle as O
 O.build()
 rng = np.random.default_rng(int(os.environ.get("STRESS_SEED", "12345")))
 smooth = sorted({(2 ** a) * (3 ** b) for a in range(0, 23) for b in range(0, 15) if (2 ** a) * (3 ** b) <= 6_000_000})
+def _smooth(limit, primes):
+    vals = {1}
+    for p in primes:
+        vals = {v * p ** e for v in vals for e in range(0, 16) if v * p ** e <= limit}
+    return vals
+smooth13 = sorted(v for v in _smooth(18432, [2, 3, 5, 7, 11, 13]) if any(v % p == 0 for p in (5, 7, 11, 13)))  # the prime-radix LDS kernels
 others = sorted({int(v) for v in np.concatenate([rng.integers(2, 5000, 150), rng.integers(5000, 200000, 80), rng.integers(200000, 3000000, 25)])})
 worst = {}
 fails = 0
 t0 = time.time()
 count = 0
-for n in smooth + others:
+for n in smooth + smooth13 + others:
     for dtype, tol in ((np.complex64, 2e-6), (np.complex128, 1e-9 if n > 100000 else 5e-11)):
         if dtype == np.complex128 and rng.random() < 0.5:
             continue
