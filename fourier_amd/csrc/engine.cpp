@@ -973,7 +973,8 @@ template <typename T> class MixedEngine {
     const int maxp = (n % 11 == 0 || n % 13 == 0) ? 13 : ((n % 5 == 0 || n % 7 == 0) ? 7 : 3);
     const size_t pts = k.group * n;
 #define FOURIER_MIX_RT(P, NT) (maxp == 13 ? &mixed_radix_kernel<T, 13, P, NT> : (maxp == 7 ? &mixed_radix_kernel<T, 7, P, NT> : &mixed_radix_kernel<T, 3, P, NT>))
-    if (pts <= 1024) k.fn = FOURIER_MIX_RT(4, 256);
+    if (pts <= 1024 && mix_threads<T>((uint32_t)n) == 128) { k.fn = FOURIER_MIX_RT(8, 128); k.threads = 128; }  // few work items per pass
+    else if (pts <= 1024) k.fn = FOURIER_MIX_RT(4, 256);
     else if (pts <= 2048) k.fn = FOURIER_MIX_RT(8, 256);
     else if (sizeof(T) == 8 && maxp == 13) {}  // f64 with a radix-13 butterfly does not fit 128 registers (spills; 4095 f64: 20 % against Bluestein's 25 %)
     else if (pts <= 4096) { k.fn = FOURIER_MIX_RT(8, 512); k.threads = 512; }

@@ -37,6 +37,8 @@
 #define FOURIER_LAUNDER(v)
 #define FOURIER_DYN_SMEM(name) unsigned char* name = hipemu::smem()
 #define LDS_NOTE(p, bytes, w, site) hipemu::lds_note((p), (bytes), (w), (site))
+static inline float fast_rcp(float x) { return 1.0f / x; }
+static inline uint32_t mul24(uint32_t a, uint32_t b) { return a * b; }
 #else
 #include <hip/hip_runtime.h>
 // stops hipcc from hoisting a whole block of table loads above the arithmetic that consumes them
@@ -49,6 +51,10 @@
 #define FOURIER_LAUNDER(v) asm volatile("" : "+v"(v))
 #define FOURIER_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #define LDS_NOTE(p, bytes, w, site)
+// v_rcp_f32 (1 ulp) instead of the IEEE division sequence; callers correct the quotient with a compare
+static __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// v_mul_u32_u24: full rate (v_mul_lo_u32 runs at a quarter); both operands must be below 2^24
+static __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
 #endif
 
 // second __launch_bounds__ argument = min waves per SIMD: ask for two workgroups per CU
@@ -1852,8 +1858,11 @@ __device__ __forceinline__ void mixed_pass(cpx<T>* __restrict__ buf, const cpx<T
   constexpr int ROUNDS = (PPT + R - 1) / R;
   const uint32_t m = size / R, nbf = n / R, total = nb * nbf;
   // q / nbf and e / stride without integer division: operands stay below 2^16 (a workgroup holds <= 8192 points), so
-  // the float quotient is off by at most one and a compare fixes it
-  const float inv_nbf = 1.0f / (float)nbf, inv_stride = 1.0f / (float)stride;
+  // the float quotient is off by at most one and a compare fixes it.  Every product below fits 24 bits: mul24 is a
+  // full-rate instruction where the 32-bit multiply runs at a quarter (the first version spent 60+ v_mul_lo_u32 a pass);
+  // the R addresses of a butterfly advance by addition.
+  const float inv_nbf = fast_rcp((float)nbf), inv_stride = fast_rcp((float)stride);
+  const uint32_t in_step = mul24(stride, m);
   cpx<T> y[ROUNDS][R];
   uint32_t off[ROUNDS];
 #pragma unroll
@@ -1861,32 +1870,47 @@ __device__ __forceinline__ void mixed_pass(cpx<T>* __restrict__ buf, const cpx<T
     const uint32_t q = threadIdx.x + (uint32_t)NT * rd;
     if (q < total) {
       uint32_t g = (uint32_t)((float)q * inv_nbf);
-      g -= (g * nbf > q); g += ((g + 1) * nbf <= q);
-      const uint32_t e = q - g * nbf;
+      g -= (mul24(g, nbf) > q); g += (mul24(g + 1, nbf) <= q);
+      const uint32_t e = q - mul24(g, nbf);
       uint32_t i = (uint32_t)((float)e * inv_stride);
-      i -= (i * stride > e); i += ((i + 1) * stride <= e);
-      const uint32_t j = e - i * stride;
-      const cpx<T>* in = buf + g * n + j + stride * i;
+      i -= (mul24(i, stride) > e); i += (mul24(i + 1, stride) <= e);
+      const uint32_t is = mul24(i, stride), j = e - is, base = mul24(g, n) + j;
+      // The twiddles first: issued behind the butterfly, inside the reference's `size != R` branch (mod.rs:238,272) -- where
+      // the compiler sinks them when the multiply is conditional -- their L2 latency adds to the LDS latency of every pass
+      // instead of hiding under it.  So the multiply is unconditional: the last pass reads W^0 = (1, -0) from its table
+      // section and multiplies by it, which returns every finite value unchanged.
+      cpx<T> w[R];
+      const cpx<T>* __restrict__ twi = tw + mul24(i, (uint32_t)R);
+      constexpr bool EARLY = sizeof(T) == 4;  // f64: the early loads cost registers the 1024-thread kernels do not have
+      if constexpr (EARLY) {
 #pragma unroll
-      for (int k = 0; k < R; ++k) y[rd][k] = in[stride * m * k];
-      ref_butterfly<T, R>(y[rd], fwd, w3, w8);
-      if (size != (uint32_t)R) {  // mod.rs:238,272
-#pragma unroll
-        for (int k = 1; k < R; ++k) {
-          cpx<T> w = tw[i * R + k];
-          if (!fwd) w.im = -w.im;  // inverse table = conj (twiddle.rs:14-18)
-          y[rd][k] = ref_mul(y[rd][k], w);
-        }
+        for (int k = 1; k < R; ++k) w[k] = twi[k];
+        FOURIER_SCHED_FENCE();
       }
-      off[rd] = g * n + j + R * stride * i;
+      uint32_t idx = base + is;
+#pragma unroll
+      for (int k = 0; k < R; ++k) { y[rd][k] = buf[idx]; idx += in_step; }
+      ref_butterfly<T, R>(y[rd], fwd, w3, w8);
+      if constexpr (!EARLY) {
+        FOURIER_SCHED_FENCE();
+#pragma unroll
+        for (int k = 1; k < R; ++k) w[k] = twi[k];
+      }
+#pragma unroll
+      for (int k = 1; k < R; ++k) {
+        if (!fwd) w[k].im = -w[k].im;  // inverse table = conj (twiddle.rs:14-18)
+        y[rd][k] = ref_mul(y[rd][k], w[k]);
+      }
+      off[rd] = base + mul24(is, (uint32_t)R);
     }
   }
   __syncthreads();  // every input of the pass has been read
 #pragma unroll
   for (int rd = 0; rd < ROUNDS; ++rd) {
     if (threadIdx.x + (uint32_t)NT * rd < total) {
+      uint32_t idx = off[rd];
 #pragma unroll
-      for (int k = 0; k < R; ++k) buf[off[rd] + stride * k] = y[rd][k];
+      for (int k = 0; k < R; ++k) { buf[idx] = y[rd][k]; idx += stride; }
     }
   }
   __syncthreads();
@@ -1895,9 +1919,14 @@ __device__ __forceinline__ void mixed_pass(cpx<T>* __restrict__ buf, const cpx<T
 // The runtime-parameterised kernel: lengths with factors 5..13 that have no per-length kernel (and, in experiments builds,
 // every length for A/B).  MAXP: the largest prime radix this instantiation carries (3: the reference's list; 7, 13: the
 // continued list) -- the radix-13 butterfly's 26 live values would otherwise set the register allocation of every length.
-// NT threads, PPT points per thread: group * n <= NT * PPT (256 x 4 / 256 x 8 up to 2048 points, 512 x 8 up to 4096, 1024 x 8 up to 8192).
+// NT threads, PPT points per thread: group * n <= NT * PPT (128 x 8 / 256 x 4 / 256 x 8 up to 2048 points, 512 x 8 up to 4096, 1024 x 8 up to 8192).
+// The second launch bound (waves per SIMD) is what makes hipcc economise: left at 128 threads and no bound it spends 119
+// VGPRs on the f32 radix-7 instantiation, which halves the resident workgroups of a latency-bound kernel.
+#ifndef FOURIER_MIX_RT_WAVES
+#define FOURIER_MIX_RT_WAVES(T, MAXP, PPT) ((sizeof(T) == 4 ? ((MAXP) <= 7 ? ((PPT) <= 4 ? 6 : 5) : 4) : ((MAXP) <= 7 ? ((PPT) <= 4 ? 4 : 3) : 2)))
+#endif
 template <typename T, int MAXP, int PPT, int NT>
-__global__ void __launch_bounds__(NT) mixed_radix_kernel(MixArgs a) {
+__global__ void __launch_bounds__(NT, FOURIER_MIX_RT_WAVES(T, MAXP, PPT)) mixed_radix_kernel(MixArgs a) {
   FOURIER_DYN_SMEM(smem);
   cpx<T>* buf = (cpx<T>*)smem;
   const uint64_t b0 = (uint64_t)blockIdx.x * a.group;
@@ -2050,8 +2079,31 @@ template <typename T> constexpr uint32_t mix_group(uint32_t n) { return 1024 / n
 #ifndef FOURIER_MIX_WIDE_MIN_N
 #define FOURIER_MIX_WIDE_MIN_N 4096u
 #endif
+// ... and 128 threads in f32 where a pass has, on average, no more than FOURIER_MIX_HALF_MAX_ITEMS work items (butterflies or
+// butterfly pairs) per workgroup: these kernels are latency-bound chains of barrier-separated passes, most of 256 threads
+// would idle, and half-size workgroups put twice as many chains on a CU (243: 50 -> 61 % of the HBM peak, 625: 43 -> 59 %,
+// 729: 40 -> 54 %, 768: 46 -> 60 %; lengths with 200+ items per pass lose 3-12 points, every f64 length loses; 64 threads
+// never beat 128; r03_s24_mixed_radix_threads_per_workgroup_ab.jsonl)
+#ifndef FOURIER_MIX_HALF_MAX_ITEMS
+#define FOURIER_MIX_HALF_MAX_ITEMS 190u
+#endif
+template <typename T> constexpr uint32_t mix_mean_items(uint32_t n) {
+  uint32_t cur = n, passes = 0, items = 0;
+  const uint32_t pts_total = mix_group<T>(n) * n;
+  while (cur > 1) {
+    const uint32_t r = mix_next_radix(n, cur, cur == n);
+    if (cur % r) return 0xffffffffu;  // not a length these kernels factor
+    const bool pair = (r == 3 || r == 5) && cur >= r * r && (cur / r) % r == 0 && mix_pairs<T>(n, r);
+    const uint32_t pts = pair ? r * r : r;
+    items += pts_total / pts;
+    passes += 1;
+    cur /= pts;
+  }
+  return passes ? items / passes : 0xffffffffu;
+}
 template <typename T> constexpr uint32_t mix_threads(uint32_t n) {
-  return (mix_extended(n) ? n * 2u * (uint32_t)sizeof(T) > FOURIER_MIX_WIDE_MIN_BYTES : n > FOURIER_MIX_WIDE_MIN_N) ? 1024u : 256u;
+  return (mix_extended(n) ? n * 2u * (uint32_t)sizeof(T) > FOURIER_MIX_WIDE_MIN_BYTES : n > FOURIER_MIX_WIDE_MIN_N) ? 1024u
+         : ((sizeof(T) == 4 && mix_mean_items<T>(n) <= FOURIER_MIX_HALF_MAX_ITEMS) ? 128u : 256u);
 }
 // Every pass runs IN PLACE on one LDS buffer: a thread keeps the outputs of all its butterflies of a pass in
 // registers across a barrier, then writes them back to the buffer it read from.  Same arithmetic as the ping-pong
