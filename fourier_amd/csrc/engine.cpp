@@ -947,8 +947,10 @@ template <typename T> class Pow2Engine {
 // small mixed-radix sizes in LDS: 2^a * 3^b (b > 0) on the reference's own schedule and tables; lengths with factors 5..13 on the same pass
 template <typename T> class MixedEngine {
  public:
-  // one LDS buffer of one transform must fit a workgroup (the passes run in place): N * sizeof(complex) <= 144 KiB
-  static constexpr size_t MAX_N = (144 * 1024) / sizeof(cpx<T>);  // 18432 (f32), 9216 (f64)
+  // one LDS buffer of one transform must fit a workgroup (the passes run in place): N * sizeof(complex) <= 160 KiB, all of a
+  // gfx950 CU's LDS (round 3; 144 KiB before: f64 N = 10000 is 156.25 KiB)
+  static constexpr size_t MAX_LDS = 160 * 1024;
+  static constexpr size_t MAX_N = MAX_LDS / sizeof(cpx<T>);  // 20480 (f32), 10240 (f64)
   // autosort/mod.rs:104-116: one radix-4 first when divisible, then greedily 8, 4, 3, 2 -- and, beyond the reference (which
   // sends such lengths to Bluestein, fourier/src/lib.rs:38-42), the same pass with prime radices 5, 7, 11, 13
   static bool factor(size_t size, std::vector<uint32_t>& radices) {
@@ -985,7 +987,7 @@ template <typename T> class MixedEngine {
   case NN:                                                                      \
     if constexpr ((size_t)NN <= MAX_N) k = Kernel{&mixed_radix_kernel_ct<T, NN>, mix_group<T>(NN), mix_inplace<T>(NN) ? (size_t)1 : (size_t)2, mix_threads<T>(NN)}; \
     break;
-    switch (n) {  // every 2^a * 3^b (b >= 1) the engine runs in LDS: 3 ... 18432 (f32) / 9216 (f64)
+    switch (n) {  // every 2^a * 3^b (b >= 1) the engine runs in LDS: 3 ... 19683 (f32) / 9216 (f64)
       FOURIER_MIX_CT(3) FOURIER_MIX_CT(6) FOURIER_MIX_CT(9) FOURIER_MIX_CT(12) FOURIER_MIX_CT(18) FOURIER_MIX_CT(24)
       FOURIER_MIX_CT(27) FOURIER_MIX_CT(36) FOURIER_MIX_CT(48) FOURIER_MIX_CT(54) FOURIER_MIX_CT(72) FOURIER_MIX_CT(81)
       FOURIER_MIX_CT(96) FOURIER_MIX_CT(108) FOURIER_MIX_CT(144) FOURIER_MIX_CT(162) FOURIER_MIX_CT(192) FOURIER_MIX_CT(216)
@@ -996,7 +998,7 @@ template <typename T> class MixedEngine {
       FOURIER_MIX_CT(3888) FOURIER_MIX_CT(4374) FOURIER_MIX_CT(4608) FOURIER_MIX_CT(5184) FOURIER_MIX_CT(5832) FOURIER_MIX_CT(6144)
       FOURIER_MIX_CT(6561) FOURIER_MIX_CT(6912) FOURIER_MIX_CT(7776) FOURIER_MIX_CT(8748) FOURIER_MIX_CT(9216) FOURIER_MIX_CT(10368)
       FOURIER_MIX_CT(11664) FOURIER_MIX_CT(13122) FOURIER_MIX_CT(13824) FOURIER_MIX_CT(15552) FOURIER_MIX_CT(17496)
-      FOURIER_MIX_CT(18432)
+      FOURIER_MIX_CT(18432) FOURIER_MIX_CT(19683)
       // beyond the reference: every 2^a * 3^b * 5^c (c >= 1) up to MAX_N -- among them the reference's own benchmark lengths
       // 5^3 .. 5^5 (fft_bench.rs:156) -- and the powers of 7; other lengths with factors 7, 11, 13 take the runtime kernel
       FOURIER_MIX_CT(10) FOURIER_MIX_CT(25) FOURIER_MIX_CT(100) FOURIER_MIX_CT(125) FOURIER_MIX_CT(625) FOURIER_MIX_CT(1000)
@@ -1024,7 +1026,8 @@ template <typename T> class MixedEngine {
       FOURIER_MIX_CT(11250) FOURIER_MIX_CT(11520) FOURIER_MIX_CT(12000) FOURIER_MIX_CT(12150) FOURIER_MIX_CT(12500)
       FOURIER_MIX_CT(12800) FOURIER_MIX_CT(12960) FOURIER_MIX_CT(13500) FOURIER_MIX_CT(14400) FOURIER_MIX_CT(14580)
       FOURIER_MIX_CT(15000) FOURIER_MIX_CT(15360) FOURIER_MIX_CT(16000) FOURIER_MIX_CT(16200) FOURIER_MIX_CT(16875)
-      FOURIER_MIX_CT(17280) FOURIER_MIX_CT(18000) FOURIER_MIX_CT(18225) FOURIER_MIX_CT(2401)
+      FOURIER_MIX_CT(17280) FOURIER_MIX_CT(18000) FOURIER_MIX_CT(18225) FOURIER_MIX_CT(18750) FOURIER_MIX_CT(19200)
+      FOURIER_MIX_CT(19440) FOURIER_MIX_CT(20000) FOURIER_MIX_CT(20250) FOURIER_MIX_CT(20480) FOURIER_MIX_CT(2401)
 #endif
       default: break;
     }
@@ -1066,7 +1069,7 @@ template <typename T> class MixedEngine {
     const Kernel k = pick_kernel(n);
     fn_ = k.fn; group_ = k.group; nbuf_ = k.nbuf; threads_ = k.threads;
     smem_ = nbuf_ * (size_t)group_ * n * sizeof(cpx<T>);
-    if (smem_ > 144 * 1024) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "mixed-radix length needs the per-length kernel");
+    if (smem_ > MAX_LDS) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "mixed-radix length needs the per-length kernel");
     raise_smem_limit((const void*)fn_, smem_);
   }
   std::string describe() const {
@@ -1232,14 +1235,23 @@ template <typename T> class Plan {
       // big-radix passes over the 2^a part (a >= 12), then a radix-3^b pass: three HBM round trips at full tile
       // efficiency beat the one-workgroup-per-CU LDS kernel where both apply (3*2^12 f32: 23 % vs 14 %)
       eng_.reset(new Pow2Engine<T>(n));
-    } else if (MixedEngine<T>::handles(n)) {
-      mix_.reset(new MixedEngine<T>(n));
+    } else if (MixedEngine<T>::handles(n) && try_mixed(n)) {
     } else if (GenericEngine<T>::handles(n)) {
       gen_.reset(new GenericEngine<T>(n));
     } else {
       init_bluestein();
     }
     refresh_desc();
+  }
+  // the longest LDS plans ask for the whole 160 KiB of a CU: where the runtime refuses, the next route takes the length
+  bool try_mixed(size_t n) {
+    try { mix_.reset(new MixedEngine<T>(n)); return true; }
+    catch (const EngineError& e) {
+      if (e.status == ::fourier::c::FOURIER_HIP_OUT_OF_MEMORY) throw;
+      (void)hipGetLastError();
+      mix_.reset();
+      return false;
+    }
   }
   void refresh_desc() {
     if (mix_) desc_ = "stockham mixed-radix " + mix_->describe();

@@ -165,6 +165,7 @@ def test_mixed_radix_sizes_are_bit_identical_to_the_oracle(fa, oracle):
                 assert np.array_equal(run_batch(plan, x.astype(dtype), code), ref), (n, dtype, code)
                 assert np.array_equal(run_batch(plan, x.astype(dtype), code, inplace=True), ref), (n, dtype, code)
     assert "mixed-radix" in make(fa, 18432, np.complex64).describe()  # one in-place LDS buffer of 144 KiB
+    assert "mixed-radix" in make(fa, 19683, np.complex64).describe()  # 3^9: 154 of the 160 KiB
     assert "mixed-radix" in make(fa, 9216, np.complex128).describe()
     assert "global-pass" in make(fa, 10368, np.complex128).describe()   # f64: above the LDS-resident limit (9216): pass by pass in global memory
     assert "x3" in make(fa, 12288, np.complex64).describe()           # 3*2^12: tiled passes + odd pass, not the LDS kernel

@@ -8,7 +8,7 @@ from fourier_amd import fft as F
 from gpu_sweep import time_plan
 dev = torch.device("cuda", 0)
 for real, esz, cdt in (("f32", 8, torch.complex64), ("f64", 16, torch.complex128)):
-    for n in (4, 8, 16, 32, 64, 128, 256, 512, 12, 96, 243, 729, 768, 1536, 2187, 3072, 4374, 4608, 6561, 9216, 4095, 100, 191, 1000, 1013, 3125, 5000, 6144, 10007):
+    for n in (4, 8, 16, 32, 64, 128, 256, 512, 12, 96, 243, 729, 768, 1536, 2187, 3072, 4374, 4608, 6561, 9216, 13122, 18432, 100, 125, 625, 1000, 3125, 5000, 10000, 15625, 343, 2401, 1001, 4095, 5005, 191, 1013, 4097, 6144, 10007):
         bb = max(1, min((2 << 30) // (n * esz), 1 << 22))
         xs = torch.empty((bb, n), dtype=cdt, device=dev); torch.view_as_real(xs).uniform_(0, 1); ys = torch.empty_like(xs)
         plan = (F.create_fft_f32 if real == "f32" else F.create_fft_f64)(n, 0)
