@@ -958,7 +958,7 @@ template <typename T> class MixedEngine {
     if (size == 0 || size > MAX_N) return false;
     for (size_t cur = size; cur > 1;) {
       const uint32_t r = mix_next_radix((uint32_t)size, (uint32_t)cur, cur == size);  // the kernels' own schedule
-      if (cur % r) return false;
+      if (cur % r || radices.size() == sizeof(MixArgs{}.radix)) return false;
       radices.push_back(r);
       cur /= r;
     }

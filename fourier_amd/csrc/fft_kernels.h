@@ -2084,6 +2084,12 @@ template <typename T> constexpr uint32_t mix_group(uint32_t n) { return 1024 / n
 // would idle, and half-size workgroups put twice as many chains on a CU (243: 50 -> 61 % of the HBM peak, 625: 43 -> 59 %,
 // 729: 40 -> 54 %, 768: 46 -> 60 %; lengths with 200+ items per pass lose 3-12 points, every f64 length loses; 64 threads
 // never beat 128; r03_s24_mixed_radix_threads_per_workgroup_ab.jsonl)
+// (512 threads for the transforms between 16 KiB and the 1024-thread threshold: measured, no -- 2187 f32 56 -> 46 %, f64
+// 1152 / 2000 53 / 55 -> 45 / 46 %, 4000 f32 46 -> 51 % the only gain; r03_s26_mixed_radix_mid_sizes_512_threads_ab.jsonl)
+#ifndef FOURIER_MIX_MID_THREADS
+#define FOURIER_MIX_MID_THREADS 256u
+#define FOURIER_MIX_MID_MIN_BYTES 16384u
+#endif
 #ifndef FOURIER_MIX_HALF_MAX_ITEMS
 #define FOURIER_MIX_HALF_MAX_ITEMS 190u
 #endif
@@ -2103,7 +2109,8 @@ template <typename T> constexpr uint32_t mix_mean_items(uint32_t n) {
 }
 template <typename T> constexpr uint32_t mix_threads(uint32_t n) {
   return (mix_extended(n) ? n * 2u * (uint32_t)sizeof(T) > FOURIER_MIX_WIDE_MIN_BYTES : n > FOURIER_MIX_WIDE_MIN_N) ? 1024u
-         : ((sizeof(T) == 4 && mix_mean_items<T>(n) <= FOURIER_MIX_HALF_MAX_ITEMS) ? 128u : 256u);
+         : ((sizeof(T) == 4 && mix_mean_items<T>(n) <= FOURIER_MIX_HALF_MAX_ITEMS) ? 128u
+         : (n * 2u * (uint32_t)sizeof(T) > FOURIER_MIX_MID_MIN_BYTES ? FOURIER_MIX_MID_THREADS : 256u));
 }
 // Every pass runs IN PLACE on one LDS buffer: a thread keeps the outputs of all its butterflies of a pass in
 // registers across a barrier, then writes them back to the buffer it read from.  Same arithmetic as the ping-pong

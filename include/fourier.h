@@ -87,8 +87,11 @@ enum {
 };
 
 /* Create a plan on a specific device (-1 = current device).  Same plan factory as
- * `create_fft_f32/f64` (fourier/src/lib.rs:31-60): Stockham for power-of-two sizes, Bluestein
- * chirp-z (fourier-algorithms/src/bluesteins.rs) for every other size.  NULL on failure. */
+ * `create_fft_f32/f64` (fourier/src/lib.rs:31-60) with one extension: Stockham autosort for 2^a * 3^b as in the reference
+ * (`Autosort::new`, autosort/mod.rs:104-134), and -- where the reference takes Bluestein -- also for lengths whose prime
+ * factors stop at 13 and that fit a compute unit's LDS (<= 20480 points in f32, 10240 in f64); Bluestein chirp-z
+ * (fourier-algorithms/src/bluesteins.rs) for every other size.  `fourier_hip_describe_*` names the route taken.
+ * NULL on failure. */
 struct fourier_fft_float *fourier_hip_create_float(FOURIER_SIZE_TYPE size, int device);
 struct fourier_fft_double *fourier_hip_create_double(FOURIER_SIZE_TYPE size, int device);
 

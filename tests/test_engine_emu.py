@@ -144,7 +144,7 @@ def test_lengths_with_prime_factors_5_to_13_run_as_stockham_passes(fa, oracle):
                 assert np.array_equal(run_batch(plan, xs, code, inplace=True), got), (n, code)
             assert rel_l2(run_batch(plan, xs, 0), np.fft.fft(xs.astype(np.complex128), axis=1)) <= ttruth, n
     assert "bluestein" in make(fa, 17 * 64, np.complex64).describe()      # a factor above 13
-    assert "bluestein" in make(fa, 20000, np.complex64).describe()        # beyond the LDS kernels (for now)
+    assert "bluestein" in make(fa, 21000, np.complex64).describe()        # 2^3*3*5^3*7: beyond the 160 KiB of LDS
     assert "bluestein" in make(fa, 9100, np.complex64).describe()         # no per-length kernel, beyond the runtime kernel's 8192 points
 
 
@@ -266,8 +266,8 @@ def test_bluestein_conv_kernel_matches_separate_passes(fa, oracle):
     Where the pass lengths are a palindrome (256x256) the same plan serves both directions and the values
     are bit-identical to the separate-pass form; otherwise the inverse runs the mirrored plan (512x256 forward,
     256x512 inverse) and agrees to rounding.  Both stay within the oracle tolerance."""
-    for n, dtype, exact, tol in ((20000, np.complex64, True, 2e-6), (40000, np.complex64, False, 2e-6),
-                                 (10000, np.complex128, False, 5e-11), (70001, np.complex128, True, 5e-11)):
+    for n, dtype, exact, tol in ((20002, np.complex64, True, 2e-6), (40000, np.complex64, False, 2e-6),
+                                 (10001, np.complex128, False, 5e-11), (70001, np.complex128, True, 5e-11)):
         x = np.stack([hash_normal(7 + b, n) for b in range(2)]).astype(dtype)
         conv, plain = make(fa, n, dtype), make(fa, n, dtype)
         plain.set_option("bluestein_conv", 0)

@@ -235,9 +235,9 @@ def test_bluestein_fusion_matches_unfused(torch, fa):
             assert np.array_equal(gpu_batch(torch, fa, fused, x, code, inplace=True), a), (n, code)
 
 
-@pytest.mark.parametrize("n,dtype,tol", [(20000, np.complex64, 2e-6), (40000, np.complex64, 2e-6), (65537, np.complex64, 2e-6),
+@pytest.mark.parametrize("n,dtype,tol", [(20002, np.complex64, 2e-6), (40000, np.complex64, 2e-6), (65537, np.complex64, 2e-6),
                                          (999983, np.complex64, 2e-6), (2200000, np.complex64, 2e-6),
-                                         (10000, np.complex128, 5e-11), (70001, np.complex128, 5e-11),
+                                         (10001, np.complex128, 5e-11), (70001, np.complex128, 5e-11),
                                          (999983, np.complex128, 1e-9)])
 def test_bluestein_conv_kernel_vs_separate_passes_and_oracle(torch, fa, oracle, n, dtype, tol):
     """Large Bluestein: last forward pass + (.) w + first inverse pass in one launch (conv_pass) against the
