@@ -87,6 +87,12 @@ enum { IO_PLAIN = 0, IO_BLU_IN = 1, IO_BLU_OUT = 2 };
 #endif
 //   FOURIER_SPLIT_THRESHOLD: exchange buffers above this many bytes are exchanged as two planes (re, im):
 //   half the LDS per workgroup, twice the workgroups per CU (16 KiB measured best over 2^8..2^20, r01 sweep)
+//   FOURIER_ROWS_STAGED: the shortest whole-transform kernels (f32 64, f64 32) move their data between global memory and
+//     registers through LDS (16-byte units, whole lines per instruction) instead of element accesses that cover
+//     32 bytes of a line per instruction.
+#ifndef FOURIER_ROWS_STAGED
+#define FOURIER_ROWS_STAGED 1
+#endif
 #ifndef FOURIER_SPLIT_THRESHOLD
 #define FOURIER_SPLIT_THRESHOLD (16 * 1024)
 #endif
@@ -367,7 +373,15 @@ template <typename T, int L, int CG> struct TileCfg {
   static constexpr size_t SMEM_FIRST = TABU_OFF + TABU_BYTES;
   static constexpr size_t TABV_BYTES = (size_t)COLS * 8 * sizeof(cpx<T>);  // chirp-in first pass: cross-term table behind tabU
   static constexpr size_t SMEM_MID = TABU_OFF + 16 * sizeof(cpx<T>);
-  static constexpr size_t SMEM_PLAIN = EXCH_BYTES;
+  // MODE_ROWS where the Q lanes of a transform cover no more than 32 bytes of a line per access (f32 L = 64, f64 L = 32)
+  // stages its global I/O through LDS, half a tile (COLS / 2 whole transforms) at a time, element (c, p) at
+  // c * STAGE_LP + p (pass_tile).  The pad keeps the gather of a half-wave (th + Q*r at fixed r) on distinct banks.
+  // Measured (r03_s28_rows_staged_io_ab.jsonl): f32 64 51 -> 62 % of the HBM peak, f64 32 58 -> 64 %; with 64-byte pieces
+  // and wider the element form is as good or better (f32 128 64 / 63 %, f64 64 64 / 59 %, f64 128 72 / 59 %).
+  static constexpr bool ROWS_STAGED = (FOURIER_ROWS_STAGED != 0) && Q >= 2 && Q * 2 * (int)sizeof(T) <= 32;
+  static constexpr int STAGE_LP = L + 4;
+  static constexpr size_t STAGE_BYTES = ROWS_STAGED ? (size_t)(COLS / 2) * STAGE_LP * 2 * sizeof(T) : 0;
+  static constexpr size_t SMEM_PLAIN = EXCH_BYTES > STAGE_BYTES ? EXCH_BYTES : STAGE_BYTES;
   static __host__ __device__ constexpr size_t smem_bytes(int mode) {
     return mode == MODE_FIRST ? SMEM_FIRST : (mode == MODE_MID ? SMEM_MID : SMEM_PLAIN);
   }
@@ -735,7 +749,37 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
 
   // ---- load: register r <- row th + Q*r
   cpx<T> x[VEC][16];
-  if constexpr (IN_ROWS) {
+  constexpr bool STAGED = IN_ROWS && C::ROWS_STAGED;
+  // staged rows: thread (th, cg) owns transform v*CG + cg of the tile (not cg*VEC + v), so that each half of the tile --
+  // v = 0 / v = 1 in f32, cg below / above CG/2 in f64 -- is one contiguous run of COLS/2 transforms
+  constexpr int HALF = COLS / 2, LP = C::STAGE_LP;
+  uint32_t stage_valid = 0;  // elements of this tile that exist (the last tile of a batch may be ragged)
+  if constexpr (STAGED) {
+    const uint64_t left = a.total_cols > g0 ? a.total_cols - g0 : 0;
+    stage_valid = (uint32_t)(left < (uint64_t)COLS ? left : (uint64_t)COLS) * (uint32_t)L;
+    cpx<T>* stage = (cpx<T>*)smem;
+    const cpx<T>* src = in + g0 * L;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      for (int u = tid; u < HALF * L / VEC; u += C::NT) {
+        const uint32_t eh = (uint32_t)u * VEC, e = (uint32_t)(h * HALF * L) + eh;
+        Unit16<T> w{};
+        if (e < stage_valid) w = load_unit_a8<T>(src + e);
+        *(Unit16<T>*)(stage + (eh / L) * LP + (eh % L)) = w;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const int col = v * CG + cg;
+        if (col / HALF == h) {
+          const cpx<T>* p = stage + (col % HALF) * LP + th;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) x[v][r] = p[Q * r];
+        }
+      }
+      __syncthreads();
+    }
+  } else if constexpr (IN_ROWS) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       const uint64_t g = g0 + (uint64_t)(cg * VEC + v);
@@ -857,7 +901,33 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
   // ---- store
   before_store();
   const T scale = (T)a.scale;
-  if constexpr (OUT_ROWS) {
+  if constexpr (STAGED) {
+    cpx<T>* stage = (cpx<T>*)smem;
+    cpx<T>* dst = out + g0 * L;
+    __syncthreads();  // the last exchange's readers are done with the buffer
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const int col = v * CG + cg;
+        if (col / HALF == h) {
+          cpx<T>* p = stage + (col % HALF) * LP + th;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            cpx<T> y = x[v][r];
+            if (a.swap_out) y = {y.im, y.re};
+            p[Q * r] = {y.re * scale, y.im * scale};
+          }
+        }
+      }
+      __syncthreads();
+      for (int u = tid; u < HALF * L / VEC; u += C::NT) {
+        const uint32_t eh = (uint32_t)u * VEC, e = (uint32_t)(h * HALF * L) + eh;
+        if (e < stage_valid) store_unit_a8<T>(dst + e, *(const Unit16<T>*)(stage + (eh / L) * LP + (eh % L)));
+      }
+      __syncthreads();
+    }
+  } else if constexpr (OUT_ROWS) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       const uint64_t g = g0 + (uint64_t)(cg * VEC + v);

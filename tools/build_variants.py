@@ -56,6 +56,7 @@ VARIANTS = {
     "mix_pair5_none": ["-DFOURIER_MIX_PAIR5_MIN_N_F32=1000000u", "-DFOURIER_MIX_PAIR5_MIN_N_F64=1000000u"],
     "mix_pair5_all": ["-DFOURIER_MIX_PAIR5_MIN_N_F32=25u", "-DFOURIER_MIX_PAIR5_MIN_N_F64=25u"],
     "mix_wide_16k": ["-DFOURIER_MIX_WIDE_MIN_BYTES=16384u"],
+    "rows_unstaged": ["-DFOURIER_ROWS_STAGED=0"],
     "mix_mid512": ["-DFOURIER_MIX_MID_THREADS=512u", "-DFOURIER_MIX_MID_MIN_BYTES=16384u"],
     "mix_half_none": ["-DFOURIER_MIX_HALF_MAX_ITEMS=0u"],
     "mix_half_250": ["-DFOURIER_MIX_HALF_MAX_ITEMS=250u"],
