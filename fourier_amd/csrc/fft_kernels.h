@@ -23,8 +23,9 @@
 //   fft_twolevel_kernel<T, L1, L2>        2^11..2^15: both passes inside one workgroup
 //   bluestein_small_kernel / bluestein_rows_kernel   whole chirp-z in one launch for M <= 2^15
 //   tiny_shfl_kernel<T, N>                N <= 16 (f32: 32): one lane per transform, wave-shuffle unit transpose
-//   mixed_radix_kernel_ct<T, N>           2^a*3^b in LDS with the reference's schedule, one instantiation per length
-//   mixed_radix_kernel<T, MAXP, PPT>      the same, runtime-parameterised: lengths with factors 5..13 that have no per-length kernel
+//   mixed_radix_kernel_ct<T, N>           2^a*3^b in LDS with the reference's schedule, one instantiation per length; also
+//                                         every 2^a*3^b*5^c and 7^k (radices 5, 7: beyond the reference, which takes Bluestein)
+//   mixed_radix_kernel<T, MAXP, PPT, NT>  the same passes, runtime-parameterised: the other lengths with factors 5..13 up to 8192 points
 //   odd_last_kernel<T, R>                 radix-3/9/27 passes (twiddled middle ones and the final one) of the large 2^a*3^b sizes
 //   stockham_pass_kernel<T, R>            one pass in global memory, any radix and stride: 2^a*3^b with a < 12 beyond the LDS limit
 //   blu_pre_kernel / blu_post_kernel      unfused chirp sweeps (option bluestein_fusion = 0)
@@ -1993,7 +1994,7 @@ __device__ __forceinline__ void mixed_pass(cpx<T>* __restrict__ buf, const cpx<T
 // The second launch bound (waves per SIMD) is what makes hipcc economise: left at 128 threads and no bound it spends 119
 // VGPRs on the f32 radix-7 instantiation, which halves the resident workgroups of a latency-bound kernel.
 #ifndef FOURIER_MIX_RT_WAVES
-#define FOURIER_MIX_RT_WAVES(T, MAXP, PPT) ((sizeof(T) == 4 ? ((MAXP) <= 7 ? ((PPT) <= 4 ? 6 : 5) : 4) : ((MAXP) <= 7 ? ((PPT) <= 4 ? 4 : 3) : 2)))
+#define FOURIER_MIX_RT_WAVES(T, MAXP, PPT) ((sizeof(T) == 4 ? ((MAXP) <= 7 ? ((PPT) <= 4 ? 6 : ((PPT) <= 8 ? 5 : 4)) : 4) : ((MAXP) <= 7 ? ((PPT) <= 4 ? 4 : ((PPT) <= 8 ? 3 : 4)) : 2)))
 #endif
 template <typename T, int MAXP, int PPT, int NT>
 __global__ void __launch_bounds__(NT, FOURIER_MIX_RT_WAVES(T, MAXP, PPT)) mixed_radix_kernel(MixArgs a) {
