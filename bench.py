@@ -124,6 +124,36 @@ def roofline_of(plan, kernels, batch, alg_bytes_per, dtype, whole_path_frac, tra
     }
 
 
+def reference_bench_sizes(fourier_amd, torch, dev, bytes_per_size=1 << 30):
+    """The reference's own criterion size sets (fourier-bench/benches/fft_bench.rs:153-159: powers of two / three / five,
+    composites, primes), device-resident and batched, f32 forward: plan, time per transform, fraction of the HBM peak on the
+    algorithmic bytes.  A fraction of a second in total; informative (the reference times one host transform per call)."""
+    from fourier_amd import Transform
+
+    rows = []
+    for scenario, sizes in (("pow2", (256, 512, 1024)), ("pow3", (243, 729, 2187)), ("pow5", (125, 625, 3125)),
+                            ("composite", (222, 722, 1418)), ("prime", (191, 439, 1013))):
+        for n in sizes:
+            batch = max(1, bytes_per_size // (n * 8))
+            plan = make_plan(fourier_amd, n, "f32", dev.index)
+            x = torch.empty((batch, n), dtype=torch.complex64, device=dev)
+            torch.view_as_real(x).uniform_(0.0, 1.0)
+            y = torch.empty_like(x)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            ts = []
+            for it in range(5):
+                t0 = time.perf_counter()
+                plan.transform_batch_ptr(x.data_ptr(), y.data_ptr(), batch, int(Transform.Fft), stream)
+                torch.cuda.synchronize(dev)
+                if it >= 2:
+                    ts.append(time.perf_counter() - t0)
+            t = sorted(ts)[len(ts) // 2]
+            rows.append({"scenario": scenario, "n": n, "plan": plan.describe(), "batch": batch, "ns_per_transform": round(t / batch * 1e9, 2),
+                         "hbm_frac_algorithmic": round(batch * 16.0 * n / t / 1e9 / HBM_PEAK_GBPS, 4)})
+            del x, y, plan
+    return rows
+
+
 def quick_config(fourier_amd, torch, dev, key, reps=3):
     """A few seconds on another BASELINE config (N=1 only): median of `reps` timed steps + kernel profile."""
     from fourier_amd import Transform
@@ -536,6 +566,11 @@ def main():
                 except Exception as e:  # never lose the headline line to a secondary config
                     others[k] = {"error": repr(e)}
                     torch.cuda.empty_cache()
+            try:
+                torch.cuda.empty_cache()
+                others["reference_bench_sizes_f32"] = reference_bench_sizes(fourier_amd, torch, dev)
+            except Exception as e:
+                others["reference_bench_sizes_f32"] = {"error": repr(e)}
             out["other_configs"] = others
         print(json.dumps(out), flush=True)
 
