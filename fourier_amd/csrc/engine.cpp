@@ -1000,7 +1000,7 @@ template <typename T> class MixedEngine {
       FOURIER_MIX_CT(11664) FOURIER_MIX_CT(13122) FOURIER_MIX_CT(13824) FOURIER_MIX_CT(15552) FOURIER_MIX_CT(17496)
       FOURIER_MIX_CT(18432) FOURIER_MIX_CT(19683)
       // beyond the reference: every 2^a * 3^b * 5^c (c >= 1) up to MAX_N -- among them the reference's own benchmark lengths
-      // 5^3 .. 5^5 (fft_bench.rs:156) -- and the powers of 7; other lengths with factors 7, 11, 13 take the runtime kernel
+      // 5^3 .. 5^5 (fft_bench.rs:156) -- the powers of 7 and a selection of lengths with a factor 7; other lengths with factors 7, 11, 13 take the runtime kernel
       FOURIER_MIX_CT(10) FOURIER_MIX_CT(25) FOURIER_MIX_CT(100) FOURIER_MIX_CT(125) FOURIER_MIX_CT(625) FOURIER_MIX_CT(1000)
       FOURIER_MIX_CT(3125) FOURIER_MIX_CT(5000) FOURIER_MIX_CT(8000) FOURIER_MIX_CT(10000) FOURIER_MIX_CT(15625) FOURIER_MIX_CT(49) FOURIER_MIX_CT(343) FOURIER_MIX_CT(16807)
 #ifndef FOURIER_EMU  // the CPU emulation build keeps the subset above (compile time); its other lengths run the runtime kernel
@@ -1028,6 +1028,16 @@ template <typename T> class MixedEngine {
       FOURIER_MIX_CT(15000) FOURIER_MIX_CT(15360) FOURIER_MIX_CT(16000) FOURIER_MIX_CT(16200) FOURIER_MIX_CT(16875)
       FOURIER_MIX_CT(17280) FOURIER_MIX_CT(18000) FOURIER_MIX_CT(18225) FOURIER_MIX_CT(18750) FOURIER_MIX_CT(19200)
       FOURIER_MIX_CT(19440) FOURIER_MIX_CT(20000) FOURIER_MIX_CT(20250) FOURIER_MIX_CT(20480) FOURIER_MIX_CT(2401)
+      // a selection with a factor 7: 7 * 2^k, the highly composite 840 / 1260 / 1680 / 2520 / 5040 / 10080 and their kin
+      FOURIER_MIX_CT(14) FOURIER_MIX_CT(21) FOURIER_MIX_CT(28) FOURIER_MIX_CT(35) FOURIER_MIX_CT(42) FOURIER_MIX_CT(56)
+      FOURIER_MIX_CT(63) FOURIER_MIX_CT(70) FOURIER_MIX_CT(84) FOURIER_MIX_CT(105) FOURIER_MIX_CT(112) FOURIER_MIX_CT(126)
+      FOURIER_MIX_CT(140) FOURIER_MIX_CT(168) FOURIER_MIX_CT(210) FOURIER_MIX_CT(224) FOURIER_MIX_CT(252) FOURIER_MIX_CT(280)
+      FOURIER_MIX_CT(315) FOURIER_MIX_CT(336) FOURIER_MIX_CT(420) FOURIER_MIX_CT(448) FOURIER_MIX_CT(504) FOURIER_MIX_CT(560)
+      FOURIER_MIX_CT(630) FOURIER_MIX_CT(672) FOURIER_MIX_CT(840) FOURIER_MIX_CT(896) FOURIER_MIX_CT(1008) FOURIER_MIX_CT(1120)
+      FOURIER_MIX_CT(1260) FOURIER_MIX_CT(1344) FOURIER_MIX_CT(1680) FOURIER_MIX_CT(1792) FOURIER_MIX_CT(2016)
+      FOURIER_MIX_CT(2240) FOURIER_MIX_CT(2520) FOURIER_MIX_CT(2688) FOURIER_MIX_CT(3360) FOURIER_MIX_CT(3584)
+      FOURIER_MIX_CT(4480) FOURIER_MIX_CT(5040) FOURIER_MIX_CT(5376) FOURIER_MIX_CT(6720) FOURIER_MIX_CT(7168)
+      FOURIER_MIX_CT(8960) FOURIER_MIX_CT(10080) FOURIER_MIX_CT(14336) FOURIER_MIX_CT(17920)
 #endif
       default: break;
     }
