@@ -2222,7 +2222,10 @@ template <typename T, uint32_t N, uint32_t SIZE, uint32_t STRIDE, uint32_t TWOFF
 #pragma unroll
       for (uint32_t k2 = 0; k2 < R; ++k2)
 #pragma unroll
-        for (uint32_t k1 = 0; k1 < R; ++k1) x[k2][k1] = in[STRIDE * (M2 * k2 + M * k1)];
+        for (uint32_t k1 = 0; k1 < R; ++k1) {
+          LDS_NOTE(in + STRIDE * (M2 * k2 + M * k1), sizeof(cpx<T>), false, 100);
+          x[k2][k1] = in[STRIDE * (M2 * k2 + M * k1)];
+        }
 #pragma unroll
       for (uint32_t k2 = 0; k2 < R; ++k2) {
         ref_butterfly<T, (int)R>(x[k2], fwd, w3, w8);
@@ -2252,7 +2255,10 @@ template <typename T, uint32_t N, uint32_t SIZE, uint32_t STRIDE, uint32_t TWOFF
       }
     } else {
 #pragma unroll
-      for (uint32_t k = 0; k < R; ++k) y[k] = in[STRIDE * M * k];
+      for (uint32_t k = 0; k < R; ++k) {
+        LDS_NOTE(in + STRIDE * M * k, sizeof(cpx<T>), false, 101);
+        y[k] = in[STRIDE * M * k];
+      }
       ref_butterfly<T, (int)R>(y, fwd, w3, w8);
       if constexpr (SIZE != R) {  // mod.rs:238,272
 #pragma unroll
@@ -2283,7 +2289,10 @@ template <typename T, uint32_t N, uint32_t SIZE, uint32_t STRIDE, uint32_t TWOFF
         const uint32_t q = threadIdx.x + NT * rd;
         if (q < nb * NBF) {
 #pragma unroll
-          for (uint32_t k = 0; k < PTS; ++k) buf[off[rd] + STRIDE * k] = y[rd][k];
+          for (uint32_t k = 0; k < PTS; ++k) {
+            LDS_NOTE(buf + off[rd] + STRIDE * k, sizeof(cpx<T>), true, 102);
+            buf[off[rd] + STRIDE * k] = y[rd][k];
+          }
         }
       }
       __syncthreads();
