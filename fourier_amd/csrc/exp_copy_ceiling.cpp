@@ -1,0 +1,72 @@
+// exp_copy_ceiling.cpp -- what a plain device copy reaches on THIS box, for bench.py's roofline record (VERDICT round 3:
+// the denominator that explains "each pass at the streaming ceiling" must be measured in the same run on the same
+// buffers, not quoted from DESIGN.md).  Linked into lib/libfourier_experiments.so only: measurement tooling, not product.
+//
+// The copy has the pass kernels' memory shape without their arithmetic: every workgroup owns one contiguous slab, 16-byte
+// accesses, eight loads in flight per thread, and the XCD-aware block mapping of the passes (block b runs on XCD b % 8;
+// every XCD walks its own contiguous eighth of the buffer, so each 2 MiB page is touched by one XCD) -- the `slab_x` form of
+// tools/membench.hip, the best of the copy forms measured in round 2 (profiles/r02_membench.jsonl: 5.87 TB/s).
+#include "engine_common.h"
+#include "kernels_common.h"
+
+namespace fourier_hip {
+
+template <int U, bool NT>
+__global__ void __launch_bounds__(256) copy_slab_kernel(const void* __restrict__ src, void* __restrict__ dst, uint64_t units_per_block) {
+  uint64_t b = blockIdx.x;
+  const uint64_t per_xcd = gridDim.x / 8;
+  if (per_xcd * 8 == gridDim.x) b = (b % 8) * per_xcd + b / 8;
+  const Unit16<float>* s = (const Unit16<float>*)src + b * units_per_block;
+  Unit16<float>* d = (Unit16<float>*)dst + b * units_per_block;
+  for (uint64_t base = threadIdx.x; base < units_per_block; base += 256 * U) {
+    Unit16<float> v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = load_unit<float, NT>(s + base + u * 256);
+#pragma unroll
+    for (int u = 0; u < U; ++u) store_unit<float, NT>(d + base + u * 256, v[u]);
+  }
+}
+
+}  // namespace fourier_hip
+
+// Copies `bytes` (a multiple of bytes_per_block, itself a multiple of 32 KiB) from src to dst `reps` times on `stream` and
+// reports the mean milliseconds per copy between two HIP events on that stream.  nt != 0: streaming (non-temporal) loads
+// and stores, the cache policy of the pass kernels.  Returns a fourier_hip status code.
+extern "C" int fourier_exp_copy_ceiling(const void* src, void* dst, uint64_t bytes, uint64_t bytes_per_block, int nt, int reps,
+                                        void* stream, float* ms_per_copy) {
+  using namespace fourier_hip;
+  if (!src || !dst || !ms_per_copy || reps <= 0 || bytes_per_block == 0 || bytes_per_block % (256 * 8 * 16) || bytes % bytes_per_block ||
+      bytes / bytes_per_block > 0x7fffffffull)
+    return ::fourier::c::FOURIER_HIP_INVALID_ARGUMENT;
+#ifdef FOURIER_EMU
+  (void)nt; (void)stream;
+  *ms_per_copy = 0.0f;
+  return ::fourier::c::FOURIER_HIP_UNSUPPORTED;
+#else
+  try {
+    const hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)(bytes / bytes_per_block);
+    hipEvent_t a, b;
+    HIP_CHECK(hipEventCreate(&a));
+    HIP_CHECK(hipEventCreate(&b));
+    auto launch = [&] {
+      if (nt) copy_slab_kernel<8, true><<<blocks, 256, 0, st>>>(src, dst, bytes_per_block / 16);
+      else copy_slab_kernel<8, false><<<blocks, 256, 0, st>>>(src, dst, bytes_per_block / 16);
+    };
+    launch();  // warm-up (page tables, clocks)
+    HIP_CHECK(hipEventRecord(a, st));
+    for (int r = 0; r < reps; ++r) launch();
+    HIP_CHECK(hipEventRecord(b, st));
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipEventSynchronize(b));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *ms_per_copy = ms / (float)reps;
+    return ::fourier::c::FOURIER_HIP_OK;
+  } catch (const EngineError& e) {
+    return e.status;
+  }
+#endif
+}

@@ -1,0 +1,106 @@
+// mixed_schedule.h -- the schedule of the LDS mixed-radix kernels as compile-time functions of the transform length: radix
+// of each pass (autosort/mod.rs:20-21,104-116 for 2^a*3^b; continued for the factors 5..13), fused pass pairs, transforms
+// and threads per workgroup.  Shared by the kernels (kernels_mixed.h) and by the host, which builds the twiddle tables and
+// the launch shape from the same rules (engine_mixed.h).
+#pragma once
+#include <stdint.h>
+
+namespace fourier_hip {
+
+// The radix of the next pass of an n-point plan with `cur` points left to factor.  2^a*3^b: the reference's schedule,
+// one radix 4 first when divisible, then greedily 8, 4, 3, 2 (autosort/mod.rs:20-21,104-116).  Lengths with a prime factor
+// 5, 7, 11 or 13 are not the reference's to schedule (it sends them to Bluestein): odd radices first, largest first -- a
+// stride-1 pass writes with a lane stride of R elements, which only an odd R spreads over all LDS banks -- then greedily
+// 8, 4, 2, which never takes more passes than the reference's rule and one fewer when 2^a is a power of 8.
+#ifndef FOURIER_MIX_PRIMES_FIRST
+#define FOURIER_MIX_PRIMES_FIRST 1
+#endif
+constexpr bool mix_extended(uint32_t n) { return n % 5 == 0 || n % 7 == 0 || n % 11 == 0 || n % 13 == 0; }
+constexpr uint32_t mix_next_radix(uint32_t n, uint32_t cur, bool first) {
+  if (FOURIER_MIX_PRIMES_FIRST && mix_extended(n))
+    return cur % 13 == 0 ? 13u : (cur % 11 == 0 ? 11u : (cur % 7 == 0 ? 7u : (cur % 5 == 0 ? 5u : (cur % 3 == 0 ? 3u :
+           (cur % 8 == 0 ? 8u : (cur % 4 == 0 ? 4u : 2u))))));
+  return (first && cur % 4 == 0) ? 4u : (cur % 8 == 0 ? 8u : (cur % 4 == 0 ? 4u : (cur % 3 == 0 ? 3u : (cur % 2 == 0 ? 2u :
+         (cur % 5 == 0 ? 5u : (cur % 7 == 0 ? 7u : (cur % 11 == 0 ? 11u : 13u)))))));
+}
+
+// fused (3,3) pass pairs: for lengths with a factor 9; in f64 only from 1024 points on (below, the 18 extra VGPRs and
+// the idle threads cost more than the saved LDS round trip: 729 f64 53 % without, 42 % with; 2187 30 % / 33 %)
+#ifndef FOURIER_MIX_PAIR_MIN_N_F64
+#define FOURIER_MIX_PAIR_MIN_N_F64 1024u
+#endif
+// fused (5,5) pairs (lengths beyond the reference's), 25 points per work item: built and measured, off -- too few work
+// items per pass and 50+ live registers (f32 5000: 53 % of the HBM peak without, 33 % with; 10000: 48 / 33 %; f64 5000:
+// 55 / 31 %; only 12500 / 15625 gain, 33 -> 35-36 %; r03_s22)
+#ifndef FOURIER_MIX_PAIR5_MIN_N_F32
+#define FOURIER_MIX_PAIR5_MIN_N_F32 0xffffffffu
+#endif
+#ifndef FOURIER_MIX_PAIR5_MIN_N_F64
+#define FOURIER_MIX_PAIR5_MIN_N_F64 0xffffffffu
+#endif
+template <typename T> constexpr bool mix_pairs(uint32_t n, uint32_t r) {
+  return r == 3 ? (n % 9 == 0 && (sizeof(T) == 4 || n >= FOURIER_MIX_PAIR_MIN_N_F64))
+                : (r == 5 && n % 25 == 0 && n >= (sizeof(T) == 4 ? FOURIER_MIX_PAIR5_MIN_N_F32 : FOURIER_MIX_PAIR5_MIN_N_F64));
+}
+// transforms per workgroup: about 1024 points (16 KiB of LDS in f32).  More points per workgroup fill the 256
+// threads better but lose more in resident workgroups than they gain (N=243 f32: 49 % at 1152 points, 40 % at
+// 2304, 27 % at 4608; r01 session 13)
+template <typename T> constexpr uint32_t mix_group(uint32_t n) { return 1024 / n ? 1024 / n : 1; }
+// threads per workgroup: 256, and 1024 for one long transform per workgroup -- at 256 threads such a transform keeps 16+
+// points per thread live across the in-place barrier and one 4-wave workgroup per CU cannot hide the LDS latency.  Same
+// arithmetic, same bits.  2^a*3^b: above 4096 points (f32 9216: 29 -> 44 % of the HBM peak, 18432: 18 -> 34 %, f64 9216:
+// 22 -> 35 %; below, f64 2187 loses 45 -> 34 %).  Lengths with factors 5..13: above 32 KiB per transform (f32 10000: 28 -> 48 %;
+// f64 3125: 43 -> 57 %, 2500: 49 -> 57 %, but 2401: 45 -> 38 %; f32 from 16 KiB loses, 3125: 46 -> 28 %).  r03_s22.
+#ifndef FOURIER_MIX_WIDE_MIN_BYTES
+#define FOURIER_MIX_WIDE_MIN_BYTES 32768u
+#endif
+#ifndef FOURIER_MIX_WIDE_MIN_N
+#define FOURIER_MIX_WIDE_MIN_N 4096u
+#endif
+// ... and 128 threads in f32 where a pass has, on average, no more than FOURIER_MIX_HALF_MAX_ITEMS work items (butterflies or
+// butterfly pairs) per workgroup: these kernels are latency-bound chains of barrier-separated passes, most of 256 threads
+// would idle, and half-size workgroups put twice as many chains on a CU (243: 50 -> 61 % of the HBM peak, 625: 43 -> 59 %,
+// 729: 40 -> 54 %, 768: 46 -> 60 %; lengths with 200+ items per pass lose 3-12 points, every f64 length loses; 64 threads
+// never beat 128; r03_s24_mixed_radix_threads_per_workgroup_ab.jsonl)
+// (512 threads for the transforms between 16 KiB and the 1024-thread threshold: measured, no -- 2187 f32 56 -> 46 %, f64
+// 1152 / 2000 53 / 55 -> 45 / 46 %, 4000 f32 46 -> 51 % the only gain; r03_s26_mixed_radix_mid_sizes_512_threads_ab.jsonl)
+#ifndef FOURIER_MIX_MID_THREADS
+#define FOURIER_MIX_MID_THREADS 256u
+#define FOURIER_MIX_MID_MIN_BYTES 16384u
+#endif
+#ifndef FOURIER_MIX_HALF_MAX_ITEMS
+#define FOURIER_MIX_HALF_MAX_ITEMS 190u
+#endif
+template <typename T> constexpr uint32_t mix_mean_items(uint32_t n) {
+  uint32_t cur = n, passes = 0, items = 0;
+  const uint32_t pts_total = mix_group<T>(n) * n;
+  while (cur > 1) {
+    const uint32_t r = mix_next_radix(n, cur, cur == n);
+    if (cur % r) return 0xffffffffu;  // not a length these kernels factor
+    const bool pair = (r == 3 || r == 5) && cur >= r * r && (cur / r) % r == 0 && mix_pairs<T>(n, r);
+    const uint32_t pts = pair ? r * r : r;
+    items += pts_total / pts;
+    passes += 1;
+    cur /= pts;
+  }
+  return passes ? items / passes : 0xffffffffu;
+}
+template <typename T> constexpr uint32_t mix_threads(uint32_t n) {
+  return (mix_extended(n) ? n * 2u * (uint32_t)sizeof(T) > FOURIER_MIX_WIDE_MIN_BYTES : n > FOURIER_MIX_WIDE_MIN_N) ? 1024u
+         : ((sizeof(T) == 4 && mix_mean_items<T>(n) <= FOURIER_MIX_HALF_MAX_ITEMS) ? 128u
+         : (n * 2u * (uint32_t)sizeof(T) > FOURIER_MIX_MID_MIN_BYTES ? FOURIER_MIX_MID_THREADS : 256u));
+}
+// Every pass runs IN PLACE on one LDS buffer: a thread keeps the outputs of all its butterflies of a pass in
+// registers across a barrier, then writes them back to the buffer it read from.  Same arithmetic as the ping-pong
+// form; half the LDS, so twice the resident workgroups where LDS was the limit (N=6561 f32 16 -> 32 % of the HBM
+// peak, 2304 37 -> 51 %, f64 1152 46 -> 61 %) and no loss elsewhere (A/B over the threshold,
+// profiles/r01_s15_mixed_inplace_ab.txt).  FOURIER_MIX_INPLACE_BYTES > 0 restores ping-pong below that footprint.
+#ifndef FOURIER_MIX_INPLACE_BYTES
+#define FOURIER_MIX_INPLACE_BYTES 0u
+#endif
+template <typename T> constexpr bool mix_inplace(uint32_t n) {
+  return FOURIER_MIX_INPLACE_BYTES == 0u || 2u * mix_group<T>(n) * n * 2u * sizeof(T) > FOURIER_MIX_INPLACE_BYTES;
+}
+
+
+}  // namespace fourier_hip

@@ -1,19 +1,52 @@
 """TEST-ONLY: builds the engine sources against tests/emu/hipemu.h (CPU fibers) so kernel logic,
-plan logic and the C ABI can be exercised without a GPU.  Not a product path."""
+plan logic and the C ABI can be exercised without a GPU.  Not a product path.
+
+The same translation units as fourier_amd/build.py (host logic + one object per kernel family and precision), compiled
+with g++ -DFOURIER_EMU on all cores, linked with the experiments switches (env_experiments.cpp + kernels_experiments.cpp):
+the CPU tests drive the alternative plans through environment variables."""
+import concurrent.futures
 import ctypes
+import glob
 import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SRC = os.path.join(ROOT, "fourier_amd", "csrc", "engine.cpp")
-DEPS = [SRC, os.path.join(ROOT, "fourier_amd", "csrc", "fft_kernels.h"), os.path.join(HERE, "hipemu.h"),
-        os.path.join(ROOT, "include", "fourier.h")]
+CSRC = os.path.join(ROOT, "fourier_amd", "csrc")
 OUT = os.path.join(HERE, "libfourier_emu.so")
+OBJDIR = os.path.join(HERE, "obj")
+
+
+def deps():
+    return (glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.cpp")) +
+            [os.path.join(HERE, "hipemu.h"), os.path.join(ROOT, "include", "fourier.h")])
+
+
+def compile_and_link(out):
+    from fourier_amd import build as B
+
+    os.makedirs(OBJDIR, exist_ok=True)
+    newest_header = max(os.path.getmtime(d) for d in deps() if d.endswith(".h"))
+    jobs, objs = [], []
+    for name, src, defs, group in B.translation_units():
+        if group in B.PRODUCT_ONLY:
+            continue
+        srcp = os.path.join(CSRC, src)
+        obj = os.path.join(OBJDIR, name + ".o")
+        objs.append(obj)
+        if os.path.exists(obj) and os.path.getmtime(obj) >= max(newest_header, os.path.getmtime(srcp)):
+            continue
+        jobs.append(["g++", "-O2", "-std=c++17", "-DFOURIER_EMU", "-include", os.path.join(HERE, "hipemu.h"), "-fPIC", "-pthread"] + defs +
+                    ["-c", srcp, "-o", obj])
+    with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, os.cpu_count() or 1)) as ex:
+        for rc in ex.map(lambda cmd: subprocess.call(cmd), jobs):
+            if rc:
+                raise RuntimeError("emulator build failed")
+    subprocess.check_call(["g++", "-shared", "-pthread", "-o", out] + objs)
 
 
 def build():
-    fresh = lambda: os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS)  # noqa: E731
+    fresh = lambda: os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps())  # noqa: E731
     if fresh():
         return OUT
     import fcntl
@@ -22,8 +55,7 @@ def build():
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not fresh():
             tmp = OUT + f".{os.getpid()}.tmp"
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFOURIER_EMU", "-DFOURIER_EXPERIMENTS", "-include", os.path.join(HERE, "hipemu.h"),
-                                   "-shared", "-fPIC", "-pthread", "-o", tmp, SRC])
+            compile_and_link(tmp)
             os.replace(tmp, OUT)
     return OUT
 

@@ -694,3 +694,22 @@ def test_empty_batch_is_a_successful_no_op_for_every_plan_family(fa):
         assert L.fourier_hip_reserve_float(plan._h, 0, 1) == 0, n
         assert L.fourier_hip_last_status_float(plan._h) == 0
         assert (buf == 7 + 7j).all(), n
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_a_non_finite_transform_does_not_reach_its_neighbours(fa, oracle, dtype):
+    """Transforms of a batch are independent (the reference runs one plan call per transform, fft.rs:51-61): a row of NaN /
+    Inf poisons its own output only.  Covers every plan family that puts several transforms into one workgroup or pads a
+    transform (the one-launch chirp-z read its padding from the next transform's row and relied on 0 * x)."""
+    for n in (8, 17, 64, 96, 127, 439, 625, 1000, 1013, 2048, 3001):
+        batch = 6
+        x = np.stack([hash_normal(900 + b, n) for b in range(batch)]).astype(dtype)
+        ref = oracle.transform_batch(x, 0)
+        for bad_row, bad in ((1, np.nan), (batch - 1, np.inf), (0, -np.inf)):
+            xb = x.copy()
+            xb[bad_row, n // 2] = bad
+            got = run_batch(make(fa, n, dtype), xb, 0)
+            keep = [b for b in range(batch) if b != bad_row]
+            assert np.isfinite(got[keep]).all(), (n, bad_row)
+            assert rel_l2(got[keep], ref[keep]) <= (2e-6 if dtype == np.complex64 else 2e-12), (n, bad_row)
+            assert not np.isfinite(got[bad_row]).all(), (n, bad_row)

@@ -1032,3 +1032,24 @@ def test_a_single_transform_of_4_gib_addresses_correctly(torch, fa, dtype, log2n
     torch.cuda.synchronize()
     err = float((torch.view_as_real(y) - xr).abs().max())
     assert err < (2e-5 if dtype == np.complex64 else 1e-12), err
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_a_non_finite_transform_does_not_reach_its_neighbours(torch, fa, oracle, dtype):
+    """Transforms of a batch are independent (fft.rs:51-61: one plan call per transform): a row of NaN / Inf poisons its own
+    output only, in every plan family -- lane-per-transform, whole rows, one-launch, LDS mixed-radix, the one-launch chirp-z
+    (whose padding positions used to read the NEXT transform's row times a zero chirp) and the tiled plans."""
+    tol = 2e-6 if dtype == np.complex64 else 2e-12
+    for n, batch in ((8, 70), (17, 37), (64, 33), (96, 21), (127, 19), (439, 11), (625, 7), (1000, 6), (1013, 6), (4096, 5),
+                     (10007, 4), (1 << 16, 3), (40009, 3)):
+        x = np.stack([hash_normal(900 + b, n) for b in range(batch)]).astype(dtype)
+        ref = oracle.transform_batch(x, 0)
+        plan = make(fa, n, dtype)
+        for bad_row, bad in ((1, np.nan), (batch - 1, np.inf), (0, -np.inf)):
+            xb = x.copy()
+            xb[bad_row, n // 2] = bad
+            got = gpu_batch(torch, fa, plan, xb, 0)
+            keep = [b for b in range(batch) if b != bad_row]
+            assert np.isfinite(got[keep]).all(), (n, plan.describe(), bad_row)
+            assert rel_l2(got[keep], ref[keep]) <= tol, (n, plan.describe(), bad_row)
+            assert not np.isfinite(got[bad_row]).all(), (n, bad_row)

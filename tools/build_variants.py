@@ -67,17 +67,41 @@ VARIANTS = {
 }
 
 
+def groups_of(flags):
+    """Translation-unit groups (fourier_amd/build.py) a variant's flags can reach: the LDS mixed-radix knobs touch only the
+    'mixed' objects, everything else only the tile / one-launch / small kernels; the other objects come from the base build."""
+    mixed = any("MIX" in f for f in flags)
+    other = any("MIX" not in f for f in flags)
+    g = set()
+    if mixed:
+        g |= {"mixed"}
+    if other or not flags:
+        g |= {"pass", "onelaunch", "misc"}
+    return g
+
+
 def main(names):
     outdir = os.path.join(ROOT, "fourier_amd", "lib", "variants")
     os.makedirs(outdir, exist_ok=True)
-    procs = []
+    base_objs, _ = B.compile_objects(B.OBJDIR, (), False, groups=set(B.group_of().values()) - B.EXPERIMENTS_ONLY)  # the shared objects
+    group = B.group_of()
     for name in names:
-        flags = [f for f in B.FLAGS if not (name == "slp" and f == "-fno-slp-vectorize")] + VARIANTS[name]
-        out = os.path.join(outdir, f"libfourier_{name}.so")
-        procs.append((name, subprocess.Popen([B.HIPCC] + flags + [B.SRC, "-o", out])))
-    for name, p in procs:
-        rc = p.wait()
-        print(name, "ok" if rc == 0 else f"FAILED rc={rc}")
+        flags = VARIANTS[name]
+        saved = list(B.CFLAGS)
+        if name == "slp":
+            B.CFLAGS[:] = [f for f in B.CFLAGS if f != "-fno-slp-vectorize"]
+        try:
+            objdir = os.path.join(outdir, "obj_" + name)
+            groups = groups_of(flags)
+            objs, _ = B.compile_objects(objdir, flags, False, groups=groups)
+            members = {n: (objs[n] if group[n] in groups else base_objs[n]) for n in objs}
+            out = os.path.join(outdir, f"libfourier_{name}.so")
+            B.link(members, out, experiments=False, soname=False)
+            print(name, "ok", sorted(groups))
+        except Exception as e:  # noqa: BLE001
+            print(name, f"FAILED {e!r}")
+        finally:
+            B.CFLAGS[:] = saved
 
 
 if __name__ == "__main__":

@@ -2,7 +2,7 @@
 """Per-kernel register / scratch / occupancy table from hipcc's -Rpass-analysis=kernel-resource-usage.
 
 usage: python tools/resource_usage.py [--from remarks.txt] [extra hipcc flags...]  > table
-Used to check that a refactor of fft_kernels.h leaves the hot kernels' allocation unchanged."""
+Used to check that a refactor of the kernel headers leaves the hot kernels' allocation unchanged."""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,9 +15,9 @@ def main():
     if argv[:1] == ["--from"]:
         err = open(argv[1]).read()
     else:
-        with tempfile.TemporaryDirectory() as td:
-            cmd = [B.HIPCC] + B.FLAGS + ["-Rpass-analysis=kernel-resource-usage"] + argv + [B.SRC, "-o", os.path.join(td, "x.so")]
-            err = subprocess.run(cmd, stderr=subprocess.PIPE, text=True).stderr
+        with tempfile.TemporaryDirectory() as td:  # every translation unit once more, remarks collected per object
+            B.compile_objects(td, ["-Rpass-analysis=kernel-resource-usage"] + argv, force=True)
+            err = "".join(open(os.path.join(td, f)).read() for f in sorted(os.listdir(td)) if f.endswith(".remarks.txt"))
     rows, cur = [], None
     for line in err.splitlines():
         m = PAT.search(line)
