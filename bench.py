@@ -24,7 +24,11 @@ efficiency against that reference, so that one record is enough to judge batch-s
 Extra objects in the JSON line:
   roofline      -- dominant kernel, algorithmic bytes per launch / HIP-event duration (events on the
                    launch stream, inside this process), peak 8 TB/s; `traffic` from the committed
-                   rocprofv3 PMC pass (profiles/traffic_latest.json) or null.
+                   rocprofv3 PMC pass (profiles/traffic_latest.json) or null.  Also measured IN THIS RUN, on
+                   the workload's own buffers: `copy_ceiling_gbps` = what a hand-written device copy of the
+                   same shape reaches on this box (lib/libfourier_experiments.so, csrc/exp_copy_ceiling.cpp),
+                   `frac_of_copy_ceiling` for the dominant kernel, `round_trips` of the plan through HBM and
+                   the bound they put on the whole path (`whole_path_bound_frac` = copy ceiling / round trips).
   cpu_baseline  -- the oracle (CPU restatement of the reference, kind "port") timed on this box's host
                    cores on a bounded sample of the same workload (rank 0, N=1 only).
   other_configs -- (N=1, default config only) a few seconds each on C1 (one N=4096 transform per call through the
@@ -67,6 +71,9 @@ def parse():
     p.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     p.add_argument("--no-other", action="store_true", help="skip the other_configs leg")
     p.add_argument("--cpu-sample", type=int, default=0, help="transforms in the CPU sample (0 = auto)")
+    p.add_argument("--dry-run", action="store_true",
+                   help="no GPU, no process group: print the shard ranges, chunk walk and byte counts a --gpus N run of this config "
+                        "WOULD execute (every rank's view), and check that they tile the global batch exactly")
     return p.parse_args()
 
 
@@ -98,7 +105,39 @@ def kernel_profile(plan, x_ptr, y_ptr, batch, stream, reps=3):
     return {k: {"ms_per_step": v[0] / reps, "launches_per_step": v[1] // reps} for k, v in acc.items()}
 
 
-def roofline_of(plan, kernels, batch, alg_bytes_per, dtype, whole_path_frac, traffic_ok=False):
+def copy_ceiling(src_ptr, dst_ptr, nbytes, stream):
+    """GB/s (read + written bytes) of a hand-written slab copy src -> dst on this box, this run: measurement tooling from
+    lib/libfourier_experiments.so (fourier_exp_copy_ceiling), never the product library.  None when unavailable."""
+    import ctypes
+
+    from fourier_amd import build as B
+
+    try:
+        lib = ctypes.CDLL(B.OUT_EXPERIMENTS)
+        f = lib.fourier_exp_copy_ceiling
+    except (OSError, AttributeError):
+        return None
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                  ctypes.POINTER(ctypes.c_float)]
+    out = {}
+    slab = 1 << 20  # bytes per workgroup
+    nbytes = min(nbytes, 16 << 30) // (8 * slab) * (8 * slab)  # whole slabs, a multiple of 8 workgroups (one range per XCD)
+    if nbytes <= 0:
+        return None
+    for label, nt in (("plain", 0), ("streaming", 1)):
+        ms = ctypes.c_float(0.0)
+        rc = f(src_ptr, dst_ptr, nbytes, slab, nt, 5, stream, ctypes.byref(ms))
+        if rc != 0 or ms.value <= 0:
+            return None
+        out[label] = 2.0 * nbytes / (ms.value * 1e-3) / 1e9
+    best = max(out, key=out.get)
+    return {"gbps": round(out[best], 1), "policy": best, "bytes_copied": nbytes, "by_policy_gbps": {k: round(v, 1) for k, v in out.items()},
+            "how": "hand-written slab copy (16-byte accesses, 8 loads in flight per thread, one contiguous 1 MiB slab per workgroup, "
+                   "XCD-aware block order), 5 launches between HIP events on the launch stream, this process, the workload's own buffers"}
+
+
+def roofline_of(plan, kernels, batch, alg_bytes_per, dtype, whole_path_frac, traffic_ok=False, ceiling=None):
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
     dom_ms = kernels[dom]["ms_per_step"]
     achieved = batch * alg_bytes_per / (dom_ms * 1e-3) / 1e9  # all launches of that kernel in a step cover the batch
@@ -111,7 +150,7 @@ def roofline_of(plan, kernels, batch, alg_bytes_per, dtype, whole_path_frac, tra
             traffic = tj.get("per_launch_bytes", {}).get(dom)
         except Exception:
             traffic = None
-    return {
+    r = {
         "bound": "hbm", "kernel": dom,
         "rocprof_name": f"fourier_hip kernel behind slot '{dom}' of plan {plan.describe()} "
                         f"({'float' if dtype == 'f32' else 'double'})",
@@ -122,35 +161,48 @@ def roofline_of(plan, kernels, batch, alg_bytes_per, dtype, whole_path_frac, tra
                     for k, v in kernels.items()},
         "whole_path_frac": round(whole_path_frac, 4),
     }
+    trips = sum(1 for v in kernels.values() if v["launches_per_step"])  # launches that each move the whole batch through HBM
+    r["round_trips"] = trips
+    if ceiling:
+        r["copy_ceiling_gbps"] = ceiling["gbps"]
+        r["copy_ceiling"] = ceiling
+        r["frac_of_copy_ceiling"] = round(achieved / ceiling["gbps"], 4)
+        # a plan that moves every point through HBM `trips` times cannot beat (copy ceiling / trips) on the algorithmic bytes
+        r["whole_path_bound_frac"] = round(ceiling["gbps"] / trips / HBM_PEAK_GBPS, 4)
+        r["whole_path_frac_of_bound"] = round(whole_path_frac / (ceiling["gbps"] / trips / HBM_PEAK_GBPS), 4)
+    return r
 
 
-def reference_bench_sizes(fourier_amd, torch, dev, bytes_per_size=1 << 30):
-    """The reference's own criterion size sets (fourier-bench/benches/fft_bench.rs:153-159: powers of two / three / five,
-    composites, primes), device-resident and batched, f32 forward: plan, time per transform, fraction of the HBM peak on the
-    algorithmic bytes.  A fraction of a second in total; informative (the reference times one host transform per call)."""
+def reference_bench_sizes(fourier_amd, torch, dev, bytes_per_size=1 << 29):
+    """The reference's own criterion grid (fourier-bench/benches/fft_bench.rs:153-159: powers of two / three / five, composites,
+    primes; forward and inverse; f32 and f64), device-resident and batched: plan, time per transform, fraction of the HBM
+    peak on the algorithmic bytes.  A few seconds in total; informative (the reference times one host transform per call)."""
     from fourier_amd import Transform
 
     rows = []
-    for scenario, sizes in (("pow2", (256, 512, 1024)), ("pow3", (243, 729, 2187)), ("pow5", (125, 625, 3125)),
-                            ("composite", (222, 722, 1418)), ("prime", (191, 439, 1013))):
-        for n in sizes:
-            batch = max(1, bytes_per_size // (n * 8))
-            plan = make_plan(fourier_amd, n, "f32", dev.index)
-            x = torch.empty((batch, n), dtype=torch.complex64, device=dev)
-            torch.view_as_real(x).uniform_(0.0, 1.0)
-            y = torch.empty_like(x)
-            stream = torch.cuda.current_stream(dev).cuda_stream
-            ts = []
-            for it in range(5):
-                t0 = time.perf_counter()
-                plan.transform_batch_ptr(x.data_ptr(), y.data_ptr(), batch, int(Transform.Fft), stream)
-                torch.cuda.synchronize(dev)
-                if it >= 2:
-                    ts.append(time.perf_counter() - t0)
-            t = sorted(ts)[len(ts) // 2]
-            rows.append({"scenario": scenario, "n": n, "plan": plan.describe(), "batch": batch, "ns_per_transform": round(t / batch * 1e9, 2),
-                         "hbm_frac_algorithmic": round(batch * 16.0 * n / t / 1e9 / HBM_PEAK_GBPS, 4)})
-            del x, y, plan
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for dtype, cdt, esz in (("f32", torch.complex64, 8), ("f64", torch.complex128, 16)):
+        for scenario, sizes in (("pow2", (256, 512, 1024)), ("pow3", (243, 729, 2187)), ("pow5", (125, 625, 3125)),
+                                ("composite", (222, 722, 1418)), ("prime", (191, 439, 1013))):
+            for n in sizes:
+                batch = max(1, bytes_per_size // (n * esz))
+                plan = make_plan(fourier_amd, n, dtype, dev.index)
+                x = torch.empty((batch, n), dtype=cdt, device=dev)
+                torch.view_as_real(x).uniform_(0.0, 1.0)
+                y = torch.empty_like(x)
+                for direction, code in (("forward", Transform.Fft), ("inverse", Transform.Ifft)):
+                    ts = []
+                    for it in range(5):
+                        t0 = time.perf_counter()
+                        plan.transform_batch_ptr(x.data_ptr(), y.data_ptr(), batch, int(code), stream)
+                        torch.cuda.synchronize(dev)
+                        if it >= 2:
+                            ts.append(time.perf_counter() - t0)
+                    t = sorted(ts)[len(ts) // 2]
+                    rows.append({"scenario": scenario, "n": n, "dtype": dtype, "direction": direction, "plan": plan.describe(), "batch": batch,
+                                 "ns_per_transform": round(t / batch * 1e9, 2),
+                                 "hbm_frac_algorithmic": round(batch * 2.0 * esz * n / t / 1e9 / HBM_PEAK_GBPS, 4)})
+                del x, y, plan
     return rows
 
 
@@ -310,8 +362,60 @@ def cpu_baseline(torch, plan, hx, n, dtype, dev, stream, cores):
     return parity, base
 
 
+def dry_run(args):
+    """What `bench.py --gpus N` would do, rank by rank, without touching a GPU or a process group: configuration, shard of
+    every rank, its chunk walk (first transform and length of every resident chunk), bytes resident and bytes streamed per
+    step.  Checks that the chunks of all ranks tile [0, global batch) exactly once.  One JSON line."""
+    from fourier_amd import shard
+
+    world = args.gpus
+    key = args.config if args.config != "auto" else ("c5" if world > 1 else "c2")
+    cfg = dict(CONFIGS[key])
+    dtype = args.dtype or cfg["dtype"]
+    n = (1 << args.log2n) if args.log2n is not None else cfg["n"]
+    esz = 8 if dtype == "f32" else 16
+    ranks, covered = [], []
+    if key == "c5":
+        gbatch = args.batch or cfg["global_batch"]
+        for r in range(world):
+            lo, hi = shard.batch_shard(gbatch, world, r)
+            chunk = max(1, min(args.chunk or cfg["chunk"], hi - lo))
+            walk = [(b0, min(chunk, hi - b0)) for b0 in range(lo, hi, chunk)]
+            covered += walk
+            ranks.append({"rank": r, "transforms": [lo, hi], "chunk": chunk, "chunks_per_step": len(walk),
+                          "ragged_last_chunk": walk[-1][1] if walk and walk[-1][1] != chunk else None,
+                          "resident_bytes": chunk * n * esz * (1 if args.inplace else 2),
+                          "algorithmic_bytes_per_step": (hi - lo) * 2 * n * esz})
+        scaling = "strong"
+    else:
+        batch = args.batch or cfg["batch"]
+        gbatch = world * batch
+        for r in range(world):
+            covered.append((r * batch, batch))
+            ranks.append({"rank": r, "transforms": [r * batch, (r + 1) * batch], "chunk": batch, "chunks_per_step": 1, "ragged_last_chunk": None,
+                          "resident_bytes": batch * n * esz * (1 if args.inplace else 2), "algorithmic_bytes_per_step": batch * 2 * n * esz})
+        scaling = "weak"
+    covered.sort()
+    pos, ok = 0, True
+    for b0, nb in covered:
+        ok = ok and b0 == pos and nb > 0
+        pos = b0 + nb
+    ok = ok and pos == gbatch
+    hbm = 288e9
+    print(json.dumps({
+        "dry_run": True, "config_key": key, "scaling": scaling, "n_gpus": world, "n": n, "dtype": dtype, "global_batch": gbatch,
+        "transforms_per_rank": [r["transforms"][1] - r["transforms"][0] for r in ranks], "ranks": ranks,
+        "tiles_global_batch_exactly_once": ok, "fits_hbm_per_gpu": all(r["resident_bytes"] < hbm for r in ranks),
+        "collectives_on_the_data_path": 0,
+        "nominal_flop_per_step": gbatch * nominal_flops(n), "algorithmic_bytes_per_step": gbatch * 2 * n * esz,
+    }), flush=True)
+    return 0 if ok else 1
+
+
 def main():
     args = parse()
+    if args.dry_run:
+        raise SystemExit(dry_run(args))
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -421,6 +525,8 @@ def main():
                 if i:
                     ts_ref.append(time.perf_counter() - t1)
             ref_ms_per_chunk = sum(ts_ref) / len(ts_ref) * 1e3
+        if dist is not None:
+            dist.barrier()  # nobody starts its warm-up while rank 0 is still timing the reference
         for w in range(args.warmup):
             step(-1 - w)
         sync_all()
@@ -443,7 +549,7 @@ def main():
                 "per_rank_fft_ms_per_step": [round(t / args.steps * 1e3, 3) for t in per_rank],
                 "transforms_per_rank": [h - l for l, h in shards],
                 "single_gpu_reference": {"ms_per_chunk": round(ref_ms_per_chunk, 3), "chunk": chunk,
-                                         "how": "rank 0 alone, two timed chunks after one warm chunk, the other ranks idle at a barrier"},
+                                         "how": "rank 0 alone, two timed chunks after one warm chunk, every other rank waiting at a barrier until it is done"},
                 "ideal_ms_per_step": round(ideal_ms, 3),  # reference x (largest shard / chunk): perfect batch-shard scaling
                 "efficiency_vs_reference": round(ideal_ms / (elapsed / args.steps * 1e3), 4),
             }
@@ -525,8 +631,15 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel: HIP events on the launch stream, live
         kernels = kernel_profile(plan, x.data_ptr(), y.data_ptr(), batch, stream)
+        ceiling = None
+        if x.data_ptr() != y.data_ptr():  # same box, same run, same buffers: a plain device copy x -> y (y is rewritten below)
+            try:
+                ceiling = copy_ceiling(x.data_ptr(), y.data_ptr(), x.numel() * x.element_size(), stream)
+                torch.cuda.synchronize(dev)
+            except Exception:
+                ceiling = None
         out["roofline"] = roofline_of(plan, kernels, batch, alg_bytes_per, dtype, alg_gbps / world / HBM_PEAK_GBPS,
-                                      traffic_ok=(key == "c2" and n == 1 << 20 and dtype == "f32" and batch == 4096))
+                                      traffic_ok=(key == "c2" and n == 1 << 20 and dtype == "f32" and batch == 4096), ceiling=ceiling)
 
         if key == "c5" and not args.no_cpu:
             # parity on the resident chunk: its first and last transform against the oracle (bounded: 2 transforms)
@@ -568,9 +681,11 @@ def main():
                     torch.cuda.empty_cache()
             try:
                 torch.cuda.empty_cache()
-                others["reference_bench_sizes_f32"] = reference_bench_sizes(fourier_amd, torch, dev)
+                grid = reference_bench_sizes(fourier_amd, torch, dev)
+                others["reference_bench_sizes"] = grid  # forward + inverse, f32 + f64 (fft_bench.rs:153-159)
+                others["reference_bench_sizes_f32"] = [r for r in grid if r["dtype"] == "f32" and r["direction"] == "forward"]
             except Exception as e:
-                others["reference_bench_sizes_f32"] = {"error": repr(e)}
+                others["reference_bench_sizes"] = {"error": repr(e)}
             out["other_configs"] = others
         print(json.dumps(out), flush=True)
 

@@ -451,8 +451,8 @@ def test_c5_full_job_65536_transforms_on_one_gpu(torch, fa, oracle):
     """BASELINE configs[4] as specified, on ONE GPU: f32 N=2^22, batch 65536 = 2 TiB of input, walked as 64 resident
     chunks of 1024 transforms (32 GiB), every chunk regenerated on the device (seed = global chunk index) and
     transformed out of place -- the loop `bench.py --config c5` times.  Checked: Parseval on EVERY chunk (energy of
-    all 1024 transforms; a chunk that was skipped, or transformed with the wrong stride, fails it), and the first
-    transform of the first chunk and the last transform of the last chunk against the oracle."""
+    all 1024 transforms; a chunk that was skipped, or transformed with the wrong stride, fails it), and 66 transforms
+    against the oracle: one per chunk plus the first and the last of the job."""
     n, gbatch, chunk = 1 << 22, 65536, 1024
     plan = fa.create_fft_f32(n)
     x = torch.empty((chunk, n), dtype=torch.complex64, device="cuda")
@@ -467,11 +467,14 @@ def test_c5_full_job_65536_transforms_on_one_gpu(torch, fa, oracle):
         ex = torch.view_as_real(x).double().pow(2).sum(dim=(1, 2))
         ey = torch.view_as_real(y).double().pow(2).sum(dim=(1, 2)) / n
         assert float(((ey - ex).abs() / ex).max()) < 2e-6, (c, "Parseval")
-        for row in ([0] if c == 0 else []) + ([chunk - 1] if b0 + chunk == gbatch else []):
+        # against the oracle: one transform of EVERY chunk, at a row that moves through the chunk from chunk to chunk (every
+        # residue of the 1024 rows modulo 64 and both halves of the chunk are visited), plus the job's first and last transform
+        rows = {(c * 611 + 17) % chunk} | ({0} if c == 0 else set()) | ({chunk - 1} if b0 + chunk == gbatch else set())
+        for row in sorted(rows):
             ref = orc.transform(x[row].cpu().numpy(), oracle.FFT)
             assert rel_l2(y[row].cpu().numpy(), ref) <= 1e-6, (c, row)
             checked += 1
-    assert checked == 2
+    assert checked == gbatch // chunk + 2
     del x, y
     torch.cuda.empty_cache()
 
@@ -571,6 +574,7 @@ def test_bench_strong_scaling_path_with_two_ranks(torch, fa, tmp_path):
     assert out["process_group"]["backend"] == ("nccl" if two else "gloo")
     ss = out["strong_scaling"]
     assert len(ss["per_rank_fft_ms_per_step"]) == 2 and ss["transforms_per_rank"] == [768, 768]
+    assert sum(ss["transforms_per_rank"]) == out["config"]["global_batch"] and "efficiency_vs_reference" in ss
     assert abs(max(ss["per_rank_fft_ms_per_step"]) - out["ms_per_step"]) / out["ms_per_step"] < 1e-3  # ms_per_step = slowest rank
     assert ss["single_gpu_reference"]["chunk"] == 256 and ss["single_gpu_reference"]["ms_per_chunk"] > 0
     assert abs(ss["ideal_ms_per_step"] - ss["single_gpu_reference"]["ms_per_chunk"] * 3) < 1e-2  # 768 per rank = 3 chunks

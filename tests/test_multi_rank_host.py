@@ -86,3 +86,32 @@ def test_two_ranks_gloo_shard_and_reduce(tmp_path, oracle):
     ref = oracle.transform_batch(x, oracle.FFT)
     got = np.load(out)
     assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 1e-6
+
+
+def test_bench_dry_run_validates_the_sharding_of_the_full_c5_job():
+    """`bench.py --gpus N --dry-run` (no GPU, no process group): the shard ranges, chunk walk and byte counts every rank of a
+    1 / 2 / 4 / 8-GPU run of BASELINE configs[4] (f32 N=2^22, GLOBAL batch 65536 = 2 TiB) would execute -- what the driver's
+    scaling step launches at round end on hardware this container does not have."""
+    import json
+
+    for gpus in (1, 2, 4, 8):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--config", "c5", "--dry-run"],
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1
+        out = json.loads(lines[0])
+        assert out["config_key"] == "c5" and out["scaling"] == "strong" and out["n_gpus"] == gpus and out["n"] == 1 << 22
+        assert out["global_batch"] == 65536 and sum(out["transforms_per_rank"]) == 65536
+        assert out["transforms_per_rank"] == [65536 // gpus] * gpus
+        assert out["tiles_global_batch_exactly_once"] and out["fits_hbm_per_gpu"] and out["collectives_on_the_data_path"] == 0
+        for rk in out["ranks"]:
+            assert rk["chunk"] == 1024 and rk["chunks_per_step"] == 64 // gpus and rk["ragged_last_chunk"] is None
+            assert rk["resident_bytes"] == 2 * 1024 * (1 << 22) * 8  # 64 GiB: input + output chunk
+        assert out["algorithmic_bytes_per_step"] == 65536 * 2 * (1 << 22) * 8
+    # the default under torch.distributed.run with more than one rank IS c5 (auto), a ragged split still tiles the batch
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--dry-run", "--batch", "1000", "--chunk", "128"],
+                       capture_output=True, text=True, timeout=120)
+    out = json.loads(r.stdout.strip())
+    assert r.returncode == 0 and out["config_key"] == "c5" and out["transforms_per_rank"] == [333, 333, 334]
+    assert out["tiles_global_batch_exactly_once"] and [rk["ragged_last_chunk"] for rk in out["ranks"]] == [77, 77, 78]
