@@ -125,7 +125,7 @@ def copy_ceiling(src_ptr, dst_ptr, nbytes, stream):
     nbytes = min(nbytes, 16 << 30) // (8 * slab) * (8 * slab)  # whole slabs, a multiple of 8 workgroups (one range per XCD)
     if nbytes <= 0:
         return None
-    for label, nt in (("plain", 0), ("streaming", 1)):
+    for label, nt in (("slab_plain", 0), ("slab_streaming", 1), ("column_tiles_plain", 2), ("column_tiles_streaming", 3)):
         ms = ctypes.c_float(0.0)
         rc = f(src_ptr, dst_ptr, nbytes, slab, nt, 5, stream, ctypes.byref(ms))
         if rc != 0 or ms.value <= 0:
@@ -133,8 +133,10 @@ def copy_ceiling(src_ptr, dst_ptr, nbytes, stream):
         out[label] = 2.0 * nbytes / (ms.value * 1e-3) / 1e9
     best = max(out, key=out.get)
     return {"gbps": round(out[best], 1), "policy": best, "bytes_copied": nbytes, "by_policy_gbps": {k: round(v, 1) for k, v in out.items()},
-            "how": "hand-written slab copy (16-byte accesses, 8 loads in flight per thread, one contiguous 1 MiB slab per workgroup, "
-                   "XCD-aware block order), 5 launches between HIP events on the launch stream, this process, the workload's own buffers"}
+            "how": "best of four hand-written device copies (16-byte accesses, XCD-aware block order): linear 1 MiB slabs per workgroup "
+                   "with 8 loads in flight per thread, and the passes' own shape -- 128-byte row segments at an 8 KiB row stride, 16 loads "
+                   "in flight per thread, one 128 KiB column tile per 512-thread workgroup -- each with plain and with streaming accesses; "
+                   "5 launches between HIP events on the launch stream, this process, the workload's own buffers"}
 
 
 def roofline_of(plan, kernels, batch, alg_bytes_per, dtype, whole_path_frac, traffic_ok=False, ceiling=None):

@@ -215,7 +215,9 @@ template <typename T> struct Real {};
   FOURIER_MIX_SHARD_LIST(FOURIER_DECLARE_MIX_SHARD, T)                                                                 \
   /* kernels_experiments.cpp (experiments library) or env_product.cpp (product: nothing available) */                  \
   bool get_fused_kernel(Real<T>, int k, FusedInfo& info);                                                              \
-  KernelInfo get_split_kernel(Real<T>, int L, int io);
+  KernelInfo get_split_kernel(Real<T>, int L, int io);                                                                 \
+  /* persistent LAST pass that prefetches its next tile (fft_last_prefetch_kernel); fn == nullptr where not built */     \
+  KernelInfo get_prefetch_kernel(Real<T>, int L, int io);
 FOURIER_DECLARE_REGISTRY(float)
 FOURIER_DECLARE_REGISTRY(double)
 #undef FOURIER_DECLARE_REGISTRY

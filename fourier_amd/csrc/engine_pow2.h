@@ -40,6 +40,8 @@ template <typename T> class Pow2Engine {
     KernelInfo k;
     KernelInfo k_blu;  // IO_BLU_IN variant of a FIRST pass / IO_BLU_OUT variant of a LAST pass (lazy)
     bool has_blu = false;
+    KernelInfo k_pf, k_pf_blu;  // LAST pass: the persistent prefetching form (fft_last_prefetch_kernel), plain / chirp-out
+    unsigned pf_grid = 0, pf_blu_grid = 0;  // resident workgroups of those kernels on this device
     StageTables<T>* st2 = nullptr;  // MODE_TWOLEVEL: stage tables of the second pass length
     OddKernel odd_fn = nullptr;     // MODE_ODD_LAST
     int odd_r = 0;
@@ -153,6 +155,11 @@ template <typename T> class Pow2Engine {
         pass->tw_half.upload(wh);
       }
       if (pass->mode == MODE_FIRST || pass->mode == MODE_MID) make_two_level(*pass, size);
+      if (pass->mode == MODE_LAST && !pass->k.split) {
+        pass->k_pf = get_prefetch_kernel(Real<T>{}, L, IO_PLAIN);
+        if (pass->k_pf.fn && pass->k_pf.COLS == pass->k.COLS) pass->pf_grid = resident_grid(pass->k_pf);
+        else pass->k_pf = KernelInfo();
+      }
       set_smem_attribute(pass->k);
       passes_.push_back(std::move(pass));
       s *= (uint64_t)L;
@@ -191,6 +198,16 @@ template <typename T> class Pow2Engine {
     pass.tw_hi.upload(hi);
   }
   static void set_smem_attribute(const KernelInfo& k) { raise_smem_limit((const void*)k.fn, k.smem); }
+  // workgroups of a persistent kernel that are resident at once on this device, a multiple of 8 (one block sequence per XCD)
+  static unsigned resident_grid(const KernelInfo& k) {
+    set_smem_attribute(k);
+    int per_cu = 0, cus = 0, dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k.fn, k.NT, k.smem));
+    HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const unsigned g = (unsigned)std::max(1, per_cu) * (unsigned)std::max(1, cus);
+    return g >= 8 ? g / 8 * 8 : g;
+  }
 
   // Whole-Bluestein-in-one-launch (bluestein_small_kernel) is available when this (inner) plan is a
   // one-launch two-level plan: it additionally needs the inter-pass table of the role-swapped L2 x L1 problem.
@@ -320,6 +337,11 @@ template <typename T> class Pow2Engine {
     l.k_blu = get_kernel(Real<T>{}, l.k.L, MODE_LAST, IO_BLU_OUT);
     f.has_blu = l.has_blu = true;
     for (Pass* p : {&f, &l}) set_smem_attribute(p->k_blu);
+    if (l.mode == MODE_LAST && !l.k_blu.split) {
+      l.k_pf_blu = get_prefetch_kernel(Real<T>{}, l.k.L, IO_BLU_OUT);
+      if (l.k_pf_blu.fn && l.k_pf_blu.COLS == l.k_blu.COLS) l.pf_blu_grid = resident_grid(l.k_pf_blu);
+      else l.k_pf_blu = KernelInfo();
+    }
   }
 
   size_t size() const { return n_; }
@@ -474,11 +496,26 @@ template <typename T> class Pow2Engine {
         grid = (uint64_t)batch * a.tiles * (kk.split ? 2 : 1);
       }
       if (grid > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");
+      // LAST pass in its persistent prefetching form (plan option "last_pass_prefetch"): the same tiles, walked by as many
+      // workgroups as are resident at once
+      const KernelInfo& pf = blu_here ? ps.k_pf_blu : ps.k_pf;
+      if (prefetch_last(ps) && ps.mode == MODE_LAST && pf.fn && !a.swap_in && (!blu_here || blu.io == IO_BLU_OUT)) {
+        a.total_cols = grid;  // tiles of the whole launch
+        const uint64_t resident = blu_here ? ps.pf_blu_grid : ps.pf_grid;
+        PROF_BEGIN(prof, slot);
+        FOURIER_LAUNCH(pf.fn, std::min<uint64_t>(grid, resident), pf.NT, pf.smem, stream, a);
+        PROF_END(prof);
+        return;
+      }
       PROF_BEGIN(prof, slot);
       FOURIER_LAUNCH(kk.fn, grid, kk.NT, kk.smem, stream, a);
       PROF_END(prof);
     }
   }
+  // "last_pass_prefetch" (experiments library): 1 = wherever the kernel exists; off by default -- measured slower
+  void set_prefetch_last(bool on) { prefetch_last_ = on; }
+  bool has_prefetch_last() const { return !passes_.empty() && passes_.back()->k_pf.fn != nullptr; }
+  bool prefetch_last(const Pass&) const { return prefetch_last_; }
 
   // Bluestein middle: this plan's LAST pass + (.) wtab + the FIRST pass of an inverse plan that starts with the
   // same length, in one launch (fft_conv_kernel).  src and dst are M-point work arrays, dst != src.
@@ -535,6 +572,7 @@ template <typename T> class Pow2Engine {
   StageTables<T>* conv_st_ = nullptr;
   FusedInfo fused_;
   bool fused_on_ = false;
+  bool prefetch_last_ = false;
   unsigned fused_grid_ = 0, fused_depth_ = 2;
   mutable DevBuf fused_window_, fused_ctrl_;
   mutable PinnedBuf fused_flag_;  // ctrl[1] (abort flag) of the last fused launch, read back before the call returns

@@ -12,5 +12,8 @@ bool get_fused_kernel(Real<float>, int, FusedInfo&) { return false; }
 bool get_fused_kernel(Real<double>, int, FusedInfo&) { return false; }
 KernelInfo get_split_kernel(Real<float>, int, int) { return KernelInfo(); }
 KernelInfo get_split_kernel(Real<double>, int, int) { return KernelInfo(); }
+// the persistent prefetching last pass: 15-30 % slower than fft_pass_kernel (kernels_experiments.h has the measurements)
+KernelInfo get_prefetch_kernel(Real<float>, int, int) { return KernelInfo(); }
+KernelInfo get_prefetch_kernel(Real<double>, int, int) { return KernelInfo(); }
 
 }  // namespace fourier_hip

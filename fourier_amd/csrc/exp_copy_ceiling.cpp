@@ -27,11 +27,31 @@ __global__ void __launch_bounds__(256) copy_slab_kernel(const void* __restrict__
   }
 }
 
+// The same bytes in the passes' own access shape: the buffer is a sequence of 8 MiB "transforms" of 1024 rows x 8 KiB; a
+// 512-thread workgroup copies one column tile -- sixteen 128-byte row segments per thread at a row stride of 8 KiB, all
+// sixteen loads in flight, then the sixteen stores to the same positions of dst (the load and store side of the LAST pass of
+// the 1024 x 1024 plan with its arithmetic and LDS exchanges removed); XCD-aware tile order as in xcd_remap mode 0.
+template <bool NT>
+__global__ void __launch_bounds__(512) copy_tile_kernel(const void* __restrict__ src, void* __restrict__ dst) {
+  uint64_t b = blockIdx.x;
+  const uint64_t per_xcd = gridDim.x / 8;
+  if (per_xcd * 8 == gridDim.x) b = (b % 8) * per_xcd + b / 8;
+  const uint64_t transform = b / 64, tile = b % 64;  // 64 tiles of 8 units (128 bytes) per 512-unit row
+  const uint64_t base = transform * (1024 * 512) + tile * 8 + (uint64_t)(threadIdx.x / 8) * 512 + threadIdx.x % 8;
+  const Unit16<float>* s = (const Unit16<float>*)src + base;
+  Unit16<float>* d = (Unit16<float>*)dst + base;
+  Unit16<float> v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = load_unit<float, NT>(s + (uint64_t)r * 64 * 512);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) store_unit<float, NT>(d + (uint64_t)r * 64 * 512, v[r]);
+}
+
 }  // namespace fourier_hip
 
 // Copies `bytes` (a multiple of bytes_per_block, itself a multiple of 32 KiB) from src to dst `reps` times on `stream` and
-// reports the mean milliseconds per copy between two HIP events on that stream.  nt != 0: streaming (non-temporal) loads
-// and stores, the cache policy of the pass kernels.  Returns a fourier_hip status code.
+// reports the mean milliseconds per copy between two HIP events on that stream.  nt bit 0: streaming (non-temporal) loads
+// and stores, the cache policy of the pass kernels; bit 1: the column-tile shape of the passes instead of linear slabs.  Returns a fourier_hip status code.
 extern "C" int fourier_exp_copy_ceiling(const void* src, void* dst, uint64_t bytes, uint64_t bytes_per_block, int nt, int reps,
                                         void* stream, float* ms_per_copy) {
   using namespace fourier_hip;
@@ -49,8 +69,14 @@ extern "C" int fourier_exp_copy_ceiling(const void* src, void* dst, uint64_t byt
     hipEvent_t a, b;
     HIP_CHECK(hipEventCreate(&a));
     HIP_CHECK(hipEventCreate(&b));
+    const bool tile_shape = (nt & 2) != 0;  // bit 1: the passes' column-tile shape (bytes must be a multiple of 8 MiB)
+    if (tile_shape && bytes % ((uint64_t)8 << 20)) return ::fourier::c::FOURIER_HIP_INVALID_ARGUMENT;
+    const unsigned tile_blocks = (unsigned)(bytes >> 17);  // 128 KiB per workgroup
     auto launch = [&] {
-      if (nt) copy_slab_kernel<8, true><<<blocks, 256, 0, st>>>(src, dst, bytes_per_block / 16);
+      if (tile_shape) {
+        if (nt & 1) copy_tile_kernel<true><<<tile_blocks, 512, 0, st>>>(src, dst);
+        else copy_tile_kernel<false><<<tile_blocks, 512, 0, st>>>(src, dst);
+      } else if (nt & 1) copy_slab_kernel<8, true><<<blocks, 256, 0, st>>>(src, dst, bytes_per_block / 16);
       else copy_slab_kernel<8, false><<<blocks, 256, 0, st>>>(src, dst, bytes_per_block / 16);
     };
     launch();  // warm-up (page tables, clocks)

@@ -54,4 +54,22 @@ bool get_fused_kernel(Real<TUReal>, int k, FusedInfo& info) {
   }
 }
 
+template <typename T, int L, int CG, int IO> static KernelInfo make_prefetch_info() {
+  using C = TileCfg<T, L, CG>;
+  KernelInfo k;
+  k.fn = &fft_last_prefetch_kernel<T, L, CG, IO>;
+  k.L = L; k.CG = CG; k.NT = C::NT; k.COLS = C::COLS; k.R3 = C::R3;
+  k.smem = PrefetchCfg<T, L, CG>::SMEM;
+  return k;
+}
+KernelInfo get_prefetch_kernel(Real<TUReal>, int L, int io) {
+  typedef TUReal T;
+  if (io != IO_PLAIN && io != IO_BLU_OUT) return KernelInfo();
+  switch (L) {
+    case 1024: return io == IO_BLU_OUT ? make_prefetch_info<T, 1024, FOURIER_CG_1024, IO_BLU_OUT>() : make_prefetch_info<T, 1024, FOURIER_CG_1024, IO_PLAIN>();
+    case 2048: return io == IO_BLU_OUT ? make_prefetch_info<T, 2048, FOURIER_CG_2048, IO_BLU_OUT>() : make_prefetch_info<T, 2048, FOURIER_CG_2048, IO_PLAIN>();
+    default: return KernelInfo();
+  }
+}
+
 }  // namespace fourier_hip

@@ -137,6 +137,14 @@ template <typename T> class Plan {
     if (key == "bluestein_conv" && (v == 0 || v == 1)) { conv_ = (v == 1) && conv_ok_; return 0; }
     if (key == "bluestein_chirp_compute" && (v == 0 || v == 1)) { chirp_compute_ = (v == 1) && chirp_p_.p != nullptr; return 0; }
     if (key == "host_chunk_bytes" && v > 0) { host_chunk_bytes_ = (size_t)v; return 0; }
+    // LAST pass as persistent workgroups that prefetch their next tile (fft_last_prefetch_kernel; experiments library only,
+    // measured slower): 1 where the kernel exists, INVALID_ARGUMENT where it does not
+    if (key == "last_pass_prefetch" && (v == 0 || v == 1) && eng_) {
+      if (v == 1 && !eng_->has_prefetch_last() && !(eng_inv_ && eng_inv_->has_prefetch_last())) return ::fourier::c::FOURIER_HIP_INVALID_ARGUMENT;
+      eng_->set_prefetch_last(v == 1);
+      if (eng_inv_) eng_inv_->set_prefetch_last(v == 1);
+      return 0;
+    }
     // both passes in one launch with the intermediate in the XCD's L2 (2^16..2^18 f32, 2^15..2^17 f64); 0 where unavailable
     if (key == "l2_fused" && (v == 0 || v == 1)) {
       if (blu_ || !eng_ || (v == 1 && !eng_->has_l2fused())) return ::fourier::c::FOURIER_HIP_INVALID_ARGUMENT;

@@ -338,6 +338,14 @@ inline void __builtin_amdgcn_raw_buffer_store_b128(hipemu_b128 v, __amdgpu_buffe
   }
 }
 
+// LDS-DMA (buffer_load_dwordx4 ... lds): the destination is a wave-uniform LDS base plus lane * size; 1-D blocks
+inline void __builtin_amdgcn_raw_ptr_buffer_load_lds(__amdgpu_buffer_rsrc_t r, void* lds, int size, int voff, int soff, int off, int) {
+  const hipemu_b128 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff + off, soff, 0);
+  memcpy((unsigned char*)lds + (size_t)(hipemu::tls().tid.x & 63u) * (size_t)size, &v, (size_t)size);
+}
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // callers pass wave-uniform values
+inline void __builtin_amdgcn_s_waitcnt(int) {}
+
 // ---- host API subset ----
 namespace hipemu { inline uint64_t& alloc_count() { static uint64_t c = 0; return c; } }
 inline hipError_t hipMalloc(void** p, size_t n) {

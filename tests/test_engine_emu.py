@@ -713,3 +713,22 @@ def test_a_non_finite_transform_does_not_reach_its_neighbours(fa, oracle, dtype)
             assert np.isfinite(got[keep]).all(), (n, bad_row)
             assert rel_l2(got[keep], ref[keep]) <= (2e-6 if dtype == np.complex64 else 2e-12), (n, bad_row)
             assert not np.isfinite(got[bad_row]).all(), (n, bad_row)
+
+
+def test_prefetching_last_pass_is_bit_identical_to_the_plain_last_pass(fa, oracle):
+    """Plan option last_pass_prefetch (fft_last_prefetch_kernel, experiments build): the LAST pass as persistent workgroups that
+    fetch their next tile -- eight rows by LDS-DMA into the idle exchange buffer, eight into registers -- ahead of the current
+    tile's stores.  Same in-tile arithmetic: under the emulator (one compiler, no FMA contraction) the same bits as fft_pass_kernel, for the plain last pass (L = 1024 and 2048, f32 and f64, with
+    and without the stage twiddles in LDS) and for the chirp-out pass of a Bluestein plan; ragged tile counts per workgroup
+    (the emulated device keeps 6 workgroups resident)."""
+    for n, dtype, batch in ((1 << 21, np.complex64, 2), (1 << 22, np.complex64, 1), (1 << 21, np.complex128, 1), (700001, np.complex64, 1)):
+        x = np.stack([hash_normal(300 + b, n) for b in range(batch)]).astype(dtype)
+        on, off = make(fa, n, dtype), make(fa, n, dtype)
+        on.set_option("last_pass_prefetch", 1)
+        off.set_option("last_pass_prefetch", 0)
+        for code in (0, 4):
+            a, b = run_batch(on, x, code), run_batch(off, x, code)
+            assert np.array_equal(a, b), (n, dtype, code)
+        assert np.array_equal(run_batch(on, x, 0, inplace=True), a if code == 0 else run_batch(on, x, 0)), (n, dtype)
+        tol = (1e-6 if n & (n - 1) == 0 else 2e-6) if dtype == np.complex64 else (5e-14 if n & (n - 1) == 0 else 1e-9)
+        assert rel_l2(run_batch(on, x, 0), oracle.transform_batch(x, 0)) <= tol, (n, dtype)

@@ -61,6 +61,13 @@ VARIANTS = {
     "mix_half_none": ["-DFOURIER_MIX_HALF_MAX_ITEMS=0u"],
     "mix_half_250": ["-DFOURIER_MIX_HALF_MAX_ITEMS=250u"],
     "mix_wide_none": ["-DFOURIER_MIX_WIDE_MIN_BYTES=0xffffffffu", "-DFOURIER_MIX_WIDE_MIN_N=0xffffffffu"],
+    "pf_nobar": ["-DFOURIER_PF_BARRIER_AFTER_WAIT=0"],
+    "pf_vm0": ["-DFOURIER_PF_WAIT_ALL=1"],
+    "pf_vm0_plainst": ["-DFOURIER_PF_WAIT_ALL=1", "-DFOURIER_PF_ST_PLAIN=1"],
+    "pf_plainst": ["-DFOURIER_PF_ST_PLAIN=1"],
+    "pf_stores_first": ["-DFOURIER_PF_STORES_FIRST=1"],
+    "pf_vm0_dma4": ["-DFOURIER_PF_WAIT_ALL=1", "-DFOURIER_PF_DMA_ROWS=4"],
+    "pf_vm0_dma12": ["-DFOURIER_PF_WAIT_ALL=1", "-DFOURIER_PF_DMA_ROWS=12"],
     "abl1": ["-DFOURIER_ABLATE=1"],
     "abl2": ["-DFOURIER_ABLATE=2"],
     "abl3": ["-DFOURIER_ABLATE=3"],
