@@ -29,11 +29,16 @@ template <typename T> class GenericEngine {
     for (int r : radices) {
       Pass ps;
       ps.r = r; ps.s = (uint32_t)s; ps.m = (uint32_t)(size / (size_t)r);
-      ps.tw.reset(new DevBuf());
-      if (ps.m > 1) {  // W_size^{e}, e < size (f64 trig, cast: twiddle.rs:7-19)
-        std::vector<cpx<T>> tw(size);
-        for (size_t e = 0; e < size; ++e) { double re, im; unit_root(e, size, re, im); tw[e] = {(T)re, (T)im}; }
-        ps.tw->upload(tw);
+      ps.tw_lo.reset(new DevBuf());
+      ps.tw_hi.reset(new DevBuf());
+      if (ps.m > 1) {  // W_size^{e} as a two-level table: lo[e & mask] * hi[e >> bits] (f64 trig, cast: twiddle.rs:7-19)
+        const int lb = (ilog2(size) + 1) / 2;
+        ps.lo_bits = (uint32_t)lb;
+        std::vector<cpx<T>> lo((size_t)1 << lb), hi((size >> lb) + 1);
+        for (size_t e = 0; e < lo.size(); ++e) { double re, im; unit_root(e, size, re, im); lo[e] = {(T)re, (T)im}; }
+        for (size_t h = 0; h < hi.size(); ++h) { double re, im; unit_root((uint64_t)h << lb, size, re, im); hi[h] = {(T)re, (T)im}; }
+        ps.tw_lo->upload(lo);
+        ps.tw_hi->upload(hi);
       }
       ps.fn = get_stockham_pass_kernel(Real<T>{}, r);
       ps.smem = s == 1 ? (size_t)r * 256 * sizeof(cpx<T>) : 0;  // first pass: the workgroup's outputs are staged in LDS
@@ -59,7 +64,8 @@ template <typename T> class GenericEngine {
       cpx<T>* dst = (p + 1 == np) ? out : half[p & 1];
       GenArgs a;
       std::memset(&a, 0, sizeof(a));
-      a.in = src; a.out = dst; a.tw = ps.m > 1 ? ps.tw->p : nullptr;
+      a.in = src; a.out = dst;
+      a.tw_lo = ps.m > 1 ? ps.tw_lo->p : nullptr; a.tw_hi = ps.m > 1 ? ps.tw_hi->p : nullptr; a.lo_bits = ps.lo_bits;
       a.n = n_; a.s = ps.s; a.m = ps.m;
       const uint64_t per = (uint64_t)ps.s * ps.m;
       a.blocks_per = (uint32_t)((per + 255) / 256);
@@ -76,7 +82,7 @@ template <typename T> class GenericEngine {
   }
 
  private:
-  struct Pass { int r = 0; uint32_t s = 0, m = 0; std::unique_ptr<DevBuf> tw; void (*fn)(GenArgs) = nullptr; size_t smem = 0; };
+  struct Pass { int r = 0; uint32_t s = 0, m = 0, lo_bits = 0; std::unique_ptr<DevBuf> tw_lo, tw_hi; void (*fn)(GenArgs) = nullptr; size_t smem = 0; };
   size_t n_;
   std::vector<Pass> passes_;
 };

@@ -392,7 +392,7 @@ template <typename T> class Pow2Engine {
       const TinyKernel fn = get_tiny_kernel(Real<T>{}, n_);
       FOURIER_LAUNCH(fn, (batch + 255) / 256, 256, 0, stream, a);
       PROF_END(prof);
-      apply_mul(out, batch, mul, inverse, scale, stream);
+      apply_mul(out, batch, mul, inverse, scale, stream, prof, slot0);
       return;
     }
     if (l2fused_enabled() && blu.io == IO_PLAIN && !mul) {
@@ -419,18 +419,21 @@ template <typename T> class Pow2Engine {
     }
     for (size_t p = 0; p < np; ++p)
       launch_pass(p, src[p], dst[p], batch, inverse, scale, stream, prof, slot0 + (int)p, nxcd, blu);
-    apply_mul(out, batch, mul, inverse, scale, stream);
+    apply_mul(out, batch, mul, inverse, scale, stream, prof, slot0 + (int)np - 1);
   }
 
   // Pointwise multiplier on the M-point spectrum of a forward, unscaled transform (bluesteins.rs:236-239): its own sweep.
   // Only the unfused Bluestein options take it (bluestein_fusion = 0, bluestein_conv = 0); the default plans multiply
-  // inside fft_conv_kernel / the one-launch kernels.  Untimed by profile(): those options exist for A/B and tests.
-  void apply_mul(cpx<T>* out, size_t batch, const cpx<T>* mul, bool inverse, double scale, hipStream_t stream) const {
+  // inside fft_conv_kernel / the one-launch kernels.  profile() adds its time to the slot of the last forward pass.
+  void apply_mul(cpx<T>* out, size_t batch, const cpx<T>* mul, bool inverse, double scale, hipStream_t stream,
+                 Profiler* prof = nullptr, int slot = 0) const {
     if (!mul) return;
     if (inverse || scale != 1.0) throw EngineError(::fourier::c::FOURIER_HIP_INVALID_ARGUMENT, "pointwise multiplier: forward unscaled only");
     BluArgs m{nullptr, out, mul, (uint64_t)n_, (uint64_t)n_, (uint64_t)batch, 0, 1.0};
     const size_t blocks = (batch * n_ + 255) / 256;
+    PROF_BEGIN(prof, slot);  // counted in the slot of the pass it follows (the last forward pass)
     FOURIER_LAUNCH(get_blu_kernel(Real<T>{}, 2), std::min<size_t>(std::max<size_t>(blocks, 1), 256 * 32), 256, 0, stream, m);
+    PROF_END(prof);
   }
 
   // One pass of the schedule.  inverse / scale / mul take effect on the passes they belong to (leading swap on

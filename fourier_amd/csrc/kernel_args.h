@@ -86,7 +86,9 @@ struct OddArgs {
 
 struct GenArgs {
   const void* in; void* out;
-  const void* tw;             // W_size^{e}, e < size (null when m == 1: the last pass has no twiddle, mod.rs:238)
+  const void* tw_lo;          // W_size^{e}, e < 2^lo_bits          } two-level table of the pass twiddle W_size^{i*k}, as in the
+  const void* tw_hi;          // W_size^{h << lo_bits}               } tile passes (null when m == 1: the last pass has no twiddle,
+  uint32_t lo_bits;           //                                       mod.rs:238)
   uint64_t n;                 // transform length (batch stride)
   uint32_t s, m;              // stride, butterflies per stride group; s * m = n / R
   uint32_t blocks_per;        // workgroups per transform

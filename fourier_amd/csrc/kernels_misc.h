@@ -117,11 +117,18 @@ __global__ void __launch_bounds__(256) stockham_pass_kernel(GenArgs a) {
   }
   if constexpr (R == 3 || R == 9 || R == 27) dft_pow3<T, R, R, 1>(x, a);
   else dft_r<T, R>(x);
-  const cpx<T>* tw = (const cpx<T>*)a.tw;
+  // W_size^{i*k} from a two-level table (2 * sqrt(size) entries, cache-resident) instead of the reference's size-entry table
+  // (mod.rs:24-46): one more complex multiply, no table the size of the transform in device memory
+  const cpx<T>* lo = (const cpx<T>*)a.tw_lo;
+  const cpx<T>* hi = (const cpx<T>*)a.tw_hi;
+  const uint32_t lo_mask = (1u << a.lo_bits) - 1u;
   const T scale = (T)a.scale;
 #pragma unroll
   for (int k = 0; k < R; ++k) {
-    if (tw && k > 0 && valid) x[k] = cmul(x[k], tw[(uint64_t)i * k]);
+    if (lo && k > 0 && valid) {
+      const uint64_t e = (uint64_t)i * (uint64_t)k;  // < size
+      x[k] = cmul(x[k], cmul(lo[e & lo_mask], hi[e >> a.lo_bits]));
+    }
     if (a.final_pass) {
       if (a.swap_out) x[k] = {x[k].im, x[k].re};
       x[k] = {x[k].re * scale, x[k].im * scale};

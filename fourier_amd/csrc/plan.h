@@ -120,8 +120,9 @@ template <typename T> class Plan {
     if (small_fused_) return (double)ELEM * 2.0 * n_;  // tables stay L2-resident
     const double chirp_reads = (chirp_compute_ ? 1.0 : 2.0) * n_;  // the n-entry chirp table: the chirp-out pass reads it, the chirp-in pass only without bluestein_chirp_compute
     if (fused_ && conv_) return (double)ELEM * (2.0 * m_ * (2.0 * eng_->num_passes() - 1.0) - 2.0 * (m_ - n_) + m_ + chirp_reads);
-    if (fused_) return (double)ELEM * (2.0 * 2.0 * m_ * eng_->num_passes() - 2.0 * (m_ - n_) + m_ + chirp_reads);
-    return (double)ELEM * ((2.0 * n_ + m_) + 2.0 * 2.0 * m_ * eng_->num_passes() + m_ + 3.0 * n_);
+    // without the conv kernel the product with w is a sweep of its own over the M-point spectrum: 2 m on top of the w table
+    if (fused_) return (double)ELEM * (2.0 * 2.0 * m_ * eng_->num_passes() - 2.0 * (m_ - n_) + 2.0 * m_ + m_ + chirp_reads);
+    return (double)ELEM * ((2.0 * n_ + m_) + 2.0 * 2.0 * m_ * eng_->num_passes() + 2.0 * m_ + m_ + 3.0 * n_);
   }
 
   int set_option(const std::string& key, long long v) {

@@ -86,12 +86,22 @@ enum {
   FOURIER_HIP_UNSUPPORTED = 4,      /* size outside the engine's range                           */
 };
 
-/* Create a plan on a specific device (-1 = current device).  Same plan factory as
- * `create_fft_f32/f64` (fourier/src/lib.rs:31-60) with one extension: Stockham autosort for 2^a * 3^b as in the reference
- * (`Autosort::new`, autosort/mod.rs:104-134), and -- where the reference takes Bluestein -- also for lengths whose prime
- * factors stop at 13 and that fit a compute unit's LDS (<= 20480 points in f32, 10240 in f64); Bluestein chirp-z
- * (fourier-algorithms/src/bluesteins.rs) for every other size.  `fourier_hip_describe_*` names the route taken.
- * NULL on failure. */
+/* Create a plan on a specific device (-1 = current device).  Same plan factory as `create_fft_f32/f64`
+ * (fourier/src/lib.rs:31-60): Stockham autosort for 2^a * 3^b as in the reference (`Autosort::new`, autosort/mod.rs:104-134),
+ * Bluestein chirp-z (fourier-algorithms/src/bluesteins.rs) otherwise -- with one extension: SOME lengths that the reference
+ * sends to Bluestein run as direct Stockham passes here (closer to the exact DFT than the chirp-z route, within the same
+ * tolerance).  The routes, in the order they are tried:
+ *   powers of two                                   big-radix Stockham passes (one, two or three HBM round trips)
+ *   2^a * 3^b, a >= 12                              the same passes over 2^a, then radix-27 / 9 / 3 passes
+ *   2^a * 3^b * 5^c * 7^d * 11^e * 13^f that fit one compute unit's LDS (<= 20480 points in f32, 10240 in f64) AND have a
+ *     kernel: every 2^a * 3^b; every such length with factors 5 (and the instantiated ones with a factor 7) has a per-length
+ *     kernel; any other length of this family up to 8192 points runs the runtime-parameterised kernel (f64 with a factor 11
+ *     or 13: up to 2048 points); the rest of the family takes Bluestein
+ *   2^a * 3^b, a < 12, beyond the LDS limit         one Stockham pass per radix in global memory (27 / 9 / 3, then 16 / 8 / 4 / 2)
+ *   every other length                              Bluestein over a power-of-two inner transform
+ * `fourier_hip_describe_*` names the route a handle took ("stockham 1024x1024", "stockham mixed-radix 5.5.5.8",
+ * "stockham global-pass 27.27.27.3", "bluestein M=... inner ..."); rely on it, not on this list, where the accuracy class
+ * (direct versus chirp-z) matters.  NULL on failure. */
 struct fourier_fft_float *fourier_hip_create_float(FOURIER_SIZE_TYPE size, int device);
 struct fourier_fft_double *fourier_hip_create_double(FOURIER_SIZE_TYPE size, int device);
 
