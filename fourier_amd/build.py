@@ -63,6 +63,7 @@ def translation_units():
         tus.append((f"kernels_onelaunch_{tag}", "kernels_onelaunch.cpp", d, "onelaunch"))
         tus.append((f"kernels_mixed_rt_{tag}", "kernels_mixed_rt.cpp", d, "mixed"))
         tus.append((f"kernels_misc_{tag}", "kernels_misc.cpp", d, "misc"))
+        tus.append((f"kernels_tiled_{tag}", "kernels_tiled.cpp", d, "mixed"))
         tus.append((f"kernels_experiments_{tag}", "kernels_experiments.cpp", d, "experiments"))
     return tus
 

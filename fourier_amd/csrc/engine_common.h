@@ -168,6 +168,9 @@ typedef void (*TinyKernel)(TinyArgs);
 typedef void (*GenKernel)(GenArgs);
 typedef void (*BluKernel)(BluArgs);
 typedef void (*MixKernelFn)(MixArgs);
+typedef void (*TiledKernelFn)(TiledArgs);
+// a tile pass of mixed length L: columns per tile, threads, LDS bytes
+struct TiledKernel { TiledKernelFn fn = nullptr; uint32_t L = 0, cols = 0, threads = 0; size_t smem = 0; };
 // a mixed-radix LDS kernel with its launch shape: transforms per workgroup, LDS buffers of `group` transforms, threads
 struct MixKernel { MixKernelFn fn; uint32_t group; size_t nbuf; uint32_t threads; };
 
@@ -213,6 +216,8 @@ template <typename T> struct Real {};
   /* kernels_mixed_ct.cpp, compiled FOURIER_MIX_SHARDS times per precision (-DFOURIER_MIX_SHARD=i): shard i of the  */  \
   /* per-length kernels; false when shard i holds no kernel for length n                                           */  \
   FOURIER_MIX_SHARD_LIST(FOURIER_DECLARE_MIX_SHARD, T)                                                                 \
+  /* kernels_tiled.cpp: column-tile pass of mixed length L = 2^x * 3^y, 64 <= L <= 512; fn == nullptr: no such kernel */ \
+  TiledKernel get_tiled_kernel(Real<T>, uint32_t L);                                                                   \
   /* kernels_experiments.cpp (experiments library) or env_product.cpp (product: nothing available) */                  \
   bool get_fused_kernel(Real<T>, int k, FusedInfo& info);                                                              \
   KernelInfo get_split_kernel(Real<T>, int L, int io);                                                                 \

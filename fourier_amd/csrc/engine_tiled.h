@@ -1,0 +1,157 @@
+// engine_tiled.h -- 2^a * 3^b with a < 12 beyond one compute unit's LDS as two or three big-radix passes of mixed length
+// on column tiles (kernels_tiled.h): N = L1 x L2 (x L3), every factor a pass length with a kernel.  The reference runs these
+// lengths natively, one small radix per sweep of memory (autosort/mod.rs:104-116, 203-284).
+#pragma once
+#include "engine_common.h"
+#include "mixed_schedule.h"
+
+namespace fourier_hip {
+
+template <typename T> class TiledMixedEngine {
+ public:
+  static constexpr size_t MAX_N = (size_t)1 << 26;
+  static const std::vector<uint32_t>& menu() {
+    static const std::vector<uint32_t> m = [] {
+      std::vector<uint32_t> v;
+      for (uint32_t L = 64; L <= 512; ++L) {
+        uint32_t r = L;
+        while (r % 2 == 0) r /= 2;
+        while (r % 3 == 0) r /= 3;
+        if (r == 1 && get_tiled_kernel(Real<T>{}, L).fn) v.push_back(L);
+      }
+      return v;
+    }();
+    return m;
+  }
+  // pass lengths, most balanced factorisation first: two factors if there is one, else three; empty: none
+  static std::vector<uint32_t> factorise(size_t n) {
+    std::vector<uint32_t> best;
+    uint32_t best_max = 0xffffffffu;
+    const auto& m = menu();
+    for (uint32_t a : m) {
+      if (n % a) continue;
+      const size_t r = n / a;
+      if (r <= 512 && r >= 64 && r <= a && std::find(m.begin(), m.end(), (uint32_t)r) != m.end() && a < best_max) {
+        best = {a, (uint32_t)r};
+        best_max = a;
+      }
+    }
+    if (!best.empty()) return best;
+    for (uint32_t a : m) {
+      if (n % a) continue;
+      for (uint32_t b : m) {
+        if (b > a || (n / a) % b) continue;
+        const size_t r = n / a / b;
+        if (r > b || r < 64 || std::find(m.begin(), m.end(), (uint32_t)r) == m.end()) continue;
+        if (a < best_max) { best = {a, b, (uint32_t)r}; best_max = a; }
+      }
+    }
+    return best;
+  }
+  static bool handles(size_t n) {
+    if (n < 4096 || n > MAX_N || dev_env("FOURIER_NO_TILED_MIXED")) return false;
+    size_t p = n;
+    while (p % 3 == 0) p /= 3;
+    if (!is_pow2(p) || p == n || p >= 4096) return false;  // 2^a * 3^b, b >= 1, a < 12 (a >= 12: power-of-two tiles + odd passes)
+    return !factorise(n).empty();
+  }
+
+  explicit TiledMixedEngine(size_t n) : n_(n) {
+    const std::vector<uint32_t> lens = factorise(n);
+    if (lens.empty()) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "no tile factorisation");
+    uint64_t s = 1, size = n;
+    for (uint32_t L : lens) {
+      Pass ps;
+      ps.k = get_tiled_kernel(Real<T>{}, L);
+      ps.s = s; ps.m = size / L;
+      raise_smem_limit((const void*)ps.k.fn, ps.k.smem);
+      // tables of the in-tile transform: the reference's layout for a plan of length L (mod.rs:24-46), f64 trig then cast
+      auto it = tables_.find(L);
+      if (it == tables_.end()) {
+        std::vector<cpx<T>> tw;
+        size_t cur = L;
+        while (cur > 1) {
+          const size_t R = mix_next_radix(L, (uint32_t)cur, cur == L);
+          const size_t mm = cur / R;
+          for (size_t i = 0; i < mm; ++i) {
+            tw.push_back({(T)1, (T)0});
+            for (size_t j = 1; j < R; ++j) tw.push_back(ref_twiddle(i * j, cur));
+          }
+          cur /= R;
+        }
+        auto buf = std::unique_ptr<DevBuf>(new DevBuf());
+        buf->upload(tw);
+        it = tables_.emplace(L, std::move(buf)).first;
+      }
+      ps.tw = it->second.get();
+      if (ps.m > 1) {  // inter-pass twiddle W_size^{i*k}, two-level
+        const int lb = (ilog2(size) + 1) / 2;
+        ps.lo_bits = (uint32_t)lb;
+        std::vector<cpx<T>> lo((size_t)1 << lb), hi((size_t)(size >> lb) + 1);
+        for (size_t e = 0; e < lo.size(); ++e) { double re, im; unit_root(e, size, re, im); lo[e] = {(T)re, (T)im}; }
+        for (size_t h = 0; h < hi.size(); ++h) { double re, im; unit_root((uint64_t)h << lb, size, re, im); hi[h] = {(T)re, (T)im}; }
+        ps.tw_lo.reset(new DevBuf()); ps.tw_hi.reset(new DevBuf());
+        ps.tw_lo->upload(lo); ps.tw_hi->upload(hi);
+      }
+      passes_.push_back(std::move(ps));
+      s *= L; size /= L;
+    }
+  }
+  size_t num_passes() const { return passes_.size(); }
+  std::string describe() const {
+    std::string d;
+    for (const Pass& p : passes_) d += (d.empty() ? "" : "x") + std::to_string(p.k.L);
+    return d;
+  }
+  // scratch: batch * n elements; needed by in-place calls and by three-pass plans
+  bool needs_scratch(bool in_place) const { return in_place || passes_.size() >= 3; }
+  void run(const cpx<T>* in, cpx<T>* out, cpx<T>* scratch, size_t batch, bool inverse, double scale, hipStream_t stream, Profiler* prof) const {
+    if (batch == 0) return;
+    const size_t np = passes_.size();
+    const bool in_place = ((const void*)in == (const void*)out);
+    // every pass but the last is out of place; the last (same columns in and out) may run in place.  Two passes: in -> out ->
+    // out, or in -> scratch -> out for an in-place call; three passes: in -> scratch -> out -> out (the input is dead after the first pass)
+    const cpx<T>* src = in;
+    for (size_t p = 0; p < np; ++p) {
+      const Pass& ps = passes_[p];
+      cpx<T>* dst = out;
+      if (p + 1 < np) dst = (np == 2) ? (in_place ? scratch : out) : (p == 0 ? scratch : out);
+      TiledArgs a;
+      std::memset(&a, 0, sizeof(a));
+      a.in = src; a.out = dst; a.tw = ps.tw->p;
+      a.tw_lo = ps.m > 1 ? ps.tw_lo->p : nullptr; a.tw_hi = ps.m > 1 ? ps.tw_hi->p : nullptr; a.lo_bits = ps.lo_bits;
+      a.n = n_; a.s = ps.s; a.m = ps.m;
+      const uint64_t columns = ps.s == 1 ? ps.m : ps.s;
+      a.tiles_per_row = (columns + ps.k.cols - 1) / ps.k.cols;
+      a.swap_in = (p == 0) && inverse; a.swap_out = (p + 1 == np) && inverse;
+      a.scale = (p + 1 == np) ? scale : 1.0;
+      const cpx<T> w3 = ref_twiddle(1, 3), w8 = ref_twiddle(1, 8);
+      a.w3re = w3.re; a.w3im = w3.im; a.w8re = w8.re; a.w8im = w8.im;
+      const uint64_t grid = (uint64_t)batch * a.tiles_per_row * (ps.s == 1 ? 1 : ps.m);
+      if (grid > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");
+      PROF_BEGIN(prof, (int)p);
+      FOURIER_LAUNCH(ps.k.fn, grid, ps.k.threads, ps.k.smem, stream, a);
+      PROF_END(prof);
+      src = dst;
+    }
+  }
+
+ private:
+  // twiddle.rs:7-19: theta = (index*2) as f64 * PI / size as f64; (cos, -sin) cast to T
+  static cpx<T> ref_twiddle(size_t index, size_t size) {
+    const double theta = (double)(index * 2) * M_PI / (double)size;
+    return {(T)std::cos(theta), (T)(-std::sin(theta))};
+  }
+  struct Pass {
+    TiledKernel k;
+    uint64_t s = 1, m = 1;
+    uint32_t lo_bits = 0;
+    DevBuf* tw = nullptr;
+    std::unique_ptr<DevBuf> tw_lo, tw_hi;
+  };
+  size_t n_;
+  std::vector<Pass> passes_;
+  std::map<uint32_t, std::unique_ptr<DevBuf>> tables_;
+};
+
+}  // namespace fourier_hip

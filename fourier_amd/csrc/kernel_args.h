@@ -102,6 +102,20 @@ struct BluArgs {
   uint64_t n, m, batch; int swap; double scale;
 };
 
+// ---- big-radix passes of mixed length on column tiles (kernels_tiled.h)
+struct TiledArgs {
+  const void* in; void* out;
+  const void* tw;             // tables of the in-tile length-L transform, the reference's per-pass layout (mod.rs:24-46)
+  const void* tw_lo;          // two-level table of the inter-pass twiddle W_size^{i*k} (null in the last pass)
+  const void* tw_hi;
+  uint32_t lo_bits;
+  uint64_t n, s, m;           // transform length (batch stride); Stockham stride; size / L (1 in the last pass)
+  uint64_t tiles_per_row;     // ceil(columns / COLS): columns = m in the first pass (s == 1), s afterwards
+  int swap_in, swap_out;
+  double scale;               // applied by the last pass
+  double w3re, w3im, w8re, w8im;  // compute_twiddle(1, 3, true), compute_twiddle(1, 8, true) as T values (butterfly.rs:12,50)
+};
+
 // ---- XCD-fused one-launch plan (kernels_experiments.h)
 struct FusedArgs {
   PassArgs a, b;       // pass A / pass B arguments; a.in, a.out, b.in, b.out are set per item

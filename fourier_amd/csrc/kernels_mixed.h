@@ -275,8 +275,12 @@ __global__ void __launch_bounds__(NT, FOURIER_MIX_RT_WAVES(T, MAXP, PPT)) mixed_
 // lengths: schedule, sizes, strides and table offsets are constants, so the per-butterfly index arithmetic
 // (two runtime divisions in mixed_pass) folds into multiply-shifts and the pass loop unrolls.  Same operations in
 // the same order: still bit-identical to the CPU restatement.
-template <typename T, uint32_t N, uint32_t SIZE, uint32_t STRIDE, uint32_t TWOFF, bool FIRST_PASS> struct MixPassesCT {
-  static constexpr uint32_t R = mix_next_radix(N, SIZE, FIRST_PASS), M = SIZE / R, NT = mix_threads<T>(N);
+// GROUP transforms per workgroup on NT threads, transform g at element g * LD of the buffer (defaults: the per-length kernels'
+// own rules; the tile passes of kernels_tiled.h run COLS = GROUP columns at a padded leading dimension)
+template <typename T, uint32_t N, uint32_t SIZE, uint32_t STRIDE, uint32_t TWOFF, bool FIRST_PASS, uint32_t GROUP = mix_group<T>(N),
+          uint32_t NT_ = mix_threads<T>(N), uint32_t LD = N>
+struct MixPassesCT {
+  static constexpr uint32_t R = mix_next_radix(N, SIZE, FIRST_PASS), M = SIZE / R, NT = NT_;
   static constexpr bool PAIR = ((R == 3 || R == 5) && SIZE >= R * R && (SIZE / R) % R == 0 && mix_pairs<T>(N, R));
   // two consecutive radix-R passes (R = 3, 5) on one LDS round trip: the R butterflies (i + M2*k2, j), k2 < R, of this pass
   // write exactly the inputs of the R butterflies (i, j + STRIDE*k), k < R, of the next one, so a thread that
@@ -293,9 +297,9 @@ template <typename T, uint32_t N, uint32_t SIZE, uint32_t STRIDE, uint32_t TWOFF
   static __device__ __forceinline__ void compute(const cpx<T>* src, const cpx<T>* tw, uint32_t q, bool fwd, cpx<T> w3, cpx<T> w8,
                                                  cpx<T> (&y)[PTS], uint32_t& out_off) {
     const uint32_t g = q / NBF, e = q % NBF, i = e / STRIDE, j = e % STRIDE;  // constants: multiply-shift
-    const cpx<T>* in = src + g * N + j + STRIDE * i;
+    const cpx<T>* in = src + g * LD + j + STRIDE * i;
     const cpx<T>* __restrict__ t = tw + TWOFF;
-    out_off = g * N + j + PTS * STRIDE * i;
+    out_off = g * LD + j + PTS * STRIDE * i;
     if constexpr (PAIR) {
       const cpx<T>* __restrict__ t2 = tw + TWOFF + SIZE;
       cpx<T> x[R][R];
@@ -354,7 +358,7 @@ template <typename T, uint32_t N, uint32_t SIZE, uint32_t STRIDE, uint32_t TWOFF
   static __device__ __forceinline__ const cpx<T>* run(const cpx<T>* src, cpx<T>* dst, const cpx<T>* tw, uint32_t nb, bool fwd,
                                                      cpx<T> w3, cpx<T> w8) {
     if constexpr (mix_inplace<T>(N)) {
-      constexpr uint32_t ROUNDS = (mix_group<T>(N) * NBF + NT - 1) / NT;
+      constexpr uint32_t ROUNDS = (GROUP * NBF + NT - 1) / NT;
       cpx<T> y[ROUNDS][PTS];
       uint32_t off[ROUNDS];
 #pragma unroll
@@ -377,7 +381,7 @@ template <typename T, uint32_t N, uint32_t SIZE, uint32_t STRIDE, uint32_t TWOFF
       }
       __syncthreads();
       if constexpr (LAST) return src;
-      else return MixPassesCT<T, N, OUT_SIZE, OUT_STRIDE, OUT_TWOFF, false>::run(src, dst, tw, nb, fwd, w3, w8);
+      else return MixPassesCT<T, N, OUT_SIZE, OUT_STRIDE, OUT_TWOFF, false, GROUP, NT_, LD>::run(src, dst, tw, nb, fwd, w3, w8);
     } else {
       for (uint32_t q = threadIdx.x; q < nb * NBF; q += NT) {
         cpx<T> y[PTS];
@@ -388,7 +392,7 @@ template <typename T, uint32_t N, uint32_t SIZE, uint32_t STRIDE, uint32_t TWOFF
       }
       __syncthreads();
       if constexpr (LAST) return dst;
-      else return MixPassesCT<T, N, OUT_SIZE, OUT_STRIDE, OUT_TWOFF, false>::run(dst, const_cast<cpx<T>*>(src), tw, nb, fwd, w3, w8);
+      else return MixPassesCT<T, N, OUT_SIZE, OUT_STRIDE, OUT_TWOFF, false, GROUP, NT_, LD>::run(dst, const_cast<cpx<T>*>(src), tw, nb, fwd, w3, w8);
     }
   }
 };

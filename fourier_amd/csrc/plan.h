@@ -4,6 +4,7 @@
 #include "engine_pow2.h"
 #include "engine_mixed.h"
 #include "engine_generic.h"
+#include "engine_tiled.h"
 
 namespace fourier_hip {
 
@@ -53,8 +54,10 @@ template <typename T> class Plan {
       // efficiency beat the one-workgroup-per-CU LDS kernel where both apply (3*2^12 f32: 23 % vs 14 %)
       eng_.reset(new Pow2Engine<T>(n));
     } else if (MixedEngine<T>::handles(n) && try_mixed(n)) {
+    } else if (TiledMixedEngine<T>::handles(n)) {
+      tiled_.reset(new TiledMixedEngine<T>(n));  // two or three HBM round trips on column tiles of mixed length
     } else if (GenericEngine<T>::handles(n)) {
-      gen_.reset(new GenericEngine<T>(n));
+      gen_.reset(new GenericEngine<T>(n));       // what is left of 2^a*3^b, a < 12: one round trip per radix
     } else {
       init_bluestein();
     }
@@ -72,6 +75,7 @@ template <typename T> class Plan {
   }
   void refresh_desc() {
     if (mix_) desc_ = "stockham mixed-radix " + mix_->describe();
+    else if (tiled_) desc_ = "stockham mixed tiles " + tiled_->describe();
     else if (gen_) desc_ = "stockham global-pass " + gen_->describe();
     else if (blu_) desc_ = "bluestein M=" + std::to_string(m_) + " inner " + eng_->describe() + (small_fused_ ? " fused" : "");
     else desc_ = "stockham " + eng_->describe();
@@ -97,6 +101,7 @@ template <typename T> class Plan {
   std::string slot_names() const {
     std::string d;
     if (mix_) return "mixed_radix";
+    if (tiled_) { for (size_t p = 0; p < tiled_->num_passes(); ++p) d += std::string(d.empty() ? "" : ",") + "pass" + std::to_string(p); return d; }
     if (gen_) { for (size_t p = 0; p < gen_->num_passes(); ++p) d += std::string(d.empty() ? "" : ",") + "pass" + std::to_string(p); return d; }
     auto passes = [&](const char* tag) {
       for (size_t p = 0; p < (blu_ ? eng_->num_passes() : eng_->hbm_round_trips()); ++p) d += std::string(d.empty() ? "" : ",") + tag + std::to_string(p);
@@ -113,6 +118,7 @@ template <typename T> class Plan {
 
   double model_bytes() const {
     if (mix_) return 2.0 * n_ * ELEM;
+    if (tiled_) return 2.0 * n_ * ELEM * tiled_->num_passes();
     if (gen_) return 2.0 * n_ * ELEM * gen_->num_passes();
     if (!blu_) return 2.0 * n_ * ELEM * eng_->hbm_round_trips();
     // unfused: pre (n + table read, m write) + 2 inner FFTs + w table + post (n + table read, n write);
@@ -165,6 +171,20 @@ template <typename T> class Plan {
   // captured into a HIP graph.  Returns the number of transforms per chunk.
   size_t prepare(size_t batch, bool in_place) const {
     if (mix_ || batch == 0) return batch;
+    if (tiled_) {  // one scratch of a chunk for in-place calls and three-pass plans
+      size_t chunk = batch;
+      if (chunk_bytes_) chunk = std::max<size_t>(1, std::min<size_t>(batch, chunk_bytes_ / (n_ * ELEM)));
+      while (chunk > 1 && (double)chunk * (double)n_ / 8.0 > 2.0e9) chunk = (chunk + 1) / 2;
+      if (!(tiled_->needs_scratch(in_place) || force_scratch_)) return chunk;
+      for (;;) {
+        try { scratch_.ensure(chunk * n_ * ELEM); return chunk; }
+        catch (const EngineError& e) {
+          if (e.status != ::fourier::c::FOURIER_HIP_OUT_OF_MEMORY || chunk <= 1) throw;
+          (void)hipGetLastError();
+          chunk = (chunk + 1) / 2;
+        }
+      }
+    }
     if (gen_) {  // two scratch halves of one chunk each; chunked so that a launch stays below 2^31 workgroups
       size_t chunk = batch;
       if (chunk_bytes_) chunk = std::max<size_t>(1, std::min<size_t>(batch, chunk_bytes_ / (n_ * ELEM)));
@@ -238,6 +258,13 @@ template <typename T> class Plan {
     }
     const size_t chunk = prepare(batch, in_place);
 
+    if (tiled_) {
+      for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+        const size_t nb = std::min(chunk, batch - b0);
+        tiled_->run(in + b0 * n_, out + b0 * n_, (cpx<T>*)scratch_.p, nb, inverse, scale, stream, prof);
+      }
+      return;
+    }
     if (gen_) {
       for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const size_t nb = std::min(chunk, batch - b0);
@@ -545,7 +572,8 @@ template <typename T> class Plan {
   bool blu_ = false;
   std::unique_ptr<Pow2Engine<T>> eng_, eng_inv_;  // eng_inv_: mirrored inverse plan of a conv-fused Bluestein
   std::unique_ptr<MixedEngine<T>> mix_;
-  std::unique_ptr<GenericEngine<T>> gen_;  // 2^a*3^b, a < 12, beyond the LDS kernels
+  std::unique_ptr<TiledMixedEngine<T>> tiled_;  // 2^a*3^b, a < 12, beyond the LDS kernels: column tiles of mixed length
+  std::unique_ptr<GenericEngine<T>> gen_;  // ... and what has no tile factorisation: one global pass per radix
   DevBuf xtab_, wtab_;
   DevBuf chirp_p_, chirp_u_, tn_lo_, tn_hi_;  // chirp-in pass computing the chirp (init_bluestein)
   uint32_t tn_bits_ = 0;

@@ -167,7 +167,7 @@ def test_mixed_radix_sizes_are_bit_identical_to_the_oracle(fa, oracle):
     assert "mixed-radix" in make(fa, 18432, np.complex64).describe()  # one in-place LDS buffer of 144 KiB
     assert "mixed-radix" in make(fa, 19683, np.complex64).describe()  # 3^9: 154 of the 160 KiB
     assert "mixed-radix" in make(fa, 9216, np.complex128).describe()
-    assert "global-pass" in make(fa, 10368, np.complex128).describe()   # f64: above the LDS-resident limit (9216): pass by pass in global memory
+    assert "mixed tiles 108x96" in make(fa, 10368, np.complex128).describe()   # f64: above the LDS-resident limit (9216): two passes on column tiles
     assert "x3" in make(fa, 12288, np.complex64).describe()           # 3*2^12: tiled passes + odd pass, not the LDS kernel
     for n, dtype in ((6144, np.complex64), (9216, np.complex64), (18432, np.complex64), (13122, np.complex64),
                      (4608, np.complex128), (9216, np.complex128), (6561, np.complex128)):
@@ -204,26 +204,38 @@ def test_large_mixed_radix_sizes_run_natively(fa, oracle):
                 assert rel_l2(run_batch(plan, x.astype(dtype), code, inplace=True), ref) <= tl2, (n, code)
     assert make(fa, 729 * 4096, np.complex64).describe().startswith("stockham 64x64x27x27")
     assert "mixed-radix" in make(fa, 3 * 2048, np.complex128).describe()  # too little 2^a for two tiled passes: LDS kernel
-    assert "global-pass" in make(fa, 9 * 2048, np.complex128).describe()   # f64 18432: beyond the LDS and the tiled routes: global-memory passes
+    assert "mixed tiles 144x128" in make(fa, 9 * 2048, np.complex128).describe()   # f64 18432: beyond the LDS route, a < 12: column tiles of mixed length
 
 
-def test_mixed_radix_sizes_beyond_the_lds_limit_with_a_small_power_of_two_run_pass_by_pass(fa, oracle, monkeypatch):
-    """2^a * 3^b with a < 12 above 18432 (f32) / 9216 (f64) points used to fall to Bluestein (missing
-    #4); the reference runs them in its Stockham path (autosort/mod.rs:104-116).  Now: one global-memory Stockham pass
-    per radix (27 / 9 / 3, then 16 / 8 / 4 / 2).  All five codes, in and out of place, ragged batch, against the oracle
-    and (experiments build) against the Bluestein route they replace."""
-    for n, dtype, tol in ((59049, np.complex64, 1e-6), (62208, np.complex64, 1e-6), (20736, np.complex64, 1e-6),
-                          (10368, np.complex128, 5e-14), (13122, np.complex128, 5e-14)):
+def test_mixed_radix_sizes_beyond_the_lds_limit_with_a_small_power_of_two_run_as_tiled_passes(fa, oracle, monkeypatch):
+    """2^a * 3^b with a < 12 above 19683 (f32) / 9216 (f64) points: the reference runs them in its Stockham path, one small
+    radix per sweep (autosort/mod.rs:104-116).  Here: two or three big-radix passes of MIXED length on column tiles
+    (kernels_tiled.h; round 4), and for the rare length without such a factorisation one global-memory pass per radix (27 / 9 /
+    3, then 16 / 8 / 4 / 2; round 3).  All five codes, in and out of place, ragged batch and ragged tiles (lengths without a
+    factor 16), against the oracle; the two routes against each other and against the Bluestein route they replaced."""
+    for n, dtype, tol, desc in ((59049, np.complex64, 1e-6, "243x243"), (62208, np.complex64, 1e-6, "256x243"), (20736, np.complex64, 1e-6, "144x144"),
+                                (10368, np.complex128, 5e-14, "108x96"), (13122, np.complex128, 5e-14, "162x81"),
+                                (2 * 3 ** 13, np.complex64, 1e-6, "243x162x81")):
         plan = make(fa, n, dtype)
-        assert "global-pass" in plan.describe(), plan.describe()
-        x = np.stack([hash_normal(900 + b, n) for b in range(2)]).astype(dtype)
+        assert "mixed tiles " + desc in plan.describe(), plan.describe()
+        x = np.stack([hash_normal(900 + b, n) for b in range(2 if n < 10 ** 6 else 1)]).astype(dtype)
         for code in (range(5) if n < 30000 else (0, 1)):  # every code on the small ones (the GPU test runs all five on all)
             ref = oracle.transform_batch(x, code)
             assert rel_l2(run_batch(plan, x, code), ref) <= tol, (n, code)
             assert rel_l2(run_batch(plan, x, code, inplace=True), ref) <= tol, (n, code, "in place")
+    monkeypatch.setenv("FOURIER_NO_TILED_MIXED", "1")
+    for n, dtype, tol in ((59049, np.complex64, 1e-6), (10368, np.complex128, 5e-14)):
+        gen = make(fa, n, dtype)
+        assert "global-pass" in gen.describe(), gen.describe()
+        x = np.stack([hash_normal(900 + b, n) for b in range(2)]).astype(dtype)
+        for code in (0, 1, 3):
+            ref = oracle.transform_batch(x, code)
+            assert rel_l2(run_batch(gen, x, code), ref) <= tol, (n, code)
+            assert rel_l2(run_batch(gen, x, code, inplace=True), ref) <= tol, (n, code, "in place")
     monkeypatch.setenv("FOURIER_NO_GENERIC_MIXED", "1")
     blu = make(fa, 62208, np.complex64)
     assert "bluestein" in blu.describe()
+    monkeypatch.delenv("FOURIER_NO_TILED_MIXED")
     x = hash_normal(5, 62208).astype(np.complex64)[None, :]
     assert rel_l2(run_batch(blu, x, 0), run_batch(make(fa, 62208, np.complex64), x, 0)) <= 2e-6
 

@@ -956,18 +956,22 @@ def test_bluestein_chirp_in_pass_computes_the_chirp(torch, fa, oracle, n, dtype,
 @pytest.mark.parametrize("n,dtype,tol", [(59049, np.complex64, 1e-6), (62208, np.complex64, 1e-6), (39366, np.complex64, 1e-6),
                                          (55296, np.complex64, 1e-6), (20736, np.complex64, 1e-6), (2 * 3 ** 13, np.complex64, 1e-6),
                                          (10368, np.complex128, 5e-14), (13122, np.complex128, 5e-14), (2048 * 3 ** 9, np.complex128, 5e-14)])
-def test_mixed_radix_sizes_beyond_the_lds_limit_with_a_small_power_of_two(torch, fa, oracle, n, dtype, tol):
-    """2^a * 3^b with a < 12 above the LDS kernels' 18432 (f32) / 9216 (f64) points: the reference's Stockham pass by pass
-    in global memory (stockham_pass_kernel, radices 27 / 9 / 3 then 16 / 8 / 4 / 2) instead of Bluestein.  All five
-    codes, in and out of place, a ragged batch, against the oracle."""
-    plan = make(fa, n, dtype)
-    assert "global-pass" in plan.describe(), plan.describe()
+def test_mixed_radix_sizes_beyond_the_lds_limit_with_a_small_power_of_two(torch, fa, fa_exp, oracle, monkeypatch, n, dtype, tol):
+    """2^a * 3^b with a < 12 above the LDS kernels' 19683 (f32) / 9216 (f64) points: two or three big-radix passes of mixed
+    length on column tiles (kernels_tiled.h, round 4) -- and, for the rare length without such a factorisation and as the A/B
+    arm of the experiments library, the reference's Stockham pass by pass in global memory (stockham_pass_kernel, radices
+    27 / 9 / 3 then 16 / 8 / 4 / 2).  All five codes, in and out of place, a ragged batch, ragged tiles, against the oracle."""
     batch = 5 if n < 1 << 20 else 2
     x = np.stack([hash_normal(1900 + b, n) for b in range(batch)]).astype(dtype)
-    for code in range(5):
-        ref = oracle.transform_batch(x, code)
-        assert rel_l2(gpu_batch(torch, fa, plan, x, code), ref) <= tol, (n, code)
-        assert rel_l2(gpu_batch(torch, fa, plan, x, code, inplace=True), ref) <= tol, (n, code, "in place")
+    for route in ("mixed tiles", "global-pass"):
+        if route == "global-pass":
+            monkeypatch.setenv("FOURIER_NO_TILED_MIXED", "1")  # honoured by the experiments library only (fa_exp is bound)
+        plan = make(fa, n, dtype)
+        assert route in plan.describe(), plan.describe()
+        for code in range(5):
+            ref = oracle.transform_batch(x, code)
+            assert rel_l2(gpu_batch(torch, fa, plan, x, code), ref) <= tol, (n, code, route)
+            assert rel_l2(gpu_batch(torch, fa, plan, x, code, inplace=True), ref) <= tol, (n, code, route, "in place")
 
 
 @pytest.mark.parametrize("n", [5, 35, 125, 143, 625, 1000, 1001, 2401, 3125, 4095, 5005, 9100, 10000, 15625, 16807, 20000, 20480])
