@@ -32,7 +32,7 @@ template <typename T> class MixedEngine {
     // runtime-parameterised: about 1024 points per workgroup up to 1024 points, then one transform per workgroup -- 256 threads
     // x 4 / 8 points up to 2048 points, 512 x 8 up to 4096, 1024 x 8 up to 8192 (1024 x 4 for 2049..4096 measured slower than
     // 256 x 16: 3125 f32 19 % against 24 %, r03_s22)
-    Kernel k{nullptr, (uint32_t)std::max<size_t>(1, 1024 / n), 1, 256};
+    Kernel k{nullptr, (uint32_t)std::max<size_t>(1, 1024 / n), 1, 256, false};
     const int maxp = (n % 11 == 0 || n % 13 == 0) ? 13 : ((n % 5 == 0 || n % 7 == 0) ? 7 : 3);
     const size_t pts = k.group * n;
     const Real<T> real{};
@@ -86,7 +86,7 @@ template <typename T> class MixedEngine {
     // fill the 256 threads better lose more in occupancy than they gain, r01 session 9)
     const Kernel k = pick_kernel(n);
     fn_ = k.fn; group_ = k.group; nbuf_ = k.nbuf; threads_ = k.threads;
-    smem_ = nbuf_ * (size_t)group_ * n * sizeof(cpx<T>);
+    smem_ = nbuf_ * (size_t)group_ * n * sizeof(cpx<T>) + (k.tw_lds ? tw.size() * sizeof(cpx<T>) : 0);  // + the tables staged in LDS
     if (smem_ > MAX_LDS) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "mixed-radix length needs the per-length kernel");
     raise_smem_limit((const void*)fn_, smem_);
   }

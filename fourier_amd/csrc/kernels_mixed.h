@@ -278,8 +278,11 @@ __global__ void __launch_bounds__(NT, FOURIER_MIX_RT_WAVES(T, MAXP, PPT)) mixed_
 // GROUP transforms per workgroup on NT threads, transform g at element g * LD of the buffer (defaults: the per-length kernels'
 // own rules; the tile passes of kernels_tiled.h run COLS = GROUP columns at a padded leading dimension)
 template <typename T, uint32_t N, uint32_t SIZE, uint32_t STRIDE, uint32_t TWOFF, bool FIRST_PASS, uint32_t GROUP = mix_group<T>(N),
-          uint32_t NT_ = mix_threads<T>(N), uint32_t LD = N>
+          uint32_t NT_ = mix_threads<T>(N), uint32_t LD = N, bool TWL = false>
 struct MixPassesCT {
+  // entry (butterfly i, output k) of a pass's table of m butterflies: the reference's layout [i][k] (mod.rs:24-46), or -- TWL, the
+  // copy staged in LDS by stage_tables() -- transposed [k][i]
+  static __device__ __forceinline__ constexpr uint32_t tw_at(uint32_t i, uint32_t k, uint32_t r, uint32_t m) { return TWL ? k * m + i : i * r + k; }
   static constexpr uint32_t R = mix_next_radix(N, SIZE, FIRST_PASS), M = SIZE / R, NT = NT_;
   static constexpr bool PAIR = ((R == 3 || R == 5) && SIZE >= R * R && (SIZE / R) % R == 0 && mix_pairs<T>(N, R));
   // two consecutive radix-R passes (R = 3, 5) on one LDS round trip: the R butterflies (i + M2*k2, j), k2 < R, of this pass
@@ -315,7 +318,7 @@ struct MixPassesCT {
         ref_butterfly<T, (int)R>(x[k2], fwd, w3, w8);
 #pragma unroll
         for (uint32_t k = 1; k < R; ++k) {
-          cpx<T> w = t[(i + M2 * k2) * R + k];
+          cpx<T> w = t[tw_at(i + M2 * k2, k, R, M)];
           if (!fwd) w.im = -w.im;
           x[k2][k] = ref_mul(x[k2][k], w);
         }
@@ -329,7 +332,7 @@ struct MixPassesCT {
         if constexpr (SIZE2 != R) {
 #pragma unroll
           for (uint32_t k2 = 1; k2 < R; ++k2) {
-            cpx<T> w = t2[i * R + k2];
+            cpx<T> w = t2[tw_at(i, k2, R, M2)];
             if (!fwd) w.im = -w.im;
             z[k2] = ref_mul(z[k2], w);
           }
@@ -347,7 +350,7 @@ struct MixPassesCT {
       if constexpr (SIZE != R) {  // mod.rs:238,272
 #pragma unroll
         for (uint32_t k = 1; k < R; ++k) {
-          cpx<T> w = t[i * R + k];
+          cpx<T> w = t[tw_at(i, k, R, M)];
           if (!fwd) w.im = -w.im;
           y[k] = ref_mul(y[k], w);
         }
@@ -355,6 +358,22 @@ struct MixPassesCT {
     }
   }
 
+  using Next = MixPassesCT<T, N, OUT_SIZE, OUT_STRIDE, OUT_TWOFF, false, GROUP, NT_, LD, TWL>;
+  // entries of all tables from this pass on (the host uploads them back to back, mod.rs:24-46)
+  static constexpr uint32_t table_end() {
+    if constexpr (LAST) return OUT_TWOFF; else return Next::table_end();
+  }
+  // copies this and the following passes' tables from global memory into LDS, transposed (every thread of the workgroup; the
+  // caller's next barrier publishes them).  A table that is never read (size == R: no twiddle, mod.rs:238) is skipped.
+  static __device__ __forceinline__ void stage_tables(const cpx<T>* g, cpx<T>* l) {
+    if constexpr (SIZE != R) {
+      for (uint32_t e = threadIdx.x; e < SIZE; e += NT) l[TWOFF + (e % R) * M + e / R] = g[TWOFF + e];
+    }
+    if constexpr (PAIR && SIZE2 != R) {
+      for (uint32_t e = threadIdx.x; e < SIZE2; e += NT) l[TWOFF + SIZE + (e % R) * M2 + e / R] = g[TWOFF + SIZE + e];
+    }
+    if constexpr (!LAST) Next::stage_tables(g, l);
+  }
   static __device__ __forceinline__ const cpx<T>* run(const cpx<T>* src, cpx<T>* dst, const cpx<T>* tw, uint32_t nb, bool fwd,
                                                      cpx<T> w3, cpx<T> w8) {
     if constexpr (mix_inplace<T>(N)) {
@@ -381,7 +400,7 @@ struct MixPassesCT {
       }
       __syncthreads();
       if constexpr (LAST) return src;
-      else return MixPassesCT<T, N, OUT_SIZE, OUT_STRIDE, OUT_TWOFF, false, GROUP, NT_, LD>::run(src, dst, tw, nb, fwd, w3, w8);
+      else return MixPassesCT<T, N, OUT_SIZE, OUT_STRIDE, OUT_TWOFF, false, GROUP, NT_, LD, TWL>::run(src, dst, tw, nb, fwd, w3, w8);
     } else {
       for (uint32_t q = threadIdx.x; q < nb * NBF; q += NT) {
         cpx<T> y[PTS];
@@ -392,7 +411,7 @@ struct MixPassesCT {
       }
       __syncthreads();
       if constexpr (LAST) return dst;
-      else return MixPassesCT<T, N, OUT_SIZE, OUT_STRIDE, OUT_TWOFF, false, GROUP, NT_, LD>::run(dst, const_cast<cpx<T>*>(src), tw, nb, fwd, w3, w8);
+      else return MixPassesCT<T, N, OUT_SIZE, OUT_STRIDE, OUT_TWOFF, false, GROUP, NT_, LD, TWL>::run(dst, const_cast<cpx<T>*>(src), tw, nb, fwd, w3, w8);
     }
   }
 };
@@ -418,11 +437,20 @@ __global__ void __launch_bounds__(mix_threads<T>(N)) mixed_radix_kernel_ct(MixAr
     for (uint32_t u = threadIdx.x; u < units; u += NT) *(Unit16<T>*)(buf0 + u * VEC) = load_unit_a8<T>(in + u * VEC);
     if ((total % VEC) && threadIdx.x == 0) buf0[total - 1] = in[total - 1];
   }
+  // twiddle tables shared by the GROUP transforms of this workgroup: staged in LDS behind the data (mix_tw_lds)
+  constexpr bool TWL = mix_tw_lds<T>(N);
+  using Passes = MixPassesCT<T, N, N, 1, 0, true, GROUP, NT, N, TWL>;
+  const cpx<T>* tw = (const cpx<T>*)a.tw;
+  if constexpr (TWL) {
+    cpx<T>* ltw = buf0 + (size_t)(mix_inplace<T>(N) ? 1 : 2) * GROUP * N;
+    Passes::stage_tables(tw, ltw);
+    tw = ltw;
+  }
   __syncthreads();
   const bool fwd = a.forward != 0;
   cpx<T> w3{(T)a.w3re, (T)a.w3im}, w8{(T)a.w8re, (T)a.w8im};
   if (!fwd) { w3.im = -w3.im; w8.im = -w8.im; }
-  const cpx<T>* res = MixPassesCT<T, N, N, 1, 0, true>::run(buf0, buf1, (const cpx<T>*)a.tw, nb, fwd, w3, w8);
+  const cpx<T>* res = Passes::run(buf0, buf1, tw, nb, fwd, w3, w8);
   const T scale = a.scaled ? (T)a.scale : (T)1;  // mod.rs:387-393 (the unscaled codes skip the multiply: x * 1 is exact)
   if constexpr (VEC == 1) {
     for (uint32_t idx = threadIdx.x; idx < total; idx += NT) {

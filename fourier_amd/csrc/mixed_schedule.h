@@ -98,6 +98,13 @@ template <typename T> constexpr uint32_t mix_threads(uint32_t n) {
 #ifndef FOURIER_MIX_INPLACE_BYTES
 #define FOURIER_MIX_INPLACE_BYTES 0u
 #endif
+// Per-pass twiddle tables of the per-length kernels staged in LDS (transposed: entry (i, k) at k * m + i, so that the lanes of a
+// wave -- consecutive butterflies i -- read consecutive words) where a workgroup's transforms share them: two or more
+// transforms per workgroup.  A/B knob; DESIGN.md section 7 has the measurement.
+#ifndef FOURIER_MIX_TW_LDS
+#define FOURIER_MIX_TW_LDS 0
+#endif
+template <typename T> constexpr bool mix_tw_lds(uint32_t n) { return FOURIER_MIX_TW_LDS != 0 && mix_group<T>(n) >= 2; }
 template <typename T> constexpr bool mix_inplace(uint32_t n) {
   return FOURIER_MIX_INPLACE_BYTES == 0u || 2u * mix_group<T>(n) * n * 2u * sizeof(T) > FOURIER_MIX_INPLACE_BYTES;
 }
