@@ -118,25 +118,29 @@ def copy_ceiling(src_ptr, dst_ptr, nbytes, stream):
     except (OSError, AttributeError):
         return None
     f.restype = ctypes.c_int
-    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                   ctypes.POINTER(ctypes.c_float)]
     out = {}
     slab = 1 << 20  # bytes per workgroup
     nbytes = min(nbytes, 16 << 30) // (8 * slab) * (8 * slab)  # whole slabs, a multiple of 8 workgroups (one range per XCD)
     if nbytes <= 0:
         return None
-    for label, nt in (("slab_plain", 0), ("slab_streaming", 1), ("column_tiles_plain", 2), ("column_tiles_streaming", 3)):
+    # (label, access bits: 1 = streaming hint, 2 = the passes' column-tile shape, resident workgroups per CU: 0 = as many as fit)
+    for label, nt, wgs in (("slab_plain", 0, 0), ("slab_streaming", 1, 0), ("column_tiles_plain", 2, 0), ("column_tiles_streaming", 3, 0),
+                           ("column_tiles_streaming_2_per_cu", 3, 2), ("column_tiles_streaming_3_per_cu", 3, 3),
+                           ("column_tiles_plain_2_per_cu", 2, 2), ("slab_streaming_4_per_cu", 1, 4)):
         ms = ctypes.c_float(0.0)
-        rc = f(src_ptr, dst_ptr, nbytes, slab, nt, 5, stream, ctypes.byref(ms))
+        rc = f(src_ptr, dst_ptr, nbytes, slab, nt, wgs, 5, stream, ctypes.byref(ms))
         if rc != 0 or ms.value <= 0:
             return None
         out[label] = 2.0 * nbytes / (ms.value * 1e-3) / 1e9
     best = max(out, key=out.get)
     return {"gbps": round(out[best], 1), "policy": best, "bytes_copied": nbytes, "by_policy_gbps": {k: round(v, 1) for k, v in out.items()},
-            "how": "best of four hand-written device copies (16-byte accesses, XCD-aware block order): linear 1 MiB slabs per workgroup "
+            "how": "best of eight hand-written device copies (16-byte accesses, XCD-aware block order): linear 1 MiB slabs per workgroup "
                    "with 8 loads in flight per thread, and the passes' own shape -- 128-byte row segments at an 8 KiB row stride, 16 loads "
-                   "in flight per thread, one 128 KiB column tile per 512-thread workgroup -- each with plain and with streaming accesses; "
-                   "5 launches between HIP events on the launch stream, this process, the workload's own buffers"}
+                   "in flight per thread, one 128 KiB column tile per 512-thread workgroup --, with plain and with streaming accesses, with "
+                   "as many workgroups per CU as fit and capped at the pass kernels' two (three, four); 5 launches between HIP events on "
+                   "the launch stream, this process, the workload's own buffers"}
 
 
 def roofline_of(plan, kernels, batch, alg_bytes_per, dtype, whole_path_frac, traffic_ok=False, ceiling=None):

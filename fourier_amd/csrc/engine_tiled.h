@@ -48,11 +48,12 @@ template <typename T> class TiledMixedEngine {
     }
     return best;
   }
-  static bool handles(size_t n) {
+  // any_a: also lengths with a >= 12, which otherwise run as power-of-two tiles + odd passes (A/B: FOURIER_TILED_FIRST)
+  static bool handles(size_t n, bool any_a = false) {
     if (n < 4096 || n > MAX_N || dev_env("FOURIER_NO_TILED_MIXED")) return false;
     size_t p = n;
     while (p % 3 == 0) p /= 3;
-    if (!is_pow2(p) || p == n || p >= 4096) return false;  // 2^a * 3^b, b >= 1, a < 12 (a >= 12: power-of-two tiles + odd passes)
+    if (!is_pow2(p) || p == n || (p >= 4096 && !any_a)) return false;  // 2^a * 3^b, b >= 1, a < 12
     return !factorise(n).empty();
   }
 

@@ -52,8 +52,10 @@ __global__ void __launch_bounds__(512) copy_tile_kernel(const void* __restrict__
 // Copies `bytes` (a multiple of bytes_per_block, itself a multiple of 32 KiB) from src to dst `reps` times on `stream` and
 // reports the mean milliseconds per copy between two HIP events on that stream.  nt bit 0: streaming (non-temporal) loads
 // and stores, the cache policy of the pass kernels; bit 1: the column-tile shape of the passes instead of linear slabs.  Returns a fourier_hip status code.
-extern "C" int fourier_exp_copy_ceiling(const void* src, void* dst, uint64_t bytes, uint64_t bytes_per_block, int nt, int reps,
-                                        void* stream, float* ms_per_copy) {
+// wgs_per_cu > 0 caps the resident workgroups per compute unit by giving every workgroup 160 KiB / wgs_per_cu of (unused)
+// dynamic LDS -- the pass kernels hold two workgroups per CU, a bare copy would hold four to eight.
+extern "C" int fourier_exp_copy_ceiling(const void* src, void* dst, uint64_t bytes, uint64_t bytes_per_block, int nt, int wgs_per_cu,
+                                        int reps, void* stream, float* ms_per_copy) {
   using namespace fourier_hip;
   if (!src || !dst || !ms_per_copy || reps <= 0 || bytes_per_block == 0 || bytes_per_block % (256 * 8 * 16) || bytes % bytes_per_block ||
       bytes / bytes_per_block > 0x7fffffffull)
@@ -72,12 +74,19 @@ extern "C" int fourier_exp_copy_ceiling(const void* src, void* dst, uint64_t byt
     const bool tile_shape = (nt & 2) != 0;  // bit 1: the passes' column-tile shape (bytes must be a multiple of 8 MiB)
     if (tile_shape && bytes % ((uint64_t)8 << 20)) return ::fourier::c::FOURIER_HIP_INVALID_ARGUMENT;
     const unsigned tile_blocks = (unsigned)(bytes >> 17);  // 128 KiB per workgroup
+    const size_t lds = wgs_per_cu > 0 ? ((size_t)160 * 1024 / (size_t)wgs_per_cu) & ~(size_t)1023 : 0;
+    if (lds > 48 * 1024) {
+      raise_smem_limit((const void*)&copy_tile_kernel<true>, lds);
+      raise_smem_limit((const void*)&copy_tile_kernel<false>, lds);
+      raise_smem_limit((const void*)&copy_slab_kernel<8, true>, lds);
+      raise_smem_limit((const void*)&copy_slab_kernel<8, false>, lds);
+    }
     auto launch = [&] {
       if (tile_shape) {
-        if (nt & 1) copy_tile_kernel<true><<<tile_blocks, 512, 0, st>>>(src, dst);
-        else copy_tile_kernel<false><<<tile_blocks, 512, 0, st>>>(src, dst);
-      } else if (nt & 1) copy_slab_kernel<8, true><<<blocks, 256, 0, st>>>(src, dst, bytes_per_block / 16);
-      else copy_slab_kernel<8, false><<<blocks, 256, 0, st>>>(src, dst, bytes_per_block / 16);
+        if (nt & 1) copy_tile_kernel<true><<<tile_blocks, 512, lds, st>>>(src, dst);
+        else copy_tile_kernel<false><<<tile_blocks, 512, lds, st>>>(src, dst);
+      } else if (nt & 1) copy_slab_kernel<8, true><<<blocks, 256, lds, st>>>(src, dst, bytes_per_block / 16);
+      else copy_slab_kernel<8, false><<<blocks, 256, lds, st>>>(src, dst, bytes_per_block / 16);
     };
     launch();  // warm-up (page tables, clocks)
     HIP_CHECK(hipEventRecord(a, st));

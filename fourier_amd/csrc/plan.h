@@ -49,6 +49,9 @@ template <typename T> class Plan {
     DeviceGuard g(device_);
     if (is_pow2(n)) {
       eng_.reset(new Pow2Engine<T>(n, false, true));
+    } else if (dev_env("FOURIER_TILED_FIRST") && !MixedEngine<T>::handles(n) && TiledMixedEngine<T>::handles(n, true) &&
+               TiledMixedEngine<T>::factorise(n).size() == 2) {
+      tiled_.reset(new TiledMixedEngine<T>(n));  // experiment: two mixed-length tile passes where the default takes 2^a tiles + odd passes
     } else if (Pow2Engine<T>::handles_mixed(n)) {
       // big-radix passes over the 2^a part (a >= 12), then a radix-3^b pass: three HBM round trips at full tile
       // efficiency beat the one-workgroup-per-CU LDS kernel where both apply (3*2^12 f32: 23 % vs 14 %)
