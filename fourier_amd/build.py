@@ -41,6 +41,14 @@ def headers():
     return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(os.path.dirname(HERE), "include", "fourier.h")]
 
 
+def gen_rtc_sources():
+    """csrc/rtc_sources.inc: the device headers of a run-time specialisation, embedded as string literals (tools/gen_rtc_sources.py)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import gen_rtc_sources
+
+    return gen_rtc_sources.main()
+
+
 def mix_shards():
     with open(os.path.join(CSRC, "engine_common.h")) as f:
         return int(re.search(r"#define FOURIER_MIX_SHARDS (\d+)", f.read()).group(1))
@@ -50,6 +58,7 @@ def translation_units():
     """(object name, source file, extra -D flags, group) for every object of the two libraries.  Groups: 'host', 'env_product',
     'env_experiments', 'pass', 'onelaunch', 'misc', 'mixed', 'experiments' (tools/build_variants.py rebuilds by group)."""
     tus = [("engine", "engine.cpp", [], "host"),
+           ("rtc", "rtc.cpp", [], "host"),
            ("env_product", "env_product.cpp", [], "env_product"),
            ("env_experiments", "env_experiments.cpp", [], "env_experiments"),
            ("exp_copy_ceiling", "exp_copy_ceiling.cpp", [], "experiments")]
@@ -88,6 +97,7 @@ def compile_objects(objdir=OBJDIR, extra=(), force=False, groups=None, verbose=F
     force -- into objdir, on all cores.  Returns ({object name: path}, number compiled).  groups: restrict to these groups
     (the others must exist already)."""
     os.makedirs(objdir, exist_ok=True)
+    gen_rtc_sources()
     all_headers = headers()
     jobs, objs = [], {}
     for name, src, defs, group in translation_units():

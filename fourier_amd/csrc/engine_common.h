@@ -190,6 +190,12 @@ static inline void unit_root(uint64_t e, uint64_t size, double& re, double& im) 
   else if (e == 0) { re = 1; im = 0; }
 }
 
+// a kernel specialised at run time (rtc.cpp): launched through hipModuleLaunchKernel
+struct RtcKernel { void* fn = nullptr; };
+// mixed_radix_kernel_ct<float|double, n> compiled with hipRTC (cached per device, precision and length), its lds_bytes of LDS
+// declared statically; false + the reason where hipRTC or the compilation is not available
+bool rtc_mixed_kernel(bool f64, uint32_t n, size_t lds_bytes, RtcKernel& out, std::string& why);
+
 // ---------------------------------------------------------------------------------------------
 // Kernel registry.  Real<T> selects the precision; every function is defined once per precision in the translation unit
 // named beside it (compiled with -DFOURIER_TU_REAL=float / double).

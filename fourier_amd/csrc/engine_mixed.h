@@ -68,8 +68,10 @@ template <typename T> class MixedEngine {
     return {(T)libm_cos(theta), (T)(-libm_sin(theta))};
   }
 
-  explicit MixedEngine(size_t n) : n_(n) {
-    factor(n, radices_);
+  // deferred_kernel: a length without any ahead-of-time kernel (beyond the runtime kernel's reach); the plan is usable only
+  // after specialise() has succeeded (Plan::set_option "specialise" on a Bluestein plan)
+  explicit MixedEngine(size_t n, bool deferred_kernel = false) : n_(n) {
+    if (!factor(n, radices_)) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "length does not factor over 2, 3, 5, 7, 11, 13");
     std::vector<cpx<T>> tw;
     size_t cur = n;
     for (const size_t R : radices_) {  // mod.rs:24-46
@@ -84,8 +86,11 @@ template <typename T> class MixedEngine {
     tw_.upload(tw);
     // transforms per workgroup: about 1024 points (16 KiB of LDS in f32: several workgroups per CU; larger groups that
     // fill the 256 threads better lose more in occupancy than they gain, r01 session 9)
+    tw_entries_ = tw.size();
+    if (deferred_kernel) return;
     const Kernel k = pick_kernel(n);
     fn_ = k.fn; group_ = k.group; nbuf_ = k.nbuf; threads_ = k.threads;
+    per_length_ = (k.group == mix_group<T>((uint32_t)n) && k.threads == mix_threads<T>((uint32_t)n) && fn_ != nullptr && !is_runtime_kernel(k));
     smem_ = nbuf_ * (size_t)group_ * n * sizeof(cpx<T>) + (k.tw_lds ? tw.size() * sizeof(cpx<T>) : 0);  // + the tables staged in LDS
     if (smem_ > MAX_LDS) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "mixed-radix length needs the per-length kernel");
     raise_smem_limit((const void*)fn_, smem_);
@@ -93,7 +98,30 @@ template <typename T> class MixedEngine {
   std::string describe() const {
     std::string d;
     for (const uint32_t r : radices_) d += (d.empty() ? "" : ".") + std::to_string(r);
+    if (rtc_.fn) d += " specialised";
     return d;
+  }
+  bool usable() const { return fn_ != nullptr || rtc_.fn != nullptr; }
+  bool specialised() const { return rtc_.fn != nullptr; }
+  // Plan option "specialise": compile this length's own kernel (mixed_radix_kernel_ct<T, n>, the form of the ahead-of-time
+  // per-length kernels) with hipRTC and use it from now on.  Nothing to do where the plan already runs a per-length kernel.
+  // Status: OK, or UNSUPPORTED (no hipRTC, or the compilation failed) -- the plan then keeps the kernel it had.
+  int specialise(std::string* why = nullptr) {
+    if (rtc_.fn || per_length_) return ::fourier::c::FOURIER_HIP_OK;
+    const uint32_t n = (uint32_t)n_;
+    const uint32_t group = mix_group<T>(n), threads = mix_threads<T>(n);
+    const size_t nbuf = mix_inplace<T>(n) ? 1 : 2;
+    const size_t smem = nbuf * (size_t)group * n * sizeof(cpx<T>) + (mix_tw_lds<T>(n) ? tw_entries_ * sizeof(cpx<T>) : 0);
+    std::string reason;
+    RtcKernel k;
+    if (smem > MAX_LDS) reason = "the length does not fit a compute unit's LDS";
+    else if (rtc_mixed_kernel(sizeof(T) == 8, n, smem, k, reason)) {
+      rtc_ = k; group_ = group; threads_ = threads; nbuf_ = nbuf;
+      smem_ = 0;  // the specialised kernel declares its LDS statically
+      return ::fourier::c::FOURIER_HIP_OK;
+    }
+    if (why) *why = reason;
+    return ::fourier::c::FOURIER_HIP_UNSUPPORTED;
   }
   void run(const cpx<T>* in, cpx<T>* out, size_t batch, bool forward, bool scaled, double scale, hipStream_t stream,
            Profiler* prof) const {
@@ -109,7 +137,15 @@ template <typename T> class MixedEngine {
     const uint64_t grid = (batch + group_ - 1) / group_;
     if (grid > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");
     PROF_BEGIN(prof, 0);
-    FOURIER_LAUNCH(fn_, grid, threads_, smem_, stream, a);
+#ifndef FOURIER_EMU
+    if (rtc_.fn) {  // the kernel specialised at run time: a module function
+      void* params[] = {&a};
+      HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)rtc_.fn, (unsigned)grid, 1, 1, threads_, 1, 1, (unsigned)smem_, stream, params, nullptr));
+    } else
+#endif
+    {
+      FOURIER_LAUNCH(fn_, grid, threads_, smem_, stream, a);
+    }
     PROF_END(prof);
   }
 
@@ -120,8 +156,18 @@ template <typename T> class MixedEngine {
   void (*fn_)(MixArgs) = nullptr;
   size_t nbuf_ = 1;  // LDS buffers of `group_` transforms: 1 = in-place passes (2 = ping-pong, FOURIER_MIX_INPLACE_BYTES builds)
   uint32_t group_ = 1;
-  size_t smem_ = 0;
+  size_t smem_ = 0, tw_entries_ = 0;
+  bool per_length_ = false;  // fn_ is this length's own ahead-of-time kernel
+  RtcKernel rtc_;            // ... or its own kernel compiled at run time (specialise)
   DevBuf tw_;
+  static bool is_runtime_kernel(const Kernel& k) {
+    const Real<T> real{};
+    for (int maxp : {3, 7, 13})
+      for (int ppt : {4, 8})
+        for (int nt : {128, 256, 512, 1024})
+          if (k.fn && k.fn == get_mixed_rt_kernel(real, maxp, ppt, nt)) return true;
+    return false;
+  }
 };
 
 }  // namespace fourier_hip

@@ -1,7 +1,11 @@
 // kernel_args.h -- argument blocks of the kernels (passed by value) and the enums that name their modes: what the host
 // translation unit needs to know about a kernel family without seeing its device code.
 #pragma once
+#ifdef __HIPCC_RTC__  // hipRTC (rtc.cpp): no system headers; its built-in runtime header is already in
+typedef unsigned char uint8_t; typedef unsigned int uint32_t; typedef unsigned long long uint64_t; typedef int int32_t;
+#else
 #include <stdint.h>
+#endif
 
 namespace fourier_hip {
 

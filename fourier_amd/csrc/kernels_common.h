@@ -34,7 +34,9 @@
 //   stockham_pass_kernel<T, R>            one pass in global memory, any radix and stride: 2^a*3^b with a < 12 beyond the LDS limit
 //   blu_pre_kernel / blu_post_kernel      unfused chirp sweeps (option bluestein_fusion = 0)
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
 #include "kernel_args.h"
 
 #ifdef FOURIER_EMU
@@ -46,7 +48,9 @@
 static inline float fast_rcp(float x) { return 1.0f / x; }
 static inline uint32_t mul24(uint32_t a, uint32_t b) { return a * b; }
 #else
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 // stops hipcc from hoisting a whole block of table loads above the arithmetic that consumes them
 // (it otherwise keeps all 16 twiddle units live at once and spills under the 128-VGPR budget)
 #define FOURIER_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -55,7 +59,13 @@ static inline uint32_t mul24(uint32_t a, uint32_t b) { return a * b; }
 // hides a per-lane value from the optimiser: inside a persistent loop it keeps everything derived from the value from
 // being hoisted out of the loop (and spilled there) -- a few VALU instructions per iteration instead
 #define FOURIER_LAUNDER(v) asm volatile("" : "+v"(v))
+#ifdef FOURIER_RTC_LDS_BYTES
+// a kernel specialised at run time (rtc.cpp) knows its LDS footprint when it is compiled: a static array, because a module
+// function cannot be given more than 64 KiB of DYNAMIC LDS (hipFuncSetAttribute does not take a hipFunction_t)
+#define FOURIER_DYN_SMEM(name) __shared__ __attribute__((aligned(16))) unsigned char name[FOURIER_RTC_LDS_BYTES]
+#else
 #define FOURIER_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#endif
 #define LDS_NOTE(p, bytes, w, site)
 // v_rcp_f32 (1 ulp) instead of the IEEE division sequence; callers correct the quotient with a compare
 static __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }

@@ -3,7 +3,9 @@
 // and threads per workgroup.  Shared by the kernels (kernels_mixed.h) and by the host, which builds the twiddle tables and
 // the launch shape from the same rules (engine_mixed.h).
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
 
 namespace fourier_hip {
 

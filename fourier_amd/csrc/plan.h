@@ -49,9 +49,10 @@ template <typename T> class Plan {
     DeviceGuard g(device_);
     if (is_pow2(n)) {
       eng_.reset(new Pow2Engine<T>(n, false, true));
-    } else if (dev_env("FOURIER_TILED_FIRST") && !MixedEngine<T>::handles(n) && TiledMixedEngine<T>::handles(n, true) &&
-               TiledMixedEngine<T>::factorise(n).size() == 2) {
-      tiled_.reset(new TiledMixedEngine<T>(n));  // experiment: two mixed-length tile passes where the default takes 2^a tiles + odd passes
+    } else if (tiled_before_pow2_tiles(n)) {
+      // 2^a * 3^b with a >= 12 as TWO mixed-length tile passes instead of power-of-two tiles + odd passes (three or four round
+      // trips): 1 - 25 % faster up to 384 x 384, slower from 512 x 432 on (profiles/r04_s8_pow2_tiles_plus_odd_passes_vs_mixed_tiles_ab.jsonl)
+      tiled_.reset(new TiledMixedEngine<T>(n));
     } else if (Pow2Engine<T>::handles_mixed(n)) {
       // big-radix passes over the 2^a part (a >= 12), then a radix-3^b pass: three HBM round trips at full tile
       // efficiency beat the one-workgroup-per-CU LDS kernel where both apply (3*2^12 f32: 23 % vs 14 %)
@@ -65,6 +66,11 @@ template <typename T> class Plan {
       init_bluestein();
     }
     refresh_desc();
+  }
+  static bool tiled_before_pow2_tiles(size_t n) {
+    if (!Pow2Engine<T>::handles_mixed(n) || dev_env("FOURIER_POW2_TILES_FIRST") || !TiledMixedEngine<T>::handles(n, true)) return false;
+    const std::vector<uint32_t> f = TiledMixedEngine<T>::factorise(n);
+    return f.size() == 2 && f[0] <= 384 && f[1] <= 384;
   }
   // the longest LDS plans ask for the whole 160 KiB of a CU: where the runtime refuses, the next route takes the length
   bool try_mixed(size_t n) {
@@ -147,6 +153,31 @@ template <typename T> class Plan {
     if (key == "bluestein_conv" && (v == 0 || v == 1)) { conv_ = (v == 1) && conv_ok_; return 0; }
     if (key == "bluestein_chirp_compute" && (v == 0 || v == 1)) { chirp_compute_ = (v == 1) && chirp_p_.p != nullptr; return 0; }
     if (key == "host_chunk_bytes" && v > 0) { host_chunk_bytes_ = (size_t)v; return 0; }
+    // "specialise" = 1: compile this length's own LDS mixed-radix kernel with hipRTC (about a second, now) and run it from the
+    // next call on -- for a length whose prime factors stop at 13, that fits a compute unit's LDS and has no ahead-of-time
+    // per-length kernel (it runs the runtime-parameterised kernel, or Bluestein beyond that kernel's reach).  A plan that
+    // already runs a per-length kernel returns OK unchanged; UNSUPPORTED where hipRTC is not available or the length is not of
+    // that family: the plan keeps its route.
+    if (key == "specialise" && v == 1) {
+      std::string why;
+      auto report = [&](int st) {
+        if (st != ::fourier::c::FOURIER_HIP_OK && getenv("FOURIER_HIP_VERBOSE")) fprintf(stderr, "libfourier: specialise(%zu): %s\n", n_, why.c_str());
+        return st;
+      };
+      if (mix_) { const int st = mix_->specialise(&why); refresh_desc(); return report(st); }
+      if (blu_ && n_ <= MixedEngine<T>::MAX_N && !is_pow2(n_)) {
+        std::vector<uint32_t> radices;
+        if (!MixedEngine<T>::factor(n_, radices)) { why = "a prime factor above 13"; return report(::fourier::c::FOURIER_HIP_UNSUPPORTED); }
+        std::unique_ptr<MixedEngine<T>> m;
+        try { m.reset(new MixedEngine<T>(n_, true)); } catch (const EngineError& e) { (void)hipGetLastError(); why = e.what(); return report(e.status); }
+        const int st = m->specialise(&why);
+        if (st != ::fourier::c::FOURIER_HIP_OK) return report(st);
+        mix_ = std::move(m);  // exec() takes the LDS route from here on; the Bluestein tables stay allocated but unused
+        refresh_desc();
+        return st;
+      }
+      return ::fourier::c::FOURIER_HIP_UNSUPPORTED;
+    }
     // LAST pass as persistent workgroups that prefetch their next tile (fft_last_prefetch_kernel; experiments library only,
     // measured slower): 1 where the kernel exists, INVALID_ARGUMENT where it does not
     if (key == "last_pass_prefetch" && (v == 0 || v == 1) && eng_) {

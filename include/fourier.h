@@ -163,7 +163,7 @@ int fourier_hip_last_status_float(const FOURIER_STRUCT fourier_fft_float *);
 int fourier_hip_last_status_double(const FOURIER_STRUCT fourier_fft_double *);
 const char *fourier_hip_status_string(int status);
 
-/* Tunables (return FOURIER_HIP_OK or FOURIER_HIP_INVALID_ARGUMENT):
+/* Tunables (return FOURIER_HIP_OK or FOURIER_HIP_INVALID_ARGUMENT; "specialise" also FOURIER_HIP_UNSUPPORTED):
  *   "chunk_bytes"  bytes of one batch chunk pushed through all passes before the next chunk starts
  *                  (keeps the inter-pass intermediate inside the 256 MiB Infinity Cache); 0 = whole batch
  *   "scratch"      1 = always route the intermediate through the plan's reused scratch buffer,
@@ -180,7 +180,16 @@ const char *fourier_hip_status_string(int status);
  *                  exact-exponent cross term) instead of reading the N-entry chirp table, a quarter of that pass's
  *                  memory traffic; default 1 where it was measured faster (first pass of length >= 1024 and a table
  *                  of >= 4 MiB, e.g. N = 999983), else 0.  Same tolerance class, not the same bits.
- *   "l2_fused"     (builds with -DFOURIER_EXPERIMENTS only; INVALID_ARGUMENT in the product library) 1 = run both
+ *   "specialise"   1 = compile this length's own LDS mixed-radix kernel with hipRTC, now (about a second, once per length,
+ *                  device and process), and run it from the next call on.  For a length whose prime factors stop at 13, that
+ *                  fits a compute unit's LDS and has no ahead-of-time per-length kernel -- by default it runs the
+ *                  runtime-parameterised kernel (24-36 % of the HBM peak where per-length kernels reach 45-60 %) or, beyond
+ *                  that kernel's reach, Bluestein.  OK and unchanged for a plan that already runs a per-length kernel;
+ *                  FOURIER_HIP_UNSUPPORTED -- the plan keeps its route -- for any other length, where libhiprtc is not
+ *                  installed, or where the compilation fails.  Never happens implicitly: creating a plan and transforming
+ *                  never compile anything.  Same tolerance class as the default route, not the same bits.
+ *   "l2_fused"     (lib/libfourier_experiments.so only; INVALID_ARGUMENT in the product library; so is
+ *                  "last_pass_prefetch", the persistent prefetching last pass of DESIGN.md section 4) 1 = run both
  *                  passes of a two-pass plan in ONE launch with the intermediate parked in the XCD's L2 (persistent
  *                  workgroups, per-XCD work queues; f32 2^16..2^18, f64 2^15..2^17 only).  Same results bit for
  *                  bit; measured 30-45 % slower than the two-launch plan on MI355X.  Calls

@@ -168,7 +168,7 @@ def test_mixed_radix_sizes_are_bit_identical_to_the_oracle(fa, oracle):
     assert "mixed-radix" in make(fa, 19683, np.complex64).describe()  # 3^9: 154 of the 160 KiB
     assert "mixed-radix" in make(fa, 9216, np.complex128).describe()
     assert "mixed tiles 108x96" in make(fa, 10368, np.complex128).describe()   # f64: above the LDS-resident limit (9216): two passes on column tiles
-    assert "x3" in make(fa, 12288, np.complex64).describe()           # 3*2^12: tiled passes + odd pass, not the LDS kernel
+    assert "mixed tiles 128x96" in make(fa, 12288, np.complex64).describe()   # 3*2^12: two mixed-length tile passes, not the LDS kernel
     for n, dtype in ((6144, np.complex64), (9216, np.complex64), (18432, np.complex64), (13122, np.complex64),
                      (4608, np.complex128), (9216, np.complex128), (6561, np.complex128)):
         xb = np.stack([hash_normal(21 + b, n) for b in range(2)]).astype(dtype)
@@ -188,20 +188,29 @@ def test_length_specialised_mixed_kernels_equal_the_generic_one(fa, monkeypatch)
             assert np.array_equal(run_batch(fast, x, code), run_batch(slow, x, code)), (n, code)
 
 
-def test_large_mixed_radix_sizes_run_natively(fa, oracle):
+def test_large_mixed_radix_sizes_run_natively(fa, oracle, monkeypatch):
     """N = 2^a*3^b (a >= 12, any b): big-radix passes over the 2^a part, then the odd part as radix-27 Stockham passes
     plus one of radix 3 / 9 / 27 -- twiddled middle passes and a final one (the reference's order, RADICES =
-    [4,8,4,3,2]); every code, in and out of place, against the oracle."""
-    for n, want in ((3 * 4096, "64x64x3"), (9 * 8192, "128x64x9"), (27 * 4096, "64x64x27"), (81 * 4096, "64x64x27x3"),
-                    (243 * 4096, "64x64x27x9")):
-        x = np.stack([hash_normal(80 + b, n) for b in range(2)])
-        for dtype, tl2 in ((np.complex64, 1e-6), (np.complex128, 5e-14)):
-            plan = make(fa, n, dtype)
-            assert plan.describe().startswith("stockham " + want), plan.describe()
-            for code in (range(5) if n <= 27 * 4096 else (0, 1)):  # the GPU test runs all five codes on all of them
-                ref = oracle.transform_batch(x.astype(dtype), code)
-                assert rel_l2(run_batch(plan, x.astype(dtype), code), ref) <= tl2, (n, code)
-                assert rel_l2(run_batch(plan, x.astype(dtype), code, inplace=True), ref) <= tl2, (n, code)
+    [4,8,4,3,2]) -- or, where the length splits into two tile lengths of at most 384 (round 4: measured faster), two
+    mixed-length tile passes; every code, in and out of place, against the oracle, on both routes."""
+    cases = ((3 * 4096, "64x64x3", "mixed tiles 128x96"), (9 * 8192, "128x64x9", "mixed tiles 288x256"), (27 * 4096, "64x64x27", "mixed tiles 384x288"),
+             (81 * 4096, "64x64x27x3", None), (243 * 4096, "64x64x27x9", None))
+    for pow2_first in (False, True):
+        if pow2_first:
+            monkeypatch.setenv("FOURIER_POW2_TILES_FIRST", "1")
+        for n, pow2_route, tile_route in cases:
+            if pow2_first and tile_route is None:
+                continue  # same plan as in the first round
+            want = pow2_route if (pow2_first or tile_route is None) else tile_route
+            x = np.stack([hash_normal(80 + b, n) for b in range(2)])
+            for dtype, tl2 in ((np.complex64, 1e-6), (np.complex128, 5e-14)):
+                plan = make(fa, n, dtype)
+                assert plan.describe().startswith("stockham " + want), plan.describe()
+                for code in (range(5) if n <= 27 * 4096 and not pow2_first else (0, 1)):  # the GPU test runs all five codes on all of them
+                    ref = oracle.transform_batch(x.astype(dtype), code)
+                    assert rel_l2(run_batch(plan, x.astype(dtype), code), ref) <= tl2, (n, code)
+                    assert rel_l2(run_batch(plan, x.astype(dtype), code, inplace=True), ref) <= tl2, (n, code)
+    monkeypatch.delenv("FOURIER_POW2_TILES_FIRST")
     assert make(fa, 729 * 4096, np.complex64).describe().startswith("stockham 64x64x27x27")
     assert "mixed-radix" in make(fa, 3 * 2048, np.complex128).describe()  # too little 2^a for two tiled passes: LDS kernel
     assert "mixed tiles 144x128" in make(fa, 9 * 2048, np.complex128).describe()   # f64 18432: beyond the LDS route, a < 12: column tiles of mixed length
@@ -744,3 +753,20 @@ def test_prefetching_last_pass_is_bit_identical_to_the_plain_last_pass(fa, oracl
         assert np.array_equal(run_batch(on, x, 0, inplace=True), a if code == 0 else run_batch(on, x, 0)), (n, dtype)
         tol = (1e-6 if n & (n - 1) == 0 else 2e-6) if dtype == np.complex64 else (5e-14 if n & (n - 1) == 0 else 1e-9)
         assert rel_l2(run_batch(on, x, 0), oracle.transform_batch(x, 0)) <= tol, (n, dtype)
+
+
+def test_plan_option_specialise_is_refused_without_hiprtc_and_leaves_the_plan_alone(fa, oracle):
+    """Under the emulator there is no hipRTC: "specialise" reports UNSUPPORTED (as it does on a box without libhiprtc) for a
+    length of the family and for one outside it, and the plan keeps its route and its results; a length that already runs a
+    per-length kernel returns OK."""
+    for n in (1001, 9009, 1013):
+        plan = make(fa, n, np.complex64)
+        desc = plan.describe()
+        with pytest.raises(fa.FourierError):
+            plan.set_option("specialise", 1)
+        assert plan.describe() == desc
+        x = np.stack([hash_normal(3 + b, n) for b in range(3)]).astype(np.complex64)
+        assert rel_l2(run_batch(plan, x, 0), oracle.transform_batch(x, 0)) <= 2e-6
+    plan = make(fa, 1000, np.complex64)
+    plan.set_option("specialise", 1)
+    assert "specialised" not in plan.describe()

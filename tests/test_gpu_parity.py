@@ -212,13 +212,16 @@ def test_mixed_radix_sizes_are_bit_identical_to_the_oracle(torch, fa, oracle):
 @pytest.mark.parametrize("n", [3 * 4096, 9 * 4096, 27 * 4096, 3 * (1 << 15), 9 * (1 << 16), 3 * (1 << 18), 27 * (1 << 16), 3 * (1 << 23),
                                81 * 4096, 243 * 4096, 729 * (1 << 13), 2187 * 4096, 81 * (1 << 17)])
 def test_large_mixed_radix_sizes_vs_oracle(torch, fa, oracle, n):
-    """2^a*3^b (a >= 12, any b) natively: big-radix passes over 2^a, then radix-27/9/3 passes (middle ones twiddled)."""
+    """2^a*3^b (a >= 12, any b) natively: big-radix passes over 2^a, then radix-27/9/3 passes (middle ones twiddled) -- or two
+    mixed-length tile passes where the length splits into two tile lengths of at most 384 (round 4)."""
     x = np.stack([hash_uniform(90 + b, n) for b in range(2)])
     for dtype, tl2 in ((np.complex64, 1e-6), (np.complex128, 5e-14)):
         if n > (1 << 24) and dtype == np.complex128:
             continue
         plan = make(fa, n, dtype)
-        assert plan.describe().startswith("stockham") and "x3" in plan.describe().replace("x9", "x3").replace("x27", "x3")
+        d = plan.describe()
+        assert d.startswith("stockham") and ("mixed tiles" in d or "x3" in d.replace("x9", "x3").replace("x27", "x3")), d
+        assert ("mixed tiles" in d) == (n in (3 * 4096, 9 * 4096, 27 * 4096, 3 * (1 << 15))), d  # 128x96, 192x192, 384x288, 384x256
         for code in (0, 1, 3):
             ref = oracle.transform_batch(x.astype(dtype), code, nthreads=2)
             assert rel_l2(gpu_batch(torch, fa, plan, x.astype(dtype), code), ref) <= tl2, (n, code)
@@ -1105,3 +1108,42 @@ def test_prefetching_last_pass_matches_the_plain_last_pass(torch, fa, fa_exp, or
         assert rel_l2(a[:1].cpu().numpy(), ref) <= tol, (n, dtype)
         del x, a, b, c
         torch.cuda.empty_cache()
+
+
+def test_plan_option_specialise_compiles_the_lengths_own_kernel_with_hiprtc(torch, fa, oracle):
+    """Plan option "specialise" (rtc.cpp): a length whose prime factors stop at 13 but that has no ahead-of-time per-length
+    kernel gets mixed_radix_kernel_ct<T, n> compiled with hipRTC on request.  Lengths on the runtime-parameterised kernel
+    (1001, 5005, 4095), lengths beyond its reach that default to Bluestein (9009 f32, 4095 f64, 15015 f32 = 117 KiB of
+    LDS), a length that already has its kernel (1000: OK, unchanged), and lengths outside the family (1013, 2^12:
+    UNSUPPORTED, the plan keeps working).  Values against the oracle and against the plan's default route."""
+    import shutil
+
+    if not (os.path.exists("/opt/rocm/lib/libhiprtc.so") or shutil.which("hipcc")):
+        pytest.skip("libhiprtc not installed")
+    for n, dtype in ((1001, np.complex64), (5005, np.complex64), (4095, np.complex64), (9009, np.complex64), (15015, np.complex64),  # 15015: 117 KiB of (static) LDS
+                     (1001, np.complex128), (4095, np.complex128), (1000, np.complex64)):
+        batch = 37
+        x = np.stack([hash_normal(2500 + b, n) for b in range(batch)]).astype(dtype)
+        base, spec = make(fa, n, dtype), make(fa, n, dtype)
+        before = spec.describe()
+        spec.set_option("specialise", 1)
+        after = spec.describe()
+        if n == 1000:
+            assert after == before and "specialised" not in after  # already a per-length kernel
+        else:
+            assert "mixed-radix" in after and "specialised" in after, (n, before, after)
+        tol = 2e-6 if dtype == np.complex64 else 5e-11
+        for code in range(5):
+            ref = oracle.transform_batch(x, code)
+            a = gpu_batch(torch, fa, spec, x, code)
+            assert rel_l2(a, ref) <= tol, (n, dtype, code, rel_l2(a, ref))
+            assert rel_l2(gpu_batch(torch, fa, base, x, code), a) <= tol, (n, dtype, code)
+            assert np.array_equal(gpu_batch(torch, fa, spec, x, code, inplace=True), a), (n, dtype, code)
+    for n in (1013, 17017, 4096, 999983):  # not of the family (17017 = 17 * 1001): refused, and the plan is untouched
+        plan = make(fa, n, np.complex64)
+        desc = plan.describe()
+        with pytest.raises(fa.FourierError):
+            plan.set_option("specialise", 1)
+        assert plan.describe() == desc
+        x = hash_normal(7, n).astype(np.complex64)[None, :]
+        assert rel_l2(gpu_batch(torch, fa, plan, x, 0), oracle.transform_batch(x, 0)) <= 2e-6
