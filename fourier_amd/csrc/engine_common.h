@@ -194,7 +194,8 @@ static inline void unit_root(uint64_t e, uint64_t size, double& re, double& im) 
 struct RtcKernel { void* fn = nullptr; };
 // mixed_radix_kernel_ct<float|double, n> compiled with hipRTC (cached per device, precision and length), its lds_bytes of LDS
 // declared statically; false + the reason where hipRTC or the compilation is not available
-bool rtc_mixed_kernel(bool f64, uint32_t n, size_t lds_bytes, RtcKernel& out, std::string& why);
+// tile_pass: tiled_mixed_kernel_ct<T, n> (a column-tile pass of length n) instead of the whole-transform kernel
+bool rtc_mixed_kernel(bool f64, uint32_t n, size_t lds_bytes, RtcKernel& out, std::string& why, bool tile_pass = false);
 
 // ---------------------------------------------------------------------------------------------
 // Kernel registry.  Real<T> selects the precision; every function is defined once per precision in the translation unit

@@ -23,11 +23,25 @@ template <typename T> class TiledMixedEngine {
     }();
     return m;
   }
+  // every length a tile pass can have once it is compiled at run time (plan option "specialise"): prime factors up to 13
+  static const std::vector<uint32_t>& menu_rtc() {
+    static const std::vector<uint32_t> m = [] {
+      std::vector<uint32_t> v;
+      for (uint32_t L = 64; L <= 512; ++L) {
+        uint32_t r = L;
+        for (uint32_t p : {2u, 3u, 5u, 7u, 11u, 13u})
+          while (r % p == 0) r /= p;
+        if (r == 1) v.push_back(L);
+      }
+      return v;
+    }();
+    return m;
+  }
   // pass lengths, most balanced factorisation first: two factors if there is one, else three; empty: none
-  static std::vector<uint32_t> factorise(size_t n) {
+  static std::vector<uint32_t> factorise(size_t n, bool rtc = false) {
     std::vector<uint32_t> best;
     uint32_t best_max = 0xffffffffu;
-    const auto& m = menu();
+    const auto& m = rtc ? menu_rtc() : menu();
     for (uint32_t a : m) {
       if (n % a) continue;
       const size_t r = n / a;
@@ -57,15 +71,35 @@ template <typename T> class TiledMixedEngine {
     return !factorise(n).empty();
   }
 
-  explicit TiledMixedEngine(size_t n) : n_(n) {
-    const std::vector<uint32_t> lens = factorise(n);
+  // launch shape of a tile pass of length L: the rules of TiledCfg (kernels_tiled.h), for a kernel compiled at run time
+  static TiledKernel shape_of(uint32_t L) {
+    TiledKernel k;
+    k.L = L; k.cols = 128 / (uint32_t)sizeof(cpx<T>);
+    const uint32_t points = L * k.cols, ld = L | 1u, kh = (L + 15) / 16;
+    k.threads = points / 8 <= 256 ? 256 : (points / 8 <= 512 ? 512 : 1024);
+    k.smem = (((size_t)k.cols * ld * sizeof(cpx<T>) + 15) & ~(size_t)15) + (size_t)k.cols * (kh + 16) * sizeof(cpx<T>);
+    return k;
+  }
+  // rtc: plan option "specialise" -- the tile lengths may have prime factors up to 13, and a length without an ahead-of-time
+  // kernel is compiled with hipRTC (rtc.cpp); throws UNSUPPORTED where that is not possible
+  explicit TiledMixedEngine(size_t n, bool rtc = false) : n_(n) {
+    const std::vector<uint32_t> lens = factorise(n, rtc);
     if (lens.empty()) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "no tile factorisation");
     uint64_t s = 1, size = n;
     for (uint32_t L : lens) {
       Pass ps;
       ps.k = get_tiled_kernel(Real<T>{}, L);
+      if (!ps.k.fn) {
+        if (!rtc) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "no tile kernel of this length");
+        ps.k = shape_of(L);
+        std::string why;
+        if (!rtc_mixed_kernel(sizeof(T) == 8, L, ps.k.smem, ps.rtc, why, true))
+          throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "tile pass of length " + std::to_string(L) + ": " + why);
+        ps.k.smem = 0;  // declared statically by the specialised kernel
+        specialised_ = true;
+      }
       ps.s = s; ps.m = size / L;
-      raise_smem_limit((const void*)ps.k.fn, ps.k.smem);
+      if (ps.k.fn) raise_smem_limit((const void*)ps.k.fn, ps.k.smem);
       // tables of the in-tile transform: the reference's layout for a plan of length L (mod.rs:24-46), f64 trig then cast
       auto it = tables_.find(L);
       if (it == tables_.end()) {
@@ -102,6 +136,7 @@ template <typename T> class TiledMixedEngine {
   std::string describe() const {
     std::string d;
     for (const Pass& p : passes_) d += (d.empty() ? "" : "x") + std::to_string(p.k.L);
+    if (specialised_) d += " specialised";
     return d;
   }
   // scratch: batch * n elements; needed by in-place calls and by three-pass plans
@@ -131,7 +166,15 @@ template <typename T> class TiledMixedEngine {
       const uint64_t grid = (uint64_t)batch * a.tiles_per_row * (ps.s == 1 ? 1 : ps.m);
       if (grid > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");
       PROF_BEGIN(prof, (int)p);
-      FOURIER_LAUNCH(ps.k.fn, grid, ps.k.threads, ps.k.smem, stream, a);
+#ifndef FOURIER_EMU
+      if (ps.rtc.fn) {  // a tile length compiled at run time: a module function
+        void* params[] = {&a};
+        HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)ps.rtc.fn, (unsigned)grid, 1, 1, ps.k.threads, 1, 1, 0, stream, params, nullptr));
+      } else
+#endif
+      {
+        FOURIER_LAUNCH(ps.k.fn, grid, ps.k.threads, ps.k.smem, stream, a);
+      }
       PROF_END(prof);
       src = dst;
     }
@@ -145,12 +188,14 @@ template <typename T> class TiledMixedEngine {
   }
   struct Pass {
     TiledKernel k;
+    RtcKernel rtc;  // set instead of k.fn for a length compiled at run time
     uint64_t s = 1, m = 1;
     uint32_t lo_bits = 0;
     DevBuf* tw = nullptr;
     std::unique_ptr<DevBuf> tw_lo, tw_hi;
   };
   size_t n_;
+  bool specialised_ = false;
   std::vector<Pass> passes_;
   std::map<uint32_t, std::unique_ptr<DevBuf>> tables_;
 };

@@ -176,7 +176,15 @@ template <typename T> class Plan {
         refresh_desc();
         return st;
       }
-      return ::fourier::c::FOURIER_HIP_UNSUPPORTED;
+      if (blu_ && n_ > MixedEngine<T>::MAX_N && n_ <= TiledMixedEngine<T>::MAX_N && !TiledMixedEngine<T>::factorise(n_, true).empty()) {
+        // beyond one compute unit's LDS: two or three column-tile passes whose lengths may have prime factors up to 13
+        try { tiled_.reset(new TiledMixedEngine<T>(n_, true)); }
+        catch (const EngineError& e) { (void)hipGetLastError(); tiled_.reset(); why = e.what(); return report(e.status); }
+        refresh_desc();
+        return ::fourier::c::FOURIER_HIP_OK;
+      }
+      why = "not a length whose prime factors stop at 13 with a kernel to specialise";
+      return report(::fourier::c::FOURIER_HIP_UNSUPPORTED);
     }
     // LAST pass as persistent workgroups that prefetch their next tile (fft_last_prefetch_kernel; experiments library only,
     // measured slower): 1 where the kernel exists, INVALID_ARGUMENT where it does not

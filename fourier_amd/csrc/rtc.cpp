@@ -22,7 +22,7 @@
 namespace fourier_hip {
 
 #ifdef FOURIER_EMU
-bool rtc_mixed_kernel(bool, uint32_t, size_t, RtcKernel&, std::string& why) { why = "no hipRTC under the CPU emulation"; return false; }
+bool rtc_mixed_kernel(bool, uint32_t, size_t, RtcKernel&, std::string& why, bool) { why = "no hipRTC under the CPU emulation"; return false; }
 #else
 
 namespace {
@@ -60,22 +60,24 @@ struct Rtc {
   }
 };
 std::mutex g_mu;
-std::map<std::pair<int, uint32_t>, RtcKernel> g_cache;  // (device * 2 + f64, n) -> loaded kernel; modules live as long as the process
+std::map<std::pair<int, uint32_t>, RtcKernel> g_cache;  // ((device, f64, tile pass), n) -> loaded kernel; modules live as long as the process
 }  // namespace
 
-bool rtc_mixed_kernel(bool f64, uint32_t n, size_t lds_bytes, RtcKernel& out, std::string& why) {
+bool rtc_mixed_kernel(bool f64, uint32_t n, size_t lds_bytes, RtcKernel& out, std::string& why, bool tile_pass) {
   static Rtc rtc;
   if (!rtc.ok) { why = "libhiprtc not available"; return false; }
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { why = "no device"; return false; }
   std::lock_guard<std::mutex> lock(g_mu);
-  const auto key = std::make_pair(dev * 2 + (f64 ? 1 : 0), n);
+  const auto key = std::make_pair((dev * 2 + (f64 ? 1 : 0)) * 2 + (tile_pass ? 1 : 0), n);
   auto it = g_cache.find(key);
   if (it != g_cache.end()) { out = it->second; return true; }
   const std::string real = f64 ? "double" : "float";
-  const std::string expr = "fourier_hip::mixed_radix_kernel_ct<" + real + ", " + std::to_string(n) + "u>";
-  const std::string src = "#include \"kernels_mixed.h\"\nnamespace fourier_hip { template __global__ void mixed_radix_kernel_ct<" + real + ", " +
-                          std::to_string(n) + "u>(MixArgs); }\n";
+  // the whole-transform kernel of length n, or the column-tile pass of length n (kernels_tiled.h)
+  const std::string kernel = tile_pass ? "tiled_mixed_kernel_ct" : "mixed_radix_kernel_ct", args = tile_pass ? "TiledArgs" : "MixArgs";
+  const std::string expr = "fourier_hip::" + kernel + "<" + real + ", " + std::to_string(n) + "u>";
+  const std::string src = std::string("#include \"") + (tile_pass ? "kernels_tiled.h" : "kernels_mixed.h") + "\"\nnamespace fourier_hip { template __global__ void " +
+                          kernel + "<" + real + ", " + std::to_string(n) + "u>(" + args + "); }\n";
   Rtc::Program prog = nullptr;
   if (rtc.create(&prog, src.c_str(), "fourier_rtc_mixed.hip", RTC_NUM_HEADERS, RTC_HEADER_SOURCES, RTC_HEADER_NAMES) != 0) { why = "hiprtcCreateProgram failed"; return false; }
   bool ok = false;

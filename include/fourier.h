@@ -186,7 +186,9 @@ const char *fourier_hip_status_string(int status);
  *                  runtime-parameterised kernel (24-36 % of the HBM peak where per-length kernels reach 45-60 %) or, beyond
  *                  that kernel's reach, Bluestein.  OK and unchanged for a plan that already runs a per-length kernel;
  *                  FOURIER_HIP_UNSUPPORTED -- the plan keeps its route -- for any other length, where libhiprtc is not
- *                  installed, or where the compilation fails.  Never happens implicitly: creating a plan and transforming
+ *                  installed, or where the compilation fails.  Beyond the LDS limit (up to 2^26 points) the option replaces a
+ *                  Bluestein plan by two or three column-tile passes whose lengths have prime factors up to 13 (10^5 = 400 x 250,
+ *                  44100 = 210 x 210), compiled the same way, where such a factorisation exists.  Never happens implicitly: creating a plan and transforming
  *                  never compile anything.  Same tolerance class as the default route, not the same bits.
  *   "l2_fused"     (lib/libfourier_experiments.so only; INVALID_ARGUMENT in the product library; so is
  *                  "last_pass_prefetch", the persistent prefetching last pass of DESIGN.md section 4) 1 = run both

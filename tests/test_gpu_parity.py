@@ -1139,6 +1139,22 @@ def test_plan_option_specialise_compiles_the_lengths_own_kernel_with_hiprtc(torc
             assert rel_l2(a, ref) <= tol, (n, dtype, code, rel_l2(a, ref))
             assert rel_l2(gpu_batch(torch, fa, base, x, code), a) <= tol, (n, dtype, code)
             assert np.array_equal(gpu_batch(torch, fa, spec, x, code, inplace=True), a), (n, dtype, code)
+    # beyond one compute unit's LDS: column-tile passes whose lengths may have prime factors up to 13 (Bluestein by default)
+    for n, dtype, want in ((100000, np.complex64, "400x250"), (44100, np.complex64, "210x210"), (1000000, np.complex64, "100x100x100"),
+                           (100000, np.complex128, "400x250")):
+        x = np.stack([hash_normal(2600 + b, n) for b in range(3)]).astype(dtype)
+        base, spec = make(fa, n, dtype), make(fa, n, dtype)
+        assert "bluestein" in base.describe()
+        spec.set_option("specialise", 1)
+        assert "mixed tiles " + want + " specialised" in spec.describe(), spec.describe()
+        tol = 2e-6 if dtype == np.complex64 else 1e-9  # f64: the ORACLE's unreduced chirp angle (bluesteins.rs:10,31,57)
+        for code in (0, 1, 4):
+            ref = oracle.transform_batch(x, code)
+            a = gpu_batch(torch, fa, spec, x, code)
+            assert rel_l2(a, ref) <= tol, (n, dtype, code, rel_l2(a, ref))
+            assert rel_l2(gpu_batch(torch, fa, spec, x, code, inplace=True), ref) <= tol, (n, dtype, code)
+        truth = torch.fft.fft(torch.from_numpy(x).to(torch.complex128)).numpy()
+        assert rel_l2(gpu_batch(torch, fa, spec, x, 0), truth) <= (4e-7 if dtype == np.complex64 else 3e-15), (n, dtype)
     for n in (1013, 17017, 4096, 999983):  # not of the family (17017 = 17 * 1001): refused, and the plan is untouched
         plan = make(fa, n, np.complex64)
         desc = plan.describe()
