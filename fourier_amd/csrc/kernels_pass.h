@@ -289,6 +289,45 @@ __device__ __forceinline__ void tile_core(RegTile<T, L, CG>& x, int& th, int& cg
   }
 }
 
+// Row-contiguous stores of an f32 register tile, 16 bytes per lane.  In the th-fastest mapping a thread holds outputs k = th + Q*r
+// of TWO columns (v = 0, 1), so its natural store is one 8-byte element per column -- 32 global_store_dwordx2 per thread, half
+// the bytes per instruction of everything else in these kernels.  Lanes l and l ^ 1 hold k and k + 1 of the same two columns:
+// one DPP exchange per value (the even lane sends its column-1 value and receives the odd lane's column-0 value) leaves the
+// even lane with (k, k + 1) of column 0 and the odd lane with (k, k + 1) of column 1 -- 16 global_store_dwordx4 per thread, a
+// wave's instruction covering 512 contiguous bytes of each column.  Same values, same addresses.
+// MEASURED, NO GAIN (round 4, profiles/r04_s10_paired_16_byte_row_stores_ab.jsonl, shared buffers, seven alternating repetitions):
+// C2's first pass 12.03 against 12.08 ms, C5's 12.34 against 12.20, C4's chirp-in pass 2.75 against 2.64, the conv kernel 3.82 / 3.81,
+// whole rows N = 128 ... 1024 within +-1.5 % -- the 8-byte stores were not what holds these kernels.  Off; the knob stays for A/B.
+#ifndef FOURIER_PAIRED_ROW_STORES
+#define FOURIER_PAIRED_ROW_STORES 0
+#endif
+__device__ __forceinline__ float shfl_xor1(float v) {
+  int i;
+  __builtin_memcpy(&i, &v, 4);
+  i = __shfl_xor(i, 1);
+  __builtin_memcpy(&v, &i, 4);
+  return v;
+}
+// base0 / base1: where column 0 / column 1 of this thread starts (element k = 0); ok0 / ok1: the column exists (ragged ROWS tile)
+template <int Q, bool NT, typename Fin>
+__device__ __forceinline__ void store_rows_paired(cpx<float> (&x)[2][16], cpx<float>* base0, cpx<float>* base1, bool ok0, bool ok1, int th,
+                                                  const Fin& fin) {
+  static_assert(Q % 2 == 0, "pairs of adjacent lanes share two columns");
+  const bool odd = (th & 1) != 0;
+  cpx<float>* p = (odd ? base1 : base0) + (th & ~1);
+  const bool ok = odd ? ok1 : ok0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const cpx<float> y0 = fin(x[0][r]), y1 = fin(x[1][r]);
+    const cpx<float> send = odd ? y0 : y1;
+    const cpx<float> recv{shfl_xor1(send.re), shfl_xor1(send.im)};
+    Unit16<float> u;
+    u.a[0] = odd ? recv.re : y0.re; u.a[1] = odd ? recv.im : y0.im;  // element k
+    u.a[2] = odd ? y1.re : recv.re; u.a[3] = odd ? y1.im : recv.im;  // element k + 1
+    if (ok) store_unit<float, NT>(p + Q * r, u);
+  }
+}
+
 // The body of a pass: one tile (block index `blk0` of `nblk`) of one big-radix Stockham pass.  LDPOL / STPOL = cache
 // policy of the data loads / stores (POL_*): the stand-alone pass kernels stream (non-temporal), the XCD-fused kernel
 // parks its intermediate in the L2 (plain stores, sc1 loads).
@@ -579,6 +618,19 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
       }
       __syncthreads();
     }
+  } else if constexpr (OUT_ROWS && VEC == 2 && Q % 2 == 0 && FOURIER_PAIRED_ROW_STORES != 0) {
+    if constexpr (sizeof(T) == 4) {  // (VEC == 2 is f32)
+      const uint64_t gc = g0 + (uint64_t)(cg * VEC);
+      const bool swap_out = FINAL && a.swap_out;
+      store_rows_paired<Q, STPOL == POL_NT>(x, out + gc * L, out + (gc + 1) * L, MODE != MODE_ROWS || gc < a.total_cols,
+                                             MODE != MODE_ROWS || gc + 1 < a.total_cols, th, [&](cpx<T> y) {
+                                               if constexpr (FINAL) {
+                                                 if (swap_out) y = {y.im, y.re};
+                                                 y = {y.re * scale, y.im * scale};
+                                               }
+                                               return y;
+                                             });
+    }
   } else if constexpr (OUT_ROWS) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
@@ -762,11 +814,18 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16)
     for (int r = 0; r < 16; ++r) x[v][r] = cmul(x[v][r], cmul(base, tu[r]));
   }
   // transposed store: column i's L outputs are contiguous
+  if constexpr (VEC == 2 && Q % 2 == 0 && FOURIER_PAIRED_ROW_STORES != 0) {
+    if constexpr (sizeof(T) == 4) {
+      cpx<T>* p0 = out + (c0 + (uint64_t)(cg * VEC)) * L;
+      store_rows_paired<Q, FOURIER_CONV_ST_NT != 0>(x, p0, p0 + L, true, true, th, [](cpx<T> y) { return y; });
+    }
+  } else {
 #pragma unroll
-  for (int v = 0; v < VEC; ++v) {
-    cpx<T>* p = out + (c0 + (uint64_t)(cg * VEC + v)) * L + th;
+    for (int v = 0; v < VEC; ++v) {
+      cpx<T>* p = out + (c0 + (uint64_t)(cg * VEC + v)) * L + th;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) store_elem<T, FOURIER_CONV_ST_NT != 0>(p + Q * r, x[v][r]);
+      for (int r = 0; r < 16; ++r) store_elem<T, FOURIER_CONV_ST_NT != 0>(p + Q * r, x[v][r]);
+    }
   }
 }
 
