@@ -2,7 +2,7 @@
 # Round 4 evidence session: parity at HEAD, smoke, bench (default line with the in-run copy ceiling and other_configs; f64; C5
 # full job through a 1-rank RCCL group), rocprofv3 kernel trace over the default bench and the other BASELINE
 # configurations, the PMC traffic passes (one counter set per run) over C2 / C3 / C4 / C5 chunk, the size sweeps, the A/B of
-# the LDS-staged twiddle tables of the per-length mixed-radix kernels.  Everything lands in gpurun_out/.
+# the LDS-staged twiddle tables of the per-length mixed-radix kernels, of the run-time specialisation and of the mixed-length tile passes.  Everything lands in gpurun_out/.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
@@ -26,4 +26,8 @@ echo "== sizes sweep"; timeout 600 python tools/gpu_sweep.py --what sizes 2>&1 |
 echo "== LDS twiddle tables of the per-length mixed-radix kernels, A/B"
 timeout 600 python tools/gpu_ab_options.py 6:8388608 12:4194304 24:4194304 48:2097152 96:1048576 192:524288 384:262144 243:524288 486:262144 100:1048576 125:1048576 250:524288 500:262144 320:262144 448:262144 96:524288:f64 243:262144:f64 500:131072:f64 \
   --libs twlds=fourier_amd/lib/variants/libfourier_mix_twlds.so --reps 7 2>&1 | grep -v amdgpu.ids > gpurun_out/mix_twlds_ab.jsonl; wc -l gpurun_out/mix_twlds_ab.jsonl
+echo "== specialise (hipRTC) A/B"
+timeout 600 python tools/gpu_ab_options.py 1001:262144 3003:131072 4095:65536 5005:53000 9009:29000 18018:14000 100000:2600 44100:6000 1001:131072:f64 9009:14000:f64 \
+  --arms default= specialise=specialise:1 --reps 5 2>&1 | grep -v amdgpu.ids > gpurun_out/specialise_ab.jsonl; wc -l gpurun_out/specialise_ab.jsonl
+echo "== mixed tiles A/B"; timeout 600 python tools/gpu_r04_tiled.py 2>&1 | grep -v amdgpu.ids > gpurun_out/tiled_ab.jsonl; wc -l gpurun_out/tiled_ab.jsonl
 echo "== stress"; STRESS_SEED=40404 timeout 900 python tools/gpu_r03_stress.py > gpurun_out/stress_40404.json 2> gpurun_out/stress.err; python -c "import json; d=json.load(open(\"gpurun_out/stress_40404.json\")); print({k: d[k] for k in (\"cases\", \"failures\", \"seconds\")})"
