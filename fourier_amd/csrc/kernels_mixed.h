@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(NT, FOURIER_MIX_RT_WAVES(T, MAXP, PPT)) mixed_
 // GROUP transforms per workgroup on NT threads, transform g at element g * LD of the buffer (defaults: the per-length kernels'
 // own rules; the tile passes of kernels_tiled.h run COLS = GROUP columns at a padded leading dimension)
 template <typename T, uint32_t N, uint32_t SIZE, uint32_t STRIDE, uint32_t TWOFF, bool FIRST_PASS, uint32_t GROUP = mix_group<T>(N),
-          uint32_t NT_ = mix_threads<T>(N), uint32_t LD = N, bool TWL = false>
+          uint32_t NT_ = mix_threads<T>(N), uint32_t LD = N, bool TWL = false, bool GIO = false>
 struct MixPassesCT {
   // entry (butterfly i, output k) of a pass's table of m butterflies: the reference's layout [i][k] (mod.rs:24-46), or -- TWL, the
   // copy staged in LDS by stage_tables() -- transposed [k][i]
@@ -358,7 +358,7 @@ struct MixPassesCT {
     }
   }
 
-  using Next = MixPassesCT<T, N, OUT_SIZE, OUT_STRIDE, OUT_TWOFF, false, GROUP, NT_, LD, TWL>;
+  using Next = MixPassesCT<T, N, OUT_SIZE, OUT_STRIDE, OUT_TWOFF, false, GROUP, NT_, LD, TWL, GIO>;
   // entries of all tables from this pass on (the host uploads them back to back, mod.rs:24-46)
   static constexpr uint32_t table_end() {
     if constexpr (LAST) return OUT_TWOFF; else return Next::table_end();
@@ -374,33 +374,53 @@ struct MixPassesCT {
     }
     if constexpr (!LAST) Next::stage_tables(g, l);
   }
+  // gin / gout / scale: GIO only (mix_gio) -- the first pass reads the transforms from global memory (same element order as the
+  // LDS buffer), the last pass scales and writes them to global memory; returns nullptr then (nothing is left to copy out)
   static __device__ __forceinline__ const cpx<T>* run(const cpx<T>* src, cpx<T>* dst, const cpx<T>* tw, uint32_t nb, bool fwd,
-                                                     cpx<T> w3, cpx<T> w8) {
+                                                     cpx<T> w3, cpx<T> w8, const cpx<T>* gin = nullptr, cpx<T>* gout = nullptr,
+                                                     T scale = (T)1, bool scaled = false) {
     if constexpr (mix_inplace<T>(N)) {
+      constexpr bool FROM_GLOBAL = GIO && FIRST_PASS, TO_GLOBAL = GIO && LAST;
       constexpr uint32_t ROUNDS = (GROUP * NBF + NT - 1) / NT;
       cpx<T> y[ROUNDS][PTS];
       uint32_t off[ROUNDS];
 #pragma unroll
       for (uint32_t rd = 0; rd < ROUNDS; ++rd) {
         const uint32_t q = threadIdx.x + NT * rd;
-        if (q < nb * NBF) compute(src, tw, q, fwd, w3, w8, y[rd], off[rd]);
+        if (q < nb * NBF) compute(FROM_GLOBAL ? gin : src, tw, q, fwd, w3, w8, y[rd], off[rd]);
       }
-      __syncthreads();  // every input of the pass has been read
-      cpx<T>* buf = const_cast<cpx<T>*>(src);
+      if constexpr (TO_GLOBAL) {
 #pragma unroll
-      for (uint32_t rd = 0; rd < ROUNDS; ++rd) {
-        const uint32_t q = threadIdx.x + NT * rd;
-        if (q < nb * NBF) {
+        for (uint32_t rd = 0; rd < ROUNDS; ++rd) {
+          const uint32_t q = threadIdx.x + NT * rd;
+          if (q < nb * NBF) {
 #pragma unroll
-          for (uint32_t k = 0; k < PTS; ++k) {
-            LDS_NOTE(buf + off[rd] + STRIDE * k, sizeof(cpx<T>), true, 102);
-            buf[off[rd] + STRIDE * k] = y[rd][k];
+            for (uint32_t k = 0; k < PTS; ++k) {
+              cpx<T> z = y[rd][k];
+              if (scaled) z = {z.re * scale, z.im * scale};  // mod.rs:387-393
+              gout[off[rd] + STRIDE * k] = z;
+            }
           }
         }
+        return nullptr;
+      } else {
+        if constexpr (!FROM_GLOBAL) __syncthreads();  // every input of the pass has been read (nothing to wait for when they came from global memory)
+        cpx<T>* buf = const_cast<cpx<T>*>(src);
+#pragma unroll
+        for (uint32_t rd = 0; rd < ROUNDS; ++rd) {
+          const uint32_t q = threadIdx.x + NT * rd;
+          if (q < nb * NBF) {
+#pragma unroll
+            for (uint32_t k = 0; k < PTS; ++k) {
+              LDS_NOTE(buf + off[rd] + STRIDE * k, sizeof(cpx<T>), true, 102);
+              buf[off[rd] + STRIDE * k] = y[rd][k];
+            }
+          }
+        }
+        __syncthreads();
+        if constexpr (LAST) return src;
+        else return Next::run(src, dst, tw, nb, fwd, w3, w8, gin, gout, scale, scaled);
       }
-      __syncthreads();
-      if constexpr (LAST) return src;
-      else return MixPassesCT<T, N, OUT_SIZE, OUT_STRIDE, OUT_TWOFF, false, GROUP, NT_, LD, TWL>::run(src, dst, tw, nb, fwd, w3, w8);
     } else {
       for (uint32_t q = threadIdx.x; q < nb * NBF; q += NT) {
         cpx<T> y[PTS];
@@ -411,7 +431,7 @@ struct MixPassesCT {
       }
       __syncthreads();
       if constexpr (LAST) return dst;
-      else return MixPassesCT<T, N, OUT_SIZE, OUT_STRIDE, OUT_TWOFF, false, GROUP, NT_, LD, TWL>::run(dst, const_cast<cpx<T>*>(src), tw, nb, fwd, w3, w8);
+      else return MixPassesCT<T, N, OUT_SIZE, OUT_STRIDE, OUT_TWOFF, false, GROUP, NT_, LD, TWL, GIO>::run(dst, const_cast<cpx<T>*>(src), tw, nb, fwd, w3, w8);
     }
   }
 };
@@ -428,10 +448,13 @@ __global__ void __launch_bounds__(mix_threads<T>(N)) mixed_radix_kernel_ct(MixAr
   const cpx<T>* in = (const cpx<T>*)a.in + b0 * N;
   cpx<T>* out = (cpx<T>*)a.out + b0 * N;
   // global <-> LDS in 16-byte units (two f32 points / one f64 point per lane and instruction; the user rows of an
-  // odd-length f32 batch are only 8-byte aligned, which global_load/store_dwordx4 tolerate), one odd point by itself
+  // odd-length f32 batch are only 8-byte aligned, which global_load/store_dwordx4 tolerate), one odd point by itself --
+  // unless the first pass reads global memory itself and the last pass writes it (mix_gio)
   constexpr uint32_t VEC = 16 / (2 * (uint32_t)sizeof(T));
+  constexpr bool GIO = mix_gio<T>(N);
   const uint32_t units = total / VEC;
-  if constexpr (VEC == 1) {
+  if constexpr (GIO) {
+  } else if constexpr (VEC == 1) {
     for (uint32_t idx = threadIdx.x; idx < total; idx += NT) buf0[idx] = in[idx];
   } else {
     for (uint32_t u = threadIdx.x; u < units; u += NT) *(Unit16<T>*)(buf0 + u * VEC) = load_unit_a8<T>(in + u * VEC);
@@ -439,7 +462,7 @@ __global__ void __launch_bounds__(mix_threads<T>(N)) mixed_radix_kernel_ct(MixAr
   }
   // twiddle tables shared by the GROUP transforms of this workgroup: staged in LDS behind the data (mix_tw_lds)
   constexpr bool TWL = mix_tw_lds<T>(N);
-  using Passes = MixPassesCT<T, N, N, 1, 0, true, GROUP, NT, N, TWL>;
+  using Passes = MixPassesCT<T, N, N, 1, 0, true, GROUP, NT, N, TWL, GIO>;
   const cpx<T>* tw = (const cpx<T>*)a.tw;
   if constexpr (TWL) {
     cpx<T>* ltw = buf0 + (size_t)(mix_inplace<T>(N) ? 1 : 2) * GROUP * N;
@@ -450,9 +473,11 @@ __global__ void __launch_bounds__(mix_threads<T>(N)) mixed_radix_kernel_ct(MixAr
   const bool fwd = a.forward != 0;
   cpx<T> w3{(T)a.w3re, (T)a.w3im}, w8{(T)a.w8re, (T)a.w8im};
   if (!fwd) { w3.im = -w3.im; w8.im = -w8.im; }
-  const cpx<T>* res = Passes::run(buf0, buf1, tw, nb, fwd, w3, w8);
   const T scale = a.scaled ? (T)a.scale : (T)1;  // mod.rs:387-393 (the unscaled codes skip the multiply: x * 1 is exact)
-  if constexpr (VEC == 1) {
+  const cpx<T>* res = Passes::run(buf0, buf1, tw, nb, fwd, w3, w8, in, out, scale, a.scaled != 0);
+  if constexpr (GIO) {
+    (void)res; (void)units;  // the last pass has written the output
+  } else if constexpr (VEC == 1) {
     for (uint32_t idx = threadIdx.x; idx < total; idx += NT) {
       cpx<T> y = res[idx];
       if (a.scaled) y = {y.re * scale, y.im * scale};

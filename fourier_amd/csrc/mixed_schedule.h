@@ -107,6 +107,31 @@ template <typename T> constexpr uint32_t mix_threads(uint32_t n) {
 #define FOURIER_MIX_TW_LDS 0
 #endif
 template <typename T> constexpr bool mix_tw_lds(uint32_t n) { return FOURIER_MIX_TW_LDS != 0 && mix_group<T>(n) >= 2; }
+// First pass straight from global memory, last pass straight to global memory (mix_gio): the per-length kernels otherwise copy the
+// transforms into LDS, run every pass there and copy the result out -- 2 * passes + 2 LDS accesses per point and 2 * passes + 1
+// barriers.  A work item of the first pass reads its points in[i + m * k] itself (for a fixed k the lanes of a wave -- consecutive
+// butterflies i -- read consecutive elements), a work item of the last pass writes out[j + stride * k] itself (consecutive j):
+// 2 * passes - 2 LDS accesses per point, 2 * passes - 3 barriers; same butterflies, tables and order, so the same bits.  Only
+// where a wave's accesses stay contiguous: at least FOURIER_MIX_GIO_MIN_RUN consecutive butterflies in the first and in the last
+// pass (short transforms pack several per workgroup and would read 3 of every 12 elements per instruction).
+#ifndef FOURIER_MIX_GIO_MIN_RUN
+#define FOURIER_MIX_GIO_MIN_RUN 64u
+#endif
+template <typename T> constexpr bool mix_gio(uint32_t n) {
+  if (FOURIER_MIX_GIO_MIN_RUN == 0u) return false;
+  uint32_t cur = n, first_run = 0, last_run = 0, stride = 1;
+  while (cur > 1) {
+    const uint32_t r = mix_next_radix(n, cur, cur == n);
+    if (cur % r) return false;
+    const bool pair = (r == 3 || r == 5) && cur >= r * r && (cur / r) % r == 0 && mix_pairs<T>(n, r);
+    const uint32_t pts = pair ? r * r : r;
+    if (cur == n) first_run = n / pts;  // butterflies i = 0 .. n / pts - 1 at stride 1
+    last_run = stride;                  // the last pass has m = 1: outputs j = 0 .. stride - 1 per k
+    stride *= pts;
+    cur /= pts;
+  }
+  return first_run >= FOURIER_MIX_GIO_MIN_RUN && last_run >= FOURIER_MIX_GIO_MIN_RUN && 2u * mix_group<T>(n) * n * 2u * sizeof(T) > FOURIER_MIX_INPLACE_BYTES;
+}
 template <typename T> constexpr bool mix_inplace(uint32_t n) {
   return FOURIER_MIX_INPLACE_BYTES == 0u || 2u * mix_group<T>(n) * n * 2u * sizeof(T) > FOURIER_MIX_INPLACE_BYTES;
 }
