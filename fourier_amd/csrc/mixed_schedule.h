@@ -113,9 +113,19 @@ template <typename T> constexpr bool mix_tw_lds(uint32_t n) { return FOURIER_MIX
 // butterflies i -- read consecutive elements), a work item of the last pass writes out[j + stride * k] itself (consecutive j):
 // 2 * passes - 2 LDS accesses per point, 2 * passes - 3 barriers; same butterflies, tables and order, so the same bits.  Only
 // where a wave's accesses stay contiguous: at least FOURIER_MIX_GIO_MIN_RUN consecutive butterflies in the first and in the last
-// pass (short transforms pack several per workgroup and would read 3 of every 12 elements per instruction).
+// pass (short transforms pack several per workgroup and would read 3 of every 12 elements per instruction) -- and only where it
+// was measured faster (profiles/r04_s13_mixed_radix_first_last_pass_global_io_ab.jsonl, bit-identical arms on shared buffers):
+// 2^a*3^b from 10 KiB per transform on -- f32 1536 +7 %, 3072 +14 %, 9216 +8 %, 18432 +16 %, 19683 +10 %, 6561 +6 %; f64 729 +11 %,
+// 2187 +27 %, 4374 +15 %, 9216 +22 % -- while 768 / 729 f32 lose 2-3 %; of the lengths with factors 5..13 only 5^5 and 5^6 gain
+// (+11 % / +8 %; 1000 -6 %, 2401 -4 %, 5000 / 10000 +-1 %).
 #ifndef FOURIER_MIX_GIO_MIN_RUN
 #define FOURIER_MIX_GIO_MIN_RUN 64u
+#endif
+#ifndef FOURIER_MIX_GIO_MIN_BYTES
+#define FOURIER_MIX_GIO_MIN_BYTES 10240u
+#endif
+#ifndef FOURIER_MIX_GIO_ALL
+#define FOURIER_MIX_GIO_ALL 0  // 1: every length that satisfies the run-length condition (A/B)
 #endif
 template <typename T> constexpr bool mix_gio(uint32_t n) {
   if (FOURIER_MIX_GIO_MIN_RUN == 0u) return false;
@@ -130,7 +140,9 @@ template <typename T> constexpr bool mix_gio(uint32_t n) {
     stride *= pts;
     cur /= pts;
   }
-  return first_run >= FOURIER_MIX_GIO_MIN_RUN && last_run >= FOURIER_MIX_GIO_MIN_RUN && 2u * mix_group<T>(n) * n * 2u * sizeof(T) > FOURIER_MIX_INPLACE_BYTES;
+  const bool measured_faster = mix_extended(n) ? (n == 3125u || n == 15625u) : n * 2u * (uint32_t)sizeof(T) >= FOURIER_MIX_GIO_MIN_BYTES;
+  return (measured_faster || FOURIER_MIX_GIO_ALL != 0) && first_run >= FOURIER_MIX_GIO_MIN_RUN && last_run >= FOURIER_MIX_GIO_MIN_RUN &&
+         2u * mix_group<T>(n) * n * 2u * sizeof(T) > FOURIER_MIX_INPLACE_BYTES;
 }
 template <typename T> constexpr bool mix_inplace(uint32_t n) {
   return FOURIER_MIX_INPLACE_BYTES == 0u || 2u * mix_group<T>(n) * n * 2u * sizeof(T) > FOURIER_MIX_INPLACE_BYTES;

@@ -67,7 +67,9 @@ inline bool& lds_trace_on() { static bool on = getenv("HIPEMU_LDS_TRACE") != nul
 inline void lds_note(const void* p, unsigned bytes, bool is_write, uint32_t site) {
   if (!lds_trace_on()) return;
   Tls& t = tls();
-  lds_log().push_back({(uint32_t)((const unsigned char*)p - t.smem), (uint16_t)bytes, (uint8_t)is_write, site});
+  const size_t off = (size_t)((const unsigned char*)p - t.smem);
+  if (off >= ((size_t)1 << 20)) return;  // not an LDS address: a pass that reads its input straight from global memory (mix_gio)
+  lds_log().push_back({(uint32_t)off, (uint16_t)bytes, (uint8_t)is_write, site});
 }
 
 // cost (LDS-array cycles) of one wave-instruction given 64 lane byte-addresses

@@ -62,6 +62,8 @@ VARIANTS = {
     "mix_half_250": ["-DFOURIER_MIX_HALF_MAX_ITEMS=250u"],
     "mix_wide_none": ["-DFOURIER_MIX_WIDE_MIN_BYTES=0xffffffffu", "-DFOURIER_MIX_WIDE_MIN_N=0xffffffffu"],
     "row_stores_16b": ["-DFOURIER_PAIRED_ROW_STORES=1"],
+    "mix_gio_off": ["-DFOURIER_MIX_GIO_MIN_RUN=0u"],
+    "mix_gio_all": ["-DFOURIER_MIX_GIO_ALL=1"],
     "mix_twlds": ["-DFOURIER_MIX_TW_LDS=1"],
     "pf_nobar": ["-DFOURIER_PF_BARRIER_AFTER_WAIT=0"],
     "pf_vm0": ["-DFOURIER_PF_WAIT_ALL=1"],
