@@ -65,6 +65,7 @@ VARIANTS = {
     "mix_gio_off": ["-DFOURIER_MIX_GIO_MIN_RUN=0u"],
     "mix_gio_all": ["-DFOURIER_MIX_GIO_ALL=1"],
     "mix_twlds": ["-DFOURIER_MIX_TW_LDS=1"],
+    "mix_slp": ["-fslp-vectorize", "-DFOURIER_MIX_SLP_BUILD=1"],  # packed f32 VALU ops in the LDS mixed-radix / mixed-tile kernels only
     "pf_nobar": ["-DFOURIER_PF_BARRIER_AFTER_WAIT=0"],
     "pf_vm0": ["-DFOURIER_PF_WAIT_ALL=1"],
     "pf_vm0_plainst": ["-DFOURIER_PF_WAIT_ALL=1", "-DFOURIER_PF_ST_PLAIN=1"],
@@ -82,11 +83,11 @@ def groups_of(flags):
     """Translation-unit groups (fourier_amd/build.py) a variant's flags can reach: the LDS mixed-radix knobs touch only the
     'mixed' objects, everything else only the tile / one-launch / small kernels; the other objects come from the base build."""
     mixed = any("MIX" in f for f in flags)
-    other = any("MIX" not in f for f in flags)
+    other = any("MIX" not in f and not f.startswith("-f") for f in flags)  # a code-generation flag follows the knobs it comes with
     g = set()
     if mixed:
         g |= {"mixed"}
-    if other or not flags:
+    if other or not mixed:
         g |= {"pass", "onelaunch", "misc"}
     return g
 
