@@ -277,8 +277,9 @@ __global__ void __launch_bounds__(NT, FOURIER_MIX_RT_WAVES(T, MAXP, PPT)) mixed_
 // the same order: still bit-identical to the CPU restatement.
 // GROUP transforms per workgroup on NT threads, transform g at element g * LD of the buffer (defaults: the per-length kernels'
 // own rules; the tile passes of kernels_tiled.h run COLS = GROUP columns at a padded leading dimension)
+// LIN: the layout (mix_out_layout) of the data this pass reads
 template <typename T, uint32_t N, uint32_t SIZE, uint32_t STRIDE, uint32_t TWOFF, bool FIRST_PASS, uint32_t GROUP = mix_group<T>(N),
-          uint32_t NT_ = mix_threads<T>(N), uint32_t LD = N, bool TWL = false, bool GIO = false>
+          uint32_t NT_ = mix_threads<T>(N), uint32_t LD = N, bool TWL = false, bool GIO = false, uint32_t LIN = 0>
 struct MixPassesCT {
   // entry (butterfly i, output k) of a pass's table of m butterflies: the reference's layout [i][k] (mod.rs:24-46), or -- TWL, the
   // copy staged in LDS by stage_tables() -- transposed [k][i]
@@ -295,14 +296,27 @@ struct MixPassesCT {
   static constexpr uint32_t OUT_SIZE = PAIR ? SIZE2 / R : SIZE / R, OUT_STRIDE = STRIDE * PTS;
   static constexpr uint32_t OUT_TWOFF = PAIR ? TWOFF + SIZE + SIZE2 : TWOFF + SIZE;
   static constexpr bool LAST = (OUT_SIZE == 1);
+  static constexpr uint32_t LOUT = mix_out_layout(N, STRIDE, PTS, LAST, sizeof(cpx<T>) == 8 ? 4u : 3u);  // the layout this pass writes
+  // element e0 + off of a transform in the layout this pass reads; `off` a compile-time constant
+  static __device__ __forceinline__ uint32_t wr_index(uint32_t q, uint32_t off, uint32_t k) {
+    if (LOUT == 0) return off + STRIDE * k;
+    return (GROUP == 1 ? 0 : (q / NBF) * LD) + mix_sw(LOUT, off + STRIDE * k);
+  }
+  // (pointer plus constant, not an index sum: the constant then folds into the instruction's offset field)
+  static __device__ __forceinline__ const cpx<T>* rd_ptr(const cpx<T>* in, uint32_t e0, uint32_t off) {
+    if (LIN == 0 || off % mix_sw_span(LIN) == 0) return (in + mix_sw(LIN, e0)) + off;  // the offset does not reach the map's bits
+    return in + mix_sw(LIN, e0 + off);
+  }
 
   // work item q: load, butterfly (+ twiddle), results in y[PTS] in the order of the output slots
   static __device__ __forceinline__ void compute(const cpx<T>* src, const cpx<T>* tw, uint32_t q, bool fwd, cpx<T> w3, cpx<T> w8,
                                                  cpx<T> (&y)[PTS], uint32_t& out_off) {
-    const uint32_t g = q / NBF, e = q % NBF, i = e / STRIDE, j = e % STRIDE;  // constants: multiply-shift
-    const cpx<T>* in = src + g * LD + j + STRIDE * i;
+    const uint32_t g = GROUP == 1 ? 0 : q / NBF, e = GROUP == 1 ? q : q % NBF, i = e / STRIDE, j = e % STRIDE;  // constants: multiply-shift
+    const cpx<T>* in = src + g * LD;
+    const uint32_t e0 = j + STRIDE * i;
     const cpx<T>* __restrict__ t = tw + TWOFF;
-    out_off = g * LD + j + PTS * STRIDE * i;
+    // plain output layout: the index in the buffer; else the index within the transform (wr_index() adds g * LD behind the map)
+    out_off = (LOUT == 0 ? g * LD : 0) + j + PTS * STRIDE * i;
     if constexpr (PAIR) {
       const cpx<T>* __restrict__ t2 = tw + TWOFF + SIZE;
       cpx<T> x[R][R];
@@ -310,8 +324,8 @@ struct MixPassesCT {
       for (uint32_t k2 = 0; k2 < R; ++k2)
 #pragma unroll
         for (uint32_t k1 = 0; k1 < R; ++k1) {
-          LDS_NOTE(in + STRIDE * (M2 * k2 + M * k1), sizeof(cpx<T>), false, 100);
-          x[k2][k1] = in[STRIDE * (M2 * k2 + M * k1)];
+          LDS_NOTE(rd_ptr(in, e0, STRIDE * (M2 * k2 + M * k1)), sizeof(cpx<T>), false, 100);
+          x[k2][k1] = *rd_ptr(in, e0, STRIDE * (M2 * k2 + M * k1));
         }
 #pragma unroll
       for (uint32_t k2 = 0; k2 < R; ++k2) {
@@ -343,8 +357,8 @@ struct MixPassesCT {
     } else {
 #pragma unroll
       for (uint32_t k = 0; k < R; ++k) {
-        LDS_NOTE(in + STRIDE * M * k, sizeof(cpx<T>), false, 101);
-        y[k] = in[STRIDE * M * k];
+        LDS_NOTE(rd_ptr(in, e0, STRIDE * M * k), sizeof(cpx<T>), false, 101);
+        y[k] = *rd_ptr(in, e0, STRIDE * M * k);
       }
       ref_butterfly<T, (int)R>(y, fwd, w3, w8);
       if constexpr (SIZE != R) {  // mod.rs:238,272
@@ -358,7 +372,7 @@ struct MixPassesCT {
     }
   }
 
-  using Next = MixPassesCT<T, N, OUT_SIZE, OUT_STRIDE, OUT_TWOFF, false, GROUP, NT_, LD, TWL, GIO>;
+  using Next = MixPassesCT<T, N, OUT_SIZE, OUT_STRIDE, OUT_TWOFF, false, GROUP, NT_, LD, TWL, GIO, LOUT>;
   // entries of all tables from this pass on (the host uploads them back to back, mod.rs:24-46)
   static constexpr uint32_t table_end() {
     if constexpr (LAST) return OUT_TWOFF; else return Next::table_end();
@@ -398,7 +412,7 @@ struct MixPassesCT {
             for (uint32_t k = 0; k < PTS; ++k) {
               cpx<T> z = y[rd][k];
               if (scaled) z = {z.re * scale, z.im * scale};  // mod.rs:387-393
-              gout[off[rd] + STRIDE * k] = z;
+              gout[off[rd] + STRIDE * k] = z;  // (the last pass writes the plain layout)
             }
           }
         }
@@ -412,8 +426,9 @@ struct MixPassesCT {
           if (q < nb * NBF) {
 #pragma unroll
             for (uint32_t k = 0; k < PTS; ++k) {
-              LDS_NOTE(buf + off[rd] + STRIDE * k, sizeof(cpx<T>), true, 102);
-              buf[off[rd] + STRIDE * k] = y[rd][k];
+              const uint32_t idx = wr_index(q, off[rd], k);
+              LDS_NOTE(buf + idx, sizeof(cpx<T>), true, 102);
+              buf[idx] = y[rd][k];
             }
           }
         }
@@ -427,11 +442,11 @@ struct MixPassesCT {
         uint32_t off;
         compute(src, tw, q, fwd, w3, w8, y, off);
 #pragma unroll
-        for (uint32_t k = 0; k < PTS; ++k) dst[off + STRIDE * k] = y[k];
+        for (uint32_t k = 0; k < PTS; ++k) dst[wr_index(q, off, k)] = y[k];
       }
       __syncthreads();
       if constexpr (LAST) return dst;
-      else return MixPassesCT<T, N, OUT_SIZE, OUT_STRIDE, OUT_TWOFF, false, GROUP, NT_, LD, TWL, GIO>::run(dst, const_cast<cpx<T>*>(src), tw, nb, fwd, w3, w8);
+      else return Next::run(dst, const_cast<cpx<T>*>(src), tw, nb, fwd, w3, w8);
     }
   }
 };

@@ -144,6 +144,36 @@ template <typename T> constexpr bool mix_gio(uint32_t n) {
   return (measured_faster || FOURIER_MIX_GIO_ALL != 0) && first_run >= FOURIER_MIX_GIO_MIN_RUN && last_run >= FOURIER_MIX_GIO_MIN_RUN &&
          2u * mix_group<T>(n) * n * 2u * sizeof(T) > FOURIER_MIX_INPLACE_BYTES;
 }
+// LDS layout of the data between two passes (FOURIER_MIX_SWIZZLE).  A pass writes out[j + PTS*stride*i + stride*k]: with a
+// power-of-two stride below 16 the sixteen lanes of a ds_write lane group -- consecutive (i, j) -- land on 4 (first pass, radix
+// 4 at stride 1: element 4 i + k) or 4 (second pass, radix 8 at stride 4: j + 32 i + 4 k) of the 16 eight-byte bank pairs, a
+// 4-way conflict that makes these two passes half of the kernel's LDS cycles (SQ_LDS_BANK_CONFLICT = 36 - 48 % of
+// SQ_LDS_IDX_ACTIVE on 768 ... 18432 points, profiles/r04_s14b_sq_breakdown_mixed.json; the later passes, stride >= 32, write
+// contiguously).  Such a pass therefore writes element e at e ^ (field << dst), field = the nbits address bits from bit `src` up
+// that tell the lanes of a group apart but lie above the bank bits, moved onto the bank bits that are the same for all of
+// them; the next pass reads through the same map.  The map permutes the elements of an aligned block of 16 (f64: 8), so contiguous
+// accesses (every read, every later write) stay conflict-free and no LDS is added.  Encoded src << 8 | nbits << 4 | dst; 0 = the
+// plain layout.  Only where the transform is a whole number of such blocks.
+#ifndef FOURIER_MIX_SWIZZLE
+#define FOURIER_MIX_SWIZZLE 1
+#endif
+constexpr bool mix_is_pow2(uint32_t v) { return v != 0 && (v & (v - 1)) == 0; }
+constexpr uint32_t mix_log2(uint32_t v) { return v <= 1 ? 0 : 1 + mix_log2(v >> 1); }
+// group_bits: log2 of the lanes in a ds_write lane group = log2 of the bank slots an element can fall on -- 4 for 8-byte elements
+// (ds_write_b64: 16 lanes, 16 bank pairs), 3 for 16-byte elements (ds_write_b128: 8 lanes, 8 slots of four banks)
+constexpr uint32_t mix_out_layout(uint32_t n, uint32_t stride, uint32_t pts, bool last, uint32_t group_bits) {
+  const uint32_t lanes = 1u << group_bits;
+  if (!FOURIER_MIX_SWIZZLE || last || n % lanes != 0 || stride >= lanes || !mix_is_pow2(stride) || !mix_is_pow2(pts) || pts < 2) return 0;
+  const uint32_t s = mix_log2(stride), b = s + mix_log2(pts);  // j: bits [0, s); k: bits [s, b); i: bits from b up
+  // the group's group_bits - s bits of i: those below bit `group_bits` already select slots; the others move onto k's bits
+  const uint32_t src = b >= group_bits ? b : group_bits, nbits = b >= group_bits ? group_bits - s : b - s, dst = s;
+  return nbits == 0 ? 0 : (src << 8 | nbits << 4 | dst);
+}
+constexpr uint32_t mix_sw(uint32_t layout, uint32_t e) {
+  return layout == 0 ? e : e ^ (((e >> (layout >> 8)) & ((1u << ((layout >> 4) & 15u)) - 1u)) << (layout & 15u));
+}
+// the bits of an element index the map looks at or changes: an offset that is a multiple of this leaves the map's XOR term alone
+constexpr uint32_t mix_sw_span(uint32_t layout) { return layout == 0 ? 1u : 1u << ((layout >> 8) + ((layout >> 4) & 15u)); }
 template <typename T> constexpr bool mix_inplace(uint32_t n) {
   return FOURIER_MIX_INPLACE_BYTES == 0u || 2u * mix_group<T>(n) * n * 2u * sizeof(T) > FOURIER_MIX_INPLACE_BYTES;
 }
