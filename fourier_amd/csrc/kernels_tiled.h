@@ -54,18 +54,26 @@ __global__ void __launch_bounds__((TiledCfg<T, L>::NT)) tiled_mixed_kernel_ct(Ti
   const uint64_t row_stride = a.s * a.m;
   const uint64_t col0 = first ? (uint64_t)c0 : (uint64_t)c0 + a.s * (uint64_t)i_row;
 
-  // ---- inter-pass twiddle tables of this tile (none in the last pass: size == L, mod.rs:238)
+  // ---- every global load of the tile first, the two factors of each inter-pass twiddle table entry and then the data, so that one
+  // memory latency covers both (the table loads used to complete -- they feed LDS writes -- before the gather was issued)
+  // inter-pass twiddle tables of this tile (none in the last pass: size == L, mod.rs:238)
   const bool twiddled = a.m > 1;
+  constexpr uint32_t TENT = COLS * (KH + 16), TITER = (TENT + NT - 1) / NT;
+  cpx<T> tlo[TITER], thi[TITER];
   if (twiddled) {
     const cpx<T>* lo = (const cpx<T>*)a.tw_lo;
     const cpx<T>* hi = (const cpx<T>*)a.tw_hi;
     const uint32_t mask = (1u << a.lo_bits) - 1u;
-    for (uint32_t e = tid; e < COLS * (KH + 16); e += NT) {
-      const uint32_t c = e / (KH + 16), q = e - c * (KH + 16);
-      const uint64_t i = first ? (uint64_t)(c0 + c) : (uint64_t)i_row;
-      const uint64_t ex = i * (uint64_t)(q < KH ? 16u * q : q - KH);  // i * k < size
-      const cpx<T> w = cmul(lo[ex & mask], hi[ex >> a.lo_bits]);
-      if (q < KH) ta[c * KH + q] = w; else tb[c * 16 + (q - KH)] = w;
+#pragma unroll
+    for (uint32_t it = 0; it < TITER; ++it) {
+      const uint32_t e = tid + it * NT;
+      if (e < TENT) {
+        const uint32_t c = e / (KH + 16), q = e - c * (KH + 16);
+        const uint64_t i = first ? (uint64_t)(c0 + c) : (uint64_t)i_row;
+        const uint64_t ex = i * (uint64_t)(q < KH ? 16u * q : q - KH);  // i * k < size
+        tlo[it] = lo[ex & mask];
+        thi[it] = hi[ex >> a.lo_bits];
+      }
     }
   }
 
@@ -86,6 +94,17 @@ __global__ void __launch_bounds__((TiledCfg<T, L>::NT)) tiled_mixed_kernel_ct(Ti
         else if (c < ncols) { w.a[0] = p->re; w.a[1] = p->im; }  // ragged tile, f32: the last valid column by itself
       }
       v[it] = w;
+    }
+    if (twiddled) {
+#pragma unroll
+      for (uint32_t it = 0; it < TITER; ++it) {
+        const uint32_t e = tid + it * NT;
+        if (e < TENT) {
+          const uint32_t c = e / (KH + 16), q = e - c * (KH + 16);
+          const cpx<T> w = cmul(tlo[it], thi[it]);
+          if (q < KH) ta[c * KH + q] = w; else tb[c * 16 + (q - KH)] = w;
+        }
+      }
     }
 #pragma unroll
     for (uint32_t it = 0; it < ITER; ++it) {
