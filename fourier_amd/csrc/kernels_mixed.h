@@ -308,12 +308,31 @@ struct MixPassesCT {
     return in + mix_sw(LIN, e0 + off);
   }
 
-  // work item q: load, butterfly (+ twiddle), results in y[PTS] in the order of the output slots
-  static __device__ __forceinline__ void compute(const cpx<T>* src, const cpx<T>* tw, uint32_t q, bool fwd, cpx<T> w3, cpx<T> w8,
-                                                 cpx<T> (&y)[PTS], uint32_t& out_off) {
+  // work item q: its PTS inputs, in the order finish() consumes them ([k2][k1] for a pass pair)
+  static __device__ __forceinline__ void load(const cpx<T>* src, uint32_t q, cpx<T> (&x)[PTS]) {
     const uint32_t g = GROUP == 1 ? 0 : q / NBF, e = GROUP == 1 ? q : q % NBF, i = e / STRIDE, j = e % STRIDE;  // constants: multiply-shift
     const cpx<T>* in = src + g * LD;
     const uint32_t e0 = j + STRIDE * i;
+    if constexpr (PAIR) {
+#pragma unroll
+      for (uint32_t k2 = 0; k2 < R; ++k2)
+#pragma unroll
+        for (uint32_t k1 = 0; k1 < R; ++k1) {
+          LDS_NOTE(rd_ptr(in, e0, STRIDE * (M2 * k2 + M * k1)), sizeof(cpx<T>), false, 100);
+          x[k2 * R + k1] = *rd_ptr(in, e0, STRIDE * (M2 * k2 + M * k1));
+        }
+    } else {
+#pragma unroll
+      for (uint32_t k = 0; k < R; ++k) {
+        LDS_NOTE(rd_ptr(in, e0, STRIDE * M * k), sizeof(cpx<T>), false, 101);
+        x[k] = *rd_ptr(in, e0, STRIDE * M * k);
+      }
+    }
+  }
+  // work item q: butterfly (+ twiddle) of its inputs, results in y[PTS] in the order of the output slots
+  static __device__ __forceinline__ void finish(const cpx<T> (&xin)[PTS], const cpx<T>* tw, uint32_t q, bool fwd, cpx<T> w3, cpx<T> w8,
+                                                cpx<T> (&y)[PTS], uint32_t& out_off) {
+    const uint32_t g = GROUP == 1 ? 0 : q / NBF, e = GROUP == 1 ? q : q % NBF, i = e / STRIDE, j = e % STRIDE;
     const cpx<T>* __restrict__ t = tw + TWOFF;
     // plain output layout: the index in the buffer; else the index within the transform (wr_index() adds g * LD behind the map)
     out_off = (LOUT == 0 ? g * LD : 0) + j + PTS * STRIDE * i;
@@ -323,10 +342,7 @@ struct MixPassesCT {
 #pragma unroll
       for (uint32_t k2 = 0; k2 < R; ++k2)
 #pragma unroll
-        for (uint32_t k1 = 0; k1 < R; ++k1) {
-          LDS_NOTE(rd_ptr(in, e0, STRIDE * (M2 * k2 + M * k1)), sizeof(cpx<T>), false, 100);
-          x[k2][k1] = *rd_ptr(in, e0, STRIDE * (M2 * k2 + M * k1));
-        }
+        for (uint32_t k1 = 0; k1 < R; ++k1) x[k2][k1] = xin[k2 * R + k1];
 #pragma unroll
       for (uint32_t k2 = 0; k2 < R; ++k2) {
         ref_butterfly<T, (int)R>(x[k2], fwd, w3, w8);
@@ -356,10 +372,7 @@ struct MixPassesCT {
       }
     } else {
 #pragma unroll
-      for (uint32_t k = 0; k < R; ++k) {
-        LDS_NOTE(rd_ptr(in, e0, STRIDE * M * k), sizeof(cpx<T>), false, 101);
-        y[k] = *rd_ptr(in, e0, STRIDE * M * k);
-      }
+      for (uint32_t k = 0; k < R; ++k) y[k] = xin[k];
       ref_butterfly<T, (int)R>(y, fwd, w3, w8);
       if constexpr (SIZE != R) {  // mod.rs:238,272
 #pragma unroll
@@ -370,6 +383,13 @@ struct MixPassesCT {
         }
       }
     }
+  }
+  // work item q: load, butterfly (+ twiddle)
+  static __device__ __forceinline__ void compute(const cpx<T>* src, const cpx<T>* tw, uint32_t q, bool fwd, cpx<T> w3, cpx<T> w8,
+                                                 cpx<T> (&y)[PTS], uint32_t& out_off) {
+    cpx<T> x[PTS];
+    load(src, q, x);
+    finish(x, tw, q, fwd, w3, w8, y, out_off);
   }
 
   using Next = MixPassesCT<T, N, OUT_SIZE, OUT_STRIDE, OUT_TWOFF, false, GROUP, NT_, LD, TWL, GIO, LOUT>;
@@ -398,10 +418,24 @@ struct MixPassesCT {
       constexpr uint32_t ROUNDS = (GROUP * NBF + NT - 1) / NT;
       cpx<T> y[ROUNDS][PTS];
       uint32_t off[ROUNDS];
+      if constexpr (mix_loads_first<T>(N) && ROUNDS > 1) {  // the loads of every work item ahead of the first butterfly
+        cpx<T> x[ROUNDS][PTS];
 #pragma unroll
-      for (uint32_t rd = 0; rd < ROUNDS; ++rd) {
-        const uint32_t q = threadIdx.x + NT * rd;
-        if (q < nb * NBF) compute(FROM_GLOBAL ? gin : src, tw, q, fwd, w3, w8, y[rd], off[rd]);
+        for (uint32_t rd = 0; rd < ROUNDS; ++rd) {
+          const uint32_t q = threadIdx.x + NT * rd;
+          if (q < nb * NBF) load(FROM_GLOBAL ? gin : src, q, x[rd]);
+        }
+#pragma unroll
+        for (uint32_t rd = 0; rd < ROUNDS; ++rd) {
+          const uint32_t q = threadIdx.x + NT * rd;
+          if (q < nb * NBF) finish(x[rd], tw, q, fwd, w3, w8, y[rd], off[rd]);
+        }
+      } else {
+#pragma unroll
+        for (uint32_t rd = 0; rd < ROUNDS; ++rd) {
+          const uint32_t q = threadIdx.x + NT * rd;
+          if (q < nb * NBF) compute(FROM_GLOBAL ? gin : src, tw, q, fwd, w3, w8, y[rd], off[rd]);
+        }
       }
       if constexpr (TO_GLOBAL) {
 #pragma unroll

@@ -174,6 +174,21 @@ constexpr uint32_t mix_sw(uint32_t layout, uint32_t e) {
 }
 // the bits of an element index the map looks at or changes: an offset that is a multiple of this leaves the map's XOR term alone
 constexpr uint32_t mix_sw_span(uint32_t layout) { return layout == 0 ? 1u : 1u << ((layout >> 8) + ((layout >> 4) & 15u)); }
+// In-place passes: the loads of ALL of a thread's work items ahead of its first butterfly (kernels_mixed.h: MixPassesCT::run).  A work
+// item is a basic block of its own (q < nb * NBF) and hipcc otherwise waits for one item's loads -- global memory in the first pass of
+// a mix_gio kernel -- before it issues the next item's.  Where it was measured faster (bit-identical arms,
+// profiles/r04_s20_mixed_radix_loads_first_ab.jsonl): 2^a*3^b from 16 KiB per transform on -- f64 1536 +7 %, 3072 +9 %, 4608 +5 %,
+// 9216 +8 %; f32 3072 +3 %, 6144 +5 %, 2304 / 13824 +2 % -- but not the f32 lengths that fill a CU's LDS (18432 -2 %); shorter
+// transforms lose 1 - 2 %; of the lengths with factors 5..13 only 5^5 gains (+3 %; 5000 -3 %, 10000 f64 -2 %).  The pass's twiddles
+// loaded with them as well: measured, no (r04_s21: 9216 f32 / f64 -22 % / -8 %, the others +-2 %).
+#ifndef FOURIER_MIX_LOADS_FIRST
+#define FOURIER_MIX_LOADS_FIRST 1  // 0: never, 2: every length (A/B)
+#endif
+template <typename T> constexpr bool mix_loads_first(uint32_t n) {
+  if (FOURIER_MIX_LOADS_FIRST != 1) return FOURIER_MIX_LOADS_FIRST != 0;
+  if (mix_extended(n)) return n == 3125u && sizeof(T) == 4;
+  return n * 2u * (uint32_t)sizeof(T) >= 16384u && (sizeof(T) == 8 || n <= 16384u);
+}
 template <typename T> constexpr bool mix_inplace(uint32_t n) {
   return FOURIER_MIX_INPLACE_BYTES == 0u || 2u * mix_group<T>(n) * n * 2u * sizeof(T) > FOURIER_MIX_INPLACE_BYTES;
 }
