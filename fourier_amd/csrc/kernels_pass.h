@@ -361,6 +361,9 @@ template <typename T> __device__ __forceinline__ cpx<T> root_n(const PassArgs& a
   return cmul(lo[e & ((1u << a.tn_bits) - 1u)], hi[e >> a.tn_bits]);
 }
 
+#ifndef FOURIER_TABS_AFTER_LOADS
+#define FOURIER_TABS_AFTER_LOADS 1
+#endif
 #ifndef FOURIER_BLU_OUT_ST_NT
 #define FOURIER_BLU_OUT_ST_NT 0
 #endif
@@ -414,7 +417,10 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
   constexpr int LDAUX = LDPOL == POL_NT ? BUF_NT : (LDPOL == POL_SC1 ? BUF_SC1 : BUF_PLAIN);
   constexpr int STAUX = STPOL == POL_NT ? BUF_NT : BUF_PLAIN;
 
-  // ---- inter-pass twiddle table for this tile: tabU[col][r] = W_size^{i_col * Q * r}
+  // ---- inter-pass twiddle table for this tile: tabU[col][r] = W_size^{i_col * Q * r}.  Filled BEHIND the tile's own loads
+  // (FOURIER_TABS_AFTER_LOADS): its table loads feed LDS writes, and ahead of the tile's loads -- where it used to sit -- their L2
+  // latency was served before the first HBM load of the tile was issued, once per tile
+  auto fill_tabs = [&]() {
   if constexpr (TWIDDLED) {
     cpx<T>* tabU = (cpx<T>*)(smem + C::TABU_OFF);
     if constexpr (MODE == MODE_FIRST) {
@@ -437,6 +443,8 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
       if (tid < 16) tabU[tid] = two_level_twiddle<T>(a, (c0 >> a.s_shift) * (uint64_t)(Q * tid));
     }
   }
+  };
+  if constexpr (FOURIER_TABS_AFTER_LOADS == 0) fill_tabs();
 
   // ---- load: register r <- row th + Q*r
   cpx<T> x[VEC][16];
@@ -491,6 +499,7 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
     Unit16<T> d[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) d[r] = buf_load_unit<T, LDAUX>(rd, voff + (uint32_t)r * rowb);
+    if constexpr (FOURIER_TABS_AFTER_LOADS != 0) fill_tabs();
     if (a.blu_p) {
       // chirp computed, not read: x[k] = P[row] * (U[b] * W_n^{cn*b*th}) * tabV[col][r]   (see PassArgs)
       const cpx<T>* pt = (const cpx<T>*)a.blu_p + th;
@@ -564,6 +573,7 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
 #pragma unroll
       for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
     }
+    if constexpr (FOURIER_TABS_AFTER_LOADS != 0) fill_tabs();
   }
   if (a.swap_in) {
 #pragma unroll
@@ -753,12 +763,16 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16)
   // two in-tile FFTs.
   const uint32_t rowb = (uint32_t)((uint64_t)Q * a.cn * sizeof(cpx<T>));  // byte distance of a thread's consecutive rows
 
-  // inter-pass twiddle table of the inverse FFT's first pass: tabU[col][r] = W_M^{i_col * Q * r}
+  // inter-pass twiddle table of the inverse FFT's first pass: tabU[col][r] = W_M^{i_col * Q * r} -- filled behind the tile's loads
+  // (see pass_tile)
   cpx<T>* tabU = (cpx<T>*)(smem + C::TABU_OFF);
-  for (int idx = tid; idx < COLS * 16; idx += C::NT) {
-    const uint64_t i = c0 + (uint64_t)(idx >> 4);
-    tabU[idx] = two_level_twiddle<T>(a, i * (uint64_t)(Q * (idx & 15)));
-  }
+  auto fill_tabs = [&]() {
+    for (int idx = tid; idx < COLS * 16; idx += C::NT) {
+      const uint64_t i = c0 + (uint64_t)(idx >> 4);
+      tabU[idx] = two_level_twiddle<T>(a, i * (uint64_t)(Q * (idx & 15)));
+    }
+  };
+  if constexpr (FOURIER_TABS_AFTER_LOADS == 0) fill_tabs();
 
   // forward LAST pass: rows th + Q*r (stride cn) of columns c0 + cg*VEC + v
   cpx<T> x[VEC][16];
@@ -774,6 +788,7 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16)
       for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
     }
   }
+  if constexpr (FOURIER_TABS_AFTER_LOADS != 0) fill_tabs();
   tile_core<T, L, CG, MODE_LAST>(x, th, cg, tid, smem, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw2);
   // register r holds X[c + cn*(th + Q*r)]: (.) w (FFT'd chirp, 1/M folded in), then the inverse's leading swap
   {
