@@ -32,7 +32,8 @@ KernelInfo get_kernel(Real<TUReal>, int L, int mode, int io) {
       if (k.fn) return k;
     }
   }
-#define FK(LL, CGG)                                                                              \
+#define FK(LL, CGG) FK2(LL, CGG, CGG)
+#define FK2(LL, CGG, CG_ROWS) /* CG_ROWS: the tile width of the whole-row kernel of this length */ \
   case LL:                                                                                       \
     switch (mode) {                                                                              \
       case MODE_FIRST:                                                                           \
@@ -42,7 +43,7 @@ KernelInfo get_kernel(Real<TUReal>, int L, int mode, int io) {
       case MODE_LAST:                                                                            \
         return io == IO_BLU_OUT ? make_info<T, LL, CGG, MODE_LAST, IO_BLU_OUT>()                 \
                                 : make_info<T, LL, CGG, MODE_LAST>();                            \
-      default: return make_info<T, LL, CGG, MODE_ROWS>();                                        \
+      default: return make_info<T, LL, CG_ROWS, MODE_ROWS>();                                    \
     }
 #define FK_ROWS_ONLY(LL, CGG) \
   case LL: return make_info<T, LL, CGG, MODE_ROWS>();
@@ -50,7 +51,9 @@ KernelInfo get_kernel(Real<TUReal>, int L, int mode, int io) {
     FK_ROWS_ONLY(16, 64)
     FK_ROWS_ONLY(32, 32)
     FK(64, 16)
-    FK(128, 16)
+    // whole rows of 128 points: 64 (f64: 32) transforms per 256-thread workgroup -- f32 64.5 -> 68.0 % of the HBM peak, f64 68.3 -> 70.2 %
+    // against 32 / 16 per 128 threads (profiles/r04_s28_rows_tile_width_64_128_ab.jsonl; N = 64 gains nothing from either width)
+    FK2(128, 16, FOURIER_CG_128_ROWS)
     FK(256, 16)
     FK(512, FOURIER_CG_512)
     FK(1024, FOURIER_CG_1024)
@@ -58,6 +61,7 @@ KernelInfo get_kernel(Real<TUReal>, int L, int mode, int io) {
     default: break;
   }
 #undef FK
+#undef FK2
 #undef FK_ROWS_ONLY
   throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "no kernel for pass length " + std::to_string(L));
 }

@@ -1,6 +1,9 @@
 // tile_shapes.h -- tile widths (column groups of 16 bytes) per pass length, shared by the translation units that
 // instantiate tile kernels; overridable for A/B builds (tools/build_variants.py).
 #pragma once
+#ifndef FOURIER_CG_128_ROWS
+#define FOURIER_CG_128_ROWS 32
+#endif
 #ifndef FOURIER_CG_512
 #define FOURIER_CG_512 8
 #endif
