@@ -74,7 +74,8 @@ template <typename T> class Pow2Engine {
     std::vector<int> lens;
     KernelInfo tl;
     int tl1 = 0, tl2 = 0;
-    if (p3 == 1 && !dev_env("FOURIER_NO_TWOLEVEL") && get_twolevel_kernel(Real<T>{}, k, tl, tl1, tl2)) {
+    // (2^10 as 32x32 only as a transform of its own: the one-launch chirp-z kernels of M = 1024 are built on the whole-row kernel)
+    if (p3 == 1 && !dev_env("FOURIER_NO_TWOLEVEL") && (k > 10 || plain) && get_twolevel_kernel(Real<T>{}, k, tl, tl1, tl2)) {
       // one launch, one HBM round trip: both passes inside a workgroup
       auto pass = std::unique_ptr<Pass>(new Pass());
       pass->mode = MODE_TWOLEVEL;

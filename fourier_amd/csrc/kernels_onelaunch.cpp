@@ -20,12 +20,15 @@ template <typename T, int L1, int L2> static KernelInfo make_twolevel_info() {
   k.smem = std::max({CA::EXCH_BYTES, CB::EXCH_BYTES, TwolevelTr<T, L1, L2>::BYTES, TwolevelTr<T, L2, L1>::BYTES});
   return k;
 }
-// single-launch plans: 2^11 = 64x32 (72 % of the HBM peak vs 57 % for the row kernel), 2^12 = 64x64,
+// single-launch plans: 2^10 = 32x32 (f64), 2^11 = 64x32 (72 % of the HBM peak vs 57 % for the row kernel), 2^12 = 64x64,
 // 2^13 = 128x64, 2^14 = 128x128, 2^15 = 256x128 (f32 only: the transform must fit one workgroup's
 // registers, at most 1024 threads x 16 points x VEC)
 bool get_twolevel_kernel(Real<TUReal>, int k, KernelInfo& info, int& l1, int& l2) {
   typedef TUReal T;
   switch (k) {
+    case 10:  // f64 only: 75.2 against 72.4 % of the HBM peak for the whole-row kernel (f32: 60 against 74 %; profiles/r04_s29_*)
+      if constexpr (sizeof(T) == 8) { info = make_twolevel_info<T, 32, 32>(); l1 = 32; l2 = 32; return true; }
+      return false;
     case 11: info = make_twolevel_info<T, 64, 32>(); l1 = 64; l2 = 32; return true;
     case 12: info = make_twolevel_info<T, 64, 64>(); l1 = 64; l2 = 64; return true;
     case 13: info = make_twolevel_info<T, 128, 64>(); l1 = 128; l2 = 64; return true;
