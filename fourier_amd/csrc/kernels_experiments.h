@@ -206,6 +206,9 @@ __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_rea
 #define FOURIER_PF_DMA_ROWS 8
 #endif
 // A/B knobs of the prefetching last pass (tools/build_variants.py)
+#ifndef FOURIER_PF_SIMPLE_LOOP
+#define FOURIER_PF_SIMPLE_LOOP 0  // 1: persistent workgroups over the plain pass_tile, no prefetch (A/B)
+#endif
 #ifndef FOURIER_PF_WAIT_ALL
 #define FOURIER_PF_WAIT_ALL 0     // 1: s_waitcnt vmcnt(0) -- also the previous tile's stores -- before the prefetched tile is used
 #endif
@@ -254,6 +257,15 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
       for (int i = tid; i < C::R3 * 16; i += NT) l2[i] = tw2[i];
     tw1 = l1; tw2 = l2;  // visible after the loop's first barrier
   }
+#if FOURIER_PF_SIMPLE_LOOP
+  // the plain last pass, tile after tile in persistent workgroups, NO prefetch: what a workgroup that is not torn down and
+  // re-dispatched between tiles (stores of tile t draining under the loads of tile t + 1) is worth by itself
+  for (uint32_t vb = blockIdx.x; vb < (uint32_t)a.total_cols; vb += gridDim.x) {
+    pass_tile<T, L, CG, MODE_LAST, IO, PassPolicy<L, MODE_LAST, CG>::LD, PassPolicy<L, MODE_LAST, CG>::ST>(a, vb, (uint32_t)a.total_cols, smem, tid);
+    __syncthreads();
+  }
+  return;
+#endif
   const cpx<T>* __restrict__ in = (const cpx<T>*)a.in;
   cpx<T>* __restrict__ out = (cpx<T>*)a.out;
   const uint32_t total = (uint32_t)a.total_cols, tiles = (uint32_t)a.tiles;  // total_cols: tiles of the whole launch
