@@ -259,7 +259,9 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
   }
 #if FOURIER_PF_SIMPLE_LOOP
   // the plain last pass, tile after tile in persistent workgroups, NO prefetch: what a workgroup that is not torn down and
-  // re-dispatched between tiles (stores of tile t draining under the loads of tile t + 1) is worth by itself
+  // re-dispatched between tiles is worth by itself.  Measured (profiles/r04_s33_*, r04_s34_*): 30 % SLOWER than one workgroup per
+  // tile -- half of that is the static tile assignment (tiles drawn from per-XCD atomic counters instead: 12 % slower), the rest
+  // the in-order vmcnt of gfx9: the first use of tile t + 1's loads also waits for the acknowledgement of tile t's stores
   for (uint32_t vb = blockIdx.x; vb < (uint32_t)a.total_cols; vb += gridDim.x) {
     pass_tile<T, L, CG, MODE_LAST, IO, PassPolicy<L, MODE_LAST, CG>::LD, PassPolicy<L, MODE_LAST, CG>::ST>(a, vb, (uint32_t)a.total_cols, smem, tid);
     __syncthreads();
