@@ -128,6 +128,76 @@ template <typename T, int R> __device__ __forceinline__ void ref_butterfly(cpx<T
   else dft_prime<T, R>(x, fwd);
 }
 
+// global memory <-> LDS in 16-byte units (two f32 points / one f64 point per lane and instruction; the rows of an odd-length f32
+// batch are only 8-byte aligned, which global_load/store_dwordx4 tolerate).  MAXU: compile-time bound of the units of a workgroup.
+// Up to eight units per thread are LOADED before the first of them is written: as a plain loop (`for u: lds[u] = g[u]`) hipcc
+// emits load, s_waitcnt vmcnt(0), ds_write per iteration -- one exposed HBM latency per 16 bytes of a thread's share (three per
+// workgroup at 768 points; FOURIER_MIX_COPY_BATCHED=0 restores that form for A/B).
+#ifndef FOURIER_MIX_COPY_BATCHED
+#define FOURIER_MIX_COPY_BATCHED 1
+#endif
+template <typename T, uint32_t NT, uint32_t MAXU>
+__device__ __forceinline__ void copy_in_units(cpx<T>* lds, const cpx<T>* g, uint32_t units) {
+  constexpr uint32_t VEC = 16 / (uint32_t)sizeof(cpx<T>);
+  if constexpr (FOURIER_MIX_COPY_BATCHED == 0) {
+    for (uint32_t u = threadIdx.x; u < units; u += NT) *(Unit16<T>*)(lds + u * VEC) = load_unit_a8<T>(g + u * VEC);
+  } else {
+    constexpr uint32_t IT = (MAXU + NT - 1) / NT, CH = 8;
+#pragma unroll
+    for (uint32_t c0 = 0; c0 < IT; c0 += CH) {
+      Unit16<T> w[CH];
+#pragma unroll
+      for (uint32_t q = 0; q < CH; ++q) {
+        const uint32_t u = threadIdx.x + (c0 + q) * NT;
+        if (c0 + q < IT && u < units) w[q] = load_unit_a8<T>(g + u * VEC);
+      }
+#pragma unroll
+      for (uint32_t q = 0; q < CH; ++q) {
+        const uint32_t u = threadIdx.x + (c0 + q) * NT;
+        if (c0 + q < IT && u < units) *(Unit16<T>*)(lds + u * VEC) = w[q];
+      }
+    }
+  }
+}
+// ... and back, scaled (mod.rs:387-393: the unscaled codes skip the multiply, x * 1 is exact)
+template <typename T, uint32_t NT, uint32_t MAXU>
+__device__ __forceinline__ void copy_out_units(cpx<T>* g, const cpx<T>* lds, uint32_t units, bool scaled, T scale) {
+  constexpr uint32_t VEC = 16 / (uint32_t)sizeof(cpx<T>);
+  constexpr uint32_t IT = FOURIER_MIX_COPY_BATCHED ? (MAXU + NT - 1) / NT : 0, CH = 8;
+  if constexpr (FOURIER_MIX_COPY_BATCHED == 0) {
+    for (uint32_t u = threadIdx.x; u < units; u += NT) {
+      Unit16<T> v = *(const Unit16<T>*)(lds + u * VEC);
+      if (scaled) {
+#pragma unroll
+        for (uint32_t c = 0; c < 2 * VEC; ++c) v.a[c] = v.a[c] * scale;
+      }
+      store_unit_a8<T>(g + u * VEC, v);
+    }
+  } else {
+#pragma unroll
+    for (uint32_t c0 = 0; c0 < IT; c0 += CH) {
+      Unit16<T> w[CH];
+#pragma unroll
+      for (uint32_t q = 0; q < CH; ++q) {
+        const uint32_t u = threadIdx.x + (c0 + q) * NT;
+        if (c0 + q < IT && u < units) w[q] = *(const Unit16<T>*)(lds + u * VEC);
+      }
+#pragma unroll
+      for (uint32_t q = 0; q < CH; ++q) {
+        const uint32_t u = threadIdx.x + (c0 + q) * NT;
+        if (c0 + q < IT && u < units) {
+          Unit16<T> v = w[q];
+          if (scaled) {
+#pragma unroll
+            for (uint32_t c = 0; c < 2 * VEC; ++c) v.a[c] = v.a[c] * scale;
+          }
+          store_unit_a8<T>(g + u * VEC, v);
+        }
+      }
+    }
+  }
+}
+
 // One pass of the runtime-parameterised kernel, IN PLACE on one LDS buffer: a thread computes up to ROUNDS butterflies,
 // keeps their outputs in registers across a barrier and writes them back to the buffer it read from (the per-length
 // kernels below do the same with every index a constant).  PPT = points per thread the instantiation is sized for.
@@ -216,10 +286,8 @@ __global__ void __launch_bounds__(NT, FOURIER_MIX_RT_WAVES(T, MAXP, PPT)) mixed_
   // global <-> LDS in 16-byte units (see mixed_radix_kernel_ct)
   constexpr uint32_t VEC = 16 / (2 * (uint32_t)sizeof(T));
   const uint32_t units = total / VEC;
-  if constexpr (VEC == 1) {
-    for (uint32_t idx = threadIdx.x; idx < total; idx += NT) buf[idx] = in[idx];
-  } else {
-    for (uint32_t u = threadIdx.x; u < units; u += NT) *(Unit16<T>*)(buf + u * VEC) = load_unit_a8<T>(in + u * VEC);
+  copy_in_units<T, NT, (uint32_t)NT * PPT / VEC>(buf, in, units);
+  if constexpr (VEC > 1) {
     if ((total % VEC) && threadIdx.x == 0) buf[total - 1] = in[total - 1];
   }
   __syncthreads();
@@ -247,21 +315,8 @@ __global__ void __launch_bounds__(NT, FOURIER_MIX_RT_WAVES(T, MAXP, PPT)) mixed_
     stride *= R;
   }
   const T scale = a.scaled ? (T)a.scale : (T)1;  // mod.rs:387-393 (the unscaled codes skip the multiply: x * 1 is exact)
-  if constexpr (VEC == 1) {
-    for (uint32_t idx = threadIdx.x; idx < total; idx += NT) {
-      cpx<T> y = buf[idx];
-      if (a.scaled) y = {y.re * scale, y.im * scale};
-      out[idx] = y;
-    }
-  } else {
-    for (uint32_t u = threadIdx.x; u < units; u += NT) {
-      Unit16<T> v = *(const Unit16<T>*)(buf + u * VEC);
-      if (a.scaled) {
-#pragma unroll
-        for (uint32_t c = 0; c < 2 * VEC; ++c) v.a[c] = v.a[c] * scale;
-      }
-      store_unit_a8<T>(out + u * VEC, v);
-    }
+  copy_out_units<T, NT, (uint32_t)NT * PPT / VEC>(out, buf, units, a.scaled != 0, scale);
+  if constexpr (VEC > 1) {
     if ((total % VEC) && threadIdx.x == 0) {
       cpx<T> y = buf[total - 1];
       if (a.scaled) y = {y.re * scale, y.im * scale};
@@ -503,11 +558,11 @@ __global__ void __launch_bounds__(mix_threads<T>(N)) mixed_radix_kernel_ct(MixAr
   constexpr bool GIO = mix_gio<T>(N);
   const uint32_t units = total / VEC;
   if constexpr (GIO) {
-  } else if constexpr (VEC == 1) {
-    for (uint32_t idx = threadIdx.x; idx < total; idx += NT) buf0[idx] = in[idx];
   } else {
-    for (uint32_t u = threadIdx.x; u < units; u += NT) *(Unit16<T>*)(buf0 + u * VEC) = load_unit_a8<T>(in + u * VEC);
-    if ((total % VEC) && threadIdx.x == 0) buf0[total - 1] = in[total - 1];
+    copy_in_units<T, NT, (GROUP * N + VEC - 1) / VEC>(buf0, in, units);
+    if constexpr (VEC > 1) {
+      if ((total % VEC) && threadIdx.x == 0) buf0[total - 1] = in[total - 1];
+    }
   }
   // twiddle tables shared by the GROUP transforms of this workgroup: staged in LDS behind the data (mix_tw_lds)
   constexpr bool TWL = mix_tw_lds<T>(N);
@@ -526,25 +581,14 @@ __global__ void __launch_bounds__(mix_threads<T>(N)) mixed_radix_kernel_ct(MixAr
   const cpx<T>* res = Passes::run(buf0, buf1, tw, nb, fwd, w3, w8, in, out, scale, a.scaled != 0);
   if constexpr (GIO) {
     (void)res; (void)units;  // the last pass has written the output
-  } else if constexpr (VEC == 1) {
-    for (uint32_t idx = threadIdx.x; idx < total; idx += NT) {
-      cpx<T> y = res[idx];
-      if (a.scaled) y = {y.re * scale, y.im * scale};
-      out[idx] = y;
-    }
   } else {
-    for (uint32_t u = threadIdx.x; u < units; u += NT) {
-      Unit16<T> v = *(const Unit16<T>*)(res + u * VEC);
-      if (a.scaled) {
-#pragma unroll
-        for (uint32_t c = 0; c < 2 * VEC; ++c) v.a[c] = v.a[c] * scale;
+    copy_out_units<T, NT, (GROUP * N + VEC - 1) / VEC>(out, res, units, a.scaled != 0, scale);
+    if constexpr (VEC > 1) {
+      if ((total % VEC) && threadIdx.x == 0) {
+        cpx<T> y = res[total - 1];
+        if (a.scaled) y = {y.re * scale, y.im * scale};
+        out[total - 1] = y;
       }
-      store_unit_a8<T>(out + u * VEC, v);
-    }
-    if ((total % VEC) && threadIdx.x == 0) {
-      cpx<T> y = res[total - 1];
-      if (a.scaled) y = {y.re * scale, y.im * scale};
-      out[total - 1] = y;
     }
   }
 }

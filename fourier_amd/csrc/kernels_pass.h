@@ -361,6 +361,9 @@ template <typename T> __device__ __forceinline__ cpx<T> root_n(const PassArgs& a
   return cmul(lo[e & ((1u << a.tn_bits) - 1u)], hi[e >> a.tn_bits]);
 }
 
+#ifndef FOURIER_ROWS_STAGED_LOADS_FIRST
+#define FOURIER_ROWS_STAGED_LOADS_FIRST 1
+#endif
 #ifndef FOURIER_TABS_AFTER_LOADS
 #define FOURIER_TABS_AFTER_LOADS 1
 #endif
@@ -458,13 +461,38 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
     stage_valid = (uint32_t)(left < (uint64_t)COLS ? left : (uint64_t)COLS) * (uint32_t)L;
     cpx<T>* stage = (cpx<T>*)smem;
     const cpx<T>* src = in + g0 * L;
+    // every unit of BOTH halves is loaded before the first LDS write (FOURIER_ROWS_STAGED_LOADS_FIRST): one memory latency per tile
+    // instead of one per half (the registers are free: x is filled from LDS afterwards)
+    constexpr int SITER = (HALF * L / VEC + C::NT - 1) / C::NT;
+    Unit16<T> sw[FOURIER_ROWS_STAGED_LOADS_FIRST ? 2 : 1][SITER];
+    if constexpr (FOURIER_ROWS_STAGED_LOADS_FIRST != 0) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int it = 0; it < SITER; ++it) {
+          const int u = tid + it * C::NT;
+          const uint32_t eh = (uint32_t)u * VEC, e = (uint32_t)(h * HALF * L) + eh;
+          Unit16<T> w{};
+          if (u < HALF * L / VEC && e < stage_valid) w = load_unit_a8<T>(src + e);
+          sw[h][it] = w;
+        }
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      for (int u = tid; u < HALF * L / VEC; u += C::NT) {
-        const uint32_t eh = (uint32_t)u * VEC, e = (uint32_t)(h * HALF * L) + eh;
-        Unit16<T> w{};
-        if (e < stage_valid) w = load_unit_a8<T>(src + e);
-        *(Unit16<T>*)(stage + (eh / L) * LP + (eh % L)) = w;
+      if constexpr (FOURIER_ROWS_STAGED_LOADS_FIRST != 0) {
+#pragma unroll
+        for (int it = 0; it < SITER; ++it) {
+          const int u = tid + it * C::NT;
+          const uint32_t eh = (uint32_t)u * VEC;
+          if (u < HALF * L / VEC) *(Unit16<T>*)(stage + (eh / L) * LP + (eh % L)) = sw[h][it];
+        }
+      } else {
+        for (int u = tid; u < HALF * L / VEC; u += C::NT) {
+          const uint32_t eh = (uint32_t)u * VEC, e = (uint32_t)(h * HALF * L) + eh;
+          Unit16<T> w{};
+          if (e < stage_valid) w = load_unit_a8<T>(src + e);
+          *(Unit16<T>*)(stage + (eh / L) * LP + (eh % L)) = w;
+        }
       }
       __syncthreads();
 #pragma unroll
@@ -622,9 +650,26 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
         }
       }
       __syncthreads();
-      for (int u = tid; u < HALF * L / VEC; u += C::NT) {
-        const uint32_t eh = (uint32_t)u * VEC, e = (uint32_t)(h * HALF * L) + eh;
-        if (e < stage_valid) store_unit_a8<T>(dst + e, *(const Unit16<T>*)(stage + (eh / L) * LP + (eh % L)));
+      if constexpr (FOURIER_ROWS_STAGED_LOADS_FIRST != 0) {  // (the LDS reads of a half ahead of its first store, as on the way in)
+        constexpr int SITER = (HALF * L / VEC + C::NT - 1) / C::NT;
+        Unit16<T> sw[SITER];
+#pragma unroll
+        for (int it = 0; it < SITER; ++it) {
+          const int u = tid + it * C::NT;
+          const uint32_t eh = (uint32_t)u * VEC;
+          if (u < HALF * L / VEC) sw[it] = *(const Unit16<T>*)(stage + (eh / L) * LP + (eh % L));
+        }
+#pragma unroll
+        for (int it = 0; it < SITER; ++it) {
+          const int u = tid + it * C::NT;
+          const uint32_t eh = (uint32_t)u * VEC, e = (uint32_t)(h * HALF * L) + eh;
+          if (u < HALF * L / VEC && e < stage_valid) store_unit_a8<T>(dst + e, sw[it]);
+        }
+      } else {
+        for (int u = tid; u < HALF * L / VEC; u += C::NT) {
+          const uint32_t eh = (uint32_t)u * VEC, e = (uint32_t)(h * HALF * L) + eh;
+          if (e < stage_valid) store_unit_a8<T>(dst + e, *(const Unit16<T>*)(stage + (eh / L) * LP + (eh % L)));
+        }
       }
       __syncthreads();
     }

@@ -70,6 +70,8 @@ VARIANTS = {
     "mix_loads_first_all": ["-DFOURIER_MIX_LOADS_FIRST=2"],
     "tabs_before_loads": ["-DFOURIER_TABS_AFTER_LOADS=0"],
     "rows128_cg16": ["-DFOURIER_CG_128_ROWS=16"],
+    "rows_staged_per_half": ["-DFOURIER_ROWS_STAGED_LOADS_FIRST=0"],
+    "mix_copy_loop": ["-DFOURIER_MIX_COPY_BATCHED=0"],
     "mix_slp": ["-fslp-vectorize", "-DFOURIER_MIX_SLP_BUILD=1"],  # packed f32 VALU ops in the LDS mixed-radix / mixed-tile kernels only
     "pf_nobar": ["-DFOURIER_PF_BARRIER_AFTER_WAIT=0"],
     "pf_vm0": ["-DFOURIER_PF_WAIT_ALL=1"],
