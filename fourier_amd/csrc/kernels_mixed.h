@@ -136,13 +136,13 @@ template <typename T, int R> __device__ __forceinline__ void ref_butterfly(cpx<T
 #ifndef FOURIER_MIX_COPY_BATCHED
 #define FOURIER_MIX_COPY_BATCHED 1
 #endif
-template <typename T, uint32_t NT, uint32_t MAXU>
+template <typename T, uint32_t NT, uint32_t MAXU, uint32_t CH = 8>  // CH: units of a thread in flight together
 __device__ __forceinline__ void copy_in_units(cpx<T>* lds, const cpx<T>* g, uint32_t units) {
   constexpr uint32_t VEC = 16 / (uint32_t)sizeof(cpx<T>);
   if constexpr (FOURIER_MIX_COPY_BATCHED == 0) {
     for (uint32_t u = threadIdx.x; u < units; u += NT) *(Unit16<T>*)(lds + u * VEC) = load_unit_a8<T>(g + u * VEC);
   } else {
-    constexpr uint32_t IT = (MAXU + NT - 1) / NT, CH = 8;
+    constexpr uint32_t IT = (MAXU + NT - 1) / NT;
 #pragma unroll
     for (uint32_t c0 = 0; c0 < IT; c0 += CH) {
       Unit16<T> w[CH];
@@ -160,12 +160,16 @@ __device__ __forceinline__ void copy_in_units(cpx<T>* lds, const cpx<T>* g, uint
   }
 }
 // ... and back, scaled (mod.rs:387-393: the unscaled codes skip the multiply, x * 1 is exact)
-template <typename T, uint32_t NT, uint32_t MAXU>
+template <typename T, uint32_t NT, uint32_t MAXU, uint32_t CH = 8>
 __device__ __forceinline__ void copy_out_units(cpx<T>* g, const cpx<T>* lds, uint32_t units, bool scaled, T scale) {
   constexpr uint32_t VEC = 16 / (uint32_t)sizeof(cpx<T>);
-  constexpr uint32_t IT = FOURIER_MIX_COPY_BATCHED ? (MAXU + NT - 1) / NT : 0, CH = 8;
+  constexpr uint32_t IT = FOURIER_MIX_COPY_BATCHED ? (MAXU + NT - 1) / NT : 0;
+  // (the thread index behind a launder: the addresses below are then computed here, not shared with copy_in_units and carried -- or
+  // spilled, under the register caps of the runtime-parameterised kernels -- across every pass)
+  uint32_t tix = threadIdx.x;
+  FOURIER_LAUNDER(tix);
   if constexpr (FOURIER_MIX_COPY_BATCHED == 0) {
-    for (uint32_t u = threadIdx.x; u < units; u += NT) {
+    for (uint32_t u = tix; u < units; u += NT) {
       Unit16<T> v = *(const Unit16<T>*)(lds + u * VEC);
       if (scaled) {
 #pragma unroll
@@ -179,12 +183,12 @@ __device__ __forceinline__ void copy_out_units(cpx<T>* g, const cpx<T>* lds, uin
       Unit16<T> w[CH];
 #pragma unroll
       for (uint32_t q = 0; q < CH; ++q) {
-        const uint32_t u = threadIdx.x + (c0 + q) * NT;
+        const uint32_t u = tix + (c0 + q) * NT;
         if (c0 + q < IT && u < units) w[q] = *(const Unit16<T>*)(lds + u * VEC);
       }
 #pragma unroll
       for (uint32_t q = 0; q < CH; ++q) {
-        const uint32_t u = threadIdx.x + (c0 + q) * NT;
+        const uint32_t u = tix + (c0 + q) * NT;
         if (c0 + q < IT && u < units) {
           Unit16<T> v = w[q];
           if (scaled) {
@@ -286,7 +290,7 @@ __global__ void __launch_bounds__(NT, FOURIER_MIX_RT_WAVES(T, MAXP, PPT)) mixed_
   // global <-> LDS in 16-byte units (see mixed_radix_kernel_ct)
   constexpr uint32_t VEC = 16 / (2 * (uint32_t)sizeof(T));
   const uint32_t units = total / VEC;
-  copy_in_units<T, NT, (uint32_t)NT * PPT / VEC>(buf, in, units);
+  copy_in_units<T, NT, (uint32_t)NT * PPT / VEC, 4>(buf, in, units);  // (four in flight: the register caps of these kernels)
   if constexpr (VEC > 1) {
     if ((total % VEC) && threadIdx.x == 0) buf[total - 1] = in[total - 1];
   }
@@ -315,7 +319,7 @@ __global__ void __launch_bounds__(NT, FOURIER_MIX_RT_WAVES(T, MAXP, PPT)) mixed_
     stride *= R;
   }
   const T scale = a.scaled ? (T)a.scale : (T)1;  // mod.rs:387-393 (the unscaled codes skip the multiply: x * 1 is exact)
-  copy_out_units<T, NT, (uint32_t)NT * PPT / VEC>(out, buf, units, a.scaled != 0, scale);
+  copy_out_units<T, NT, (uint32_t)NT * PPT / VEC, 4>(out, buf, units, a.scaled != 0, scale);
   if constexpr (VEC > 1) {
     if ((total % VEC) && threadIdx.x == 0) {
       cpx<T> y = buf[total - 1];
