@@ -777,17 +777,20 @@ def test_prefetching_last_pass_is_bit_identical_to_the_plain_last_pass(fa, oracl
     tile's stores.  Same in-tile arithmetic: under the emulator (one compiler, no FMA contraction) the same bits as fft_pass_kernel, for the plain last pass (L = 1024 and 2048, f32 and f64, with
     and without the stage twiddles in LDS) and for the chirp-out pass of a Bluestein plan; ragged tile counts per workgroup
     (the emulated device keeps 6 workgroups resident)."""
-    for n, dtype, batch in ((1 << 21, np.complex64, 2), (1 << 22, np.complex64, 1), (1 << 21, np.complex128, 1), (700001, np.complex64, 1)):
+    # (the kernel is a measured-slower experiment, kept for A/B: one case per form -- L = 1024 f32 with a ragged tile count and both
+    # directions, L = 1024 f64 behind a 2048-point first pass, the chirp-out form; L = 2048 runs on the GPU, tests/test_gpu_parity.py)
+    for n, dtype, batch, codes in ((1 << 20, np.complex64, 3, (0, 4)), (1 << 21, np.complex128, 1, (0,)), (300007, np.complex64, 1, (0,))):
         x = np.stack([hash_normal(300 + b, n) for b in range(batch)]).astype(dtype)
         on, off = make(fa, n, dtype), make(fa, n, dtype)
         on.set_option("last_pass_prefetch", 1)
         off.set_option("last_pass_prefetch", 0)
-        for code in (0, 4):
+        for code in codes:
             a, b = run_batch(on, x, code), run_batch(off, x, code)
             assert np.array_equal(a, b), (n, dtype, code)
-        assert np.array_equal(run_batch(on, x, 0, inplace=True), a if code == 0 else run_batch(on, x, 0)), (n, dtype)
+        first = run_batch(on, x, 0)
+        assert np.array_equal(run_batch(on, x, 0, inplace=True), first), (n, dtype)
         tol = (1e-6 if n & (n - 1) == 0 else 2e-6) if dtype == np.complex64 else (5e-14 if n & (n - 1) == 0 else 1e-9)
-        assert rel_l2(run_batch(on, x, 0), oracle.transform_batch(x, 0)) <= tol, (n, dtype)
+        assert rel_l2(first, oracle.transform_batch(x, 0)) <= tol, (n, dtype)
 
 
 def test_plan_option_specialise_is_refused_without_hiprtc_and_leaves_the_plan_alone(fa, oracle):
