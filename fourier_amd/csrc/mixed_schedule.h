@@ -124,6 +124,9 @@ template <typename T> constexpr bool mix_tw_lds(uint32_t n) { return FOURIER_MIX
 #ifndef FOURIER_MIX_GIO_MIN_BYTES
 #define FOURIER_MIX_GIO_MIN_BYTES 10240u
 #endif
+#ifndef FOURIER_MIX_GIO_MIN_BYTES_F32
+#define FOURIER_MIX_GIO_MIN_BYTES_F32 98304u
+#endif
 #ifndef FOURIER_MIX_GIO_ALL
 #define FOURIER_MIX_GIO_ALL 0  // 1: every length that satisfies the run-length condition (A/B)
 #endif
@@ -140,7 +143,12 @@ template <typename T> constexpr bool mix_gio(uint32_t n) {
     stride *= pts;
     cur /= pts;
   }
-  const bool measured_faster = mix_extended(n) ? (n == 3125u || n == 15625u) : n * 2u * (uint32_t)sizeof(T) >= FOURIER_MIX_GIO_MIN_BYTES;
+  // (re-measured once the copies into and out of LDS were batched, profiles/r04_s48_gio_rule_after_batched_copies_ab.jsonl: in f64 the
+  // direct form still wins from 10 KiB on -- 729 +9 %, 3072 +12 %, 9216 +18 % --, in f32 only for the transforms that leave a CU no
+  // second workgroup -- 13824 +11 %, 18432 +8 %, 15625 +4 % -- while 1536 ... 9216, 3125 and 19683 are 3 - 7 % faster through the copy)
+  const uint32_t bytes = n * 2u * (uint32_t)sizeof(T);
+  const bool measured_faster = mix_extended(n) ? n == 15625u
+                               : (sizeof(T) == 8 ? bytes >= FOURIER_MIX_GIO_MIN_BYTES : (bytes >= FOURIER_MIX_GIO_MIN_BYTES_F32 && n != 19683u));
   return (measured_faster || FOURIER_MIX_GIO_ALL != 0) && first_run >= FOURIER_MIX_GIO_MIN_RUN && last_run >= FOURIER_MIX_GIO_MIN_RUN &&
          2u * mix_group<T>(n) * n * 2u * sizeof(T) > FOURIER_MIX_INPLACE_BYTES;
 }
@@ -186,7 +194,7 @@ constexpr uint32_t mix_sw_span(uint32_t layout) { return layout == 0 ? 1u : 1u <
 #endif
 template <typename T> constexpr bool mix_loads_first(uint32_t n) {
   if (FOURIER_MIX_LOADS_FIRST != 1) return FOURIER_MIX_LOADS_FIRST != 0;
-  if (mix_extended(n)) return n == 3125u && sizeof(T) == 4;
+  if (mix_extended(n)) return false;  // (5^5 f32 gained 3 % while its first pass read global memory; through the batched copy: -1 %, r04_s49)
   return n * 2u * (uint32_t)sizeof(T) >= 16384u && (sizeof(T) == 8 || n <= 16384u);
 }
 template <typename T> constexpr bool mix_inplace(uint32_t n) {
