@@ -74,6 +74,7 @@ def translation_units():
         tus.append((f"kernels_misc_{tag}", "kernels_misc.cpp", d, "misc"))
         tus.append((f"kernels_tiled_{tag}", "kernels_tiled.cpp", d, "mixed"))
         tus.append((f"kernels_experiments_{tag}", "kernels_experiments.cpp", d, "experiments"))
+        tus.append((f"kernels_skeleton_{tag}", "kernels_skeleton.cpp", d, "experiments"))
     return tus
 
 
@@ -139,7 +140,7 @@ def link(objs, out, experiments, soname=True):
     g = group_of()
     skip = PRODUCT_ONLY if experiments else EXPERIMENTS_ONLY
     members = [p for n, p in objs.items() if g[n] not in skip]
-    subprocess.check_call([HIPCC] + LINK_FLAGS + ([SONAME] if soname else []) + members + ["-o", out])
+    subprocess.check_call([HIPCC] + LINK_FLAGS + ([SONAME] if soname else []) + members + ["-ldl", "-o", out])  # rtc.cpp: dlopen (libhiprtc, lazily)
     return members
 
 

@@ -229,7 +229,10 @@ template <typename T> struct Real {};
   bool get_fused_kernel(Real<T>, int k, FusedInfo& info);                                                              \
   KernelInfo get_split_kernel(Real<T>, int L, int io);                                                                 \
   /* persistent LAST pass that prefetches its next tile (fft_last_prefetch_kernel); fn == nullptr where not built */     \
-  KernelInfo get_prefetch_kernel(Real<T>, int L, int io);
+  KernelInfo get_prefetch_kernel(Real<T>, int L, int io);                                                               \
+  /* kernels_skeleton.cpp (experiments library): the tile passes of length 1024 / 2048 WITHOUT butterflies, twiddles and */ \
+  /* LDS exchanges -- the load-tile / store-tile skeleton bench.py times as the streaming ceiling; product: fn == nullptr */ \
+  KernelInfo get_skeleton_kernel(Real<T>, int L, int mode);
 FOURIER_DECLARE_REGISTRY(float)
 FOURIER_DECLARE_REGISTRY(double)
 #undef FOURIER_DECLARE_REGISTRY

@@ -40,6 +40,7 @@ template <typename T> class Pow2Engine {
     KernelInfo k;
     KernelInfo k_blu;  // IO_BLU_IN variant of a FIRST pass / IO_BLU_OUT variant of a LAST pass (lazy)
     bool has_blu = false;
+    KernelInfo k_skel;          // the pass without arithmetic and exchanges (experiments library: bench.py's streaming ceiling)
     KernelInfo k_pf, k_pf_blu;  // LAST pass: the persistent prefetching form (fft_last_prefetch_kernel), plain / chirp-out
     unsigned pf_grid = 0, pf_blu_grid = 0;  // resident workgroups of those kernels on this device
     StageTables<T>* st2 = nullptr;  // MODE_TWOLEVEL: stage tables of the second pass length
@@ -162,6 +163,11 @@ template <typename T> class Pow2Engine {
         else pass->k_pf = KernelInfo();
       }
       set_smem_attribute(pass->k);
+      if (pass->mode == MODE_FIRST || pass->mode == MODE_LAST) {
+        pass->k_skel = get_skeleton_kernel(Real<T>{}, L, pass->mode);
+        if (pass->k_skel.fn && (pass->k_skel.COLS != pass->k.COLS || pass->k.split)) pass->k_skel = KernelInfo();
+        if (pass->k_skel.fn) set_smem_attribute(pass->k_skel);
+      }
       passes_.push_back(std::move(pass));
       s *= (uint64_t)L;
       size /= (uint64_t)L;
@@ -511,11 +517,18 @@ template <typename T> class Pow2Engine {
         PROF_END(prof);
         return;
       }
+      const KernelInfo& run = (skeleton_ && !blu_here && ps.k_skel.fn) ? ps.k_skel : kk;
       PROF_BEGIN(prof, slot);
-      FOURIER_LAUNCH(kk.fn, grid, kk.NT, kk.smem, stream, a);
+      FOURIER_LAUNCH(run.fn, grid, run.NT, run.smem, stream, a);
       PROF_END(prof);
     }
   }
+  // "skeleton" (experiments library): every pass that has one runs as its load / store skeleton -- timing only, wrong results
+  bool has_skeleton() const {
+    for (const auto& p : passes_) if (!p->k_skel.fn) return false;
+    return !passes_.empty();
+  }
+  void set_skeleton(bool on) { skeleton_ = on; }
   // "last_pass_prefetch" (experiments library): 1 = wherever the kernel exists; off by default -- measured slower
   void set_prefetch_last(bool on) { prefetch_last_ = on; }
   bool has_prefetch_last() const { return !passes_.empty() && passes_.back()->k_pf.fn != nullptr; }
@@ -577,6 +590,7 @@ template <typename T> class Pow2Engine {
   FusedInfo fused_;
   bool fused_on_ = false;
   bool prefetch_last_ = false;
+  bool skeleton_ = false;
   unsigned fused_grid_ = 0, fused_depth_ = 2;
   mutable DevBuf fused_window_, fused_ctrl_;
   mutable PinnedBuf fused_flag_;  // ctrl[1] (abort flag) of the last fused launch, read back before the call returns

@@ -15,5 +15,8 @@ KernelInfo get_split_kernel(Real<double>, int, int) { return KernelInfo(); }
 // the persistent prefetching last pass: 15-30 % slower than fft_pass_kernel (kernels_experiments.h has the measurements)
 KernelInfo get_prefetch_kernel(Real<float>, int, int) { return KernelInfo(); }
 KernelInfo get_prefetch_kernel(Real<double>, int, int) { return KernelInfo(); }
+// measurement tooling (the passes' load / store skeleton, bench.py's streaming ceiling)
+KernelInfo get_skeleton_kernel(Real<float>, int, int) { return KernelInfo(); }
+KernelInfo get_skeleton_kernel(Real<double>, int, int) { return KernelInfo(); }
 
 }  // namespace fourier_hip

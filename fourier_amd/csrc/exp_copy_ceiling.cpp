@@ -31,27 +31,31 @@ __global__ void __launch_bounds__(256) copy_slab_kernel(const void* __restrict__
 // 512-thread workgroup copies one column tile -- sixteen 128-byte row segments per thread at a row stride of 8 KiB, all
 // sixteen loads in flight, then the sixteen stores to the same positions of dst (the load and store side of the LAST pass of
 // the 1024 x 1024 plan with its arithmetic and LDS exchanges removed); XCD-aware tile order as in xcd_remap mode 0.
-template <bool NT>
+// ROWU = 16-byte units per row: 512 (8 KiB rows, the f32 1024 x 1024 plan) or 1024 (16 KiB rows, 16 MiB "transforms": the f64 plan,
+// whose pass kernels stream faster than the f32 ones -- VERDICT round 4, item 1a)
+template <bool NT, int ROWU>
 __global__ void __launch_bounds__(512) copy_tile_kernel(const void* __restrict__ src, void* __restrict__ dst) {
   uint64_t b = blockIdx.x;
   const uint64_t per_xcd = gridDim.x / 8;
   if (per_xcd * 8 == gridDim.x) b = (b % 8) * per_xcd + b / 8;
-  const uint64_t transform = b / 64, tile = b % 64;  // 64 tiles of 8 units (128 bytes) per 512-unit row
-  const uint64_t base = transform * (1024 * 512) + tile * 8 + (uint64_t)(threadIdx.x / 8) * 512 + threadIdx.x % 8;
+  constexpr uint64_t TILES = ROWU / 8;  // tiles of 8 units (128 bytes) per row
+  const uint64_t transform = b / TILES, tile = b % TILES;
+  const uint64_t base = transform * (1024 * (uint64_t)ROWU) + tile * 8 + (uint64_t)(threadIdx.x / 8) * ROWU + threadIdx.x % 8;
   const Unit16<float>* s = (const Unit16<float>*)src + base;
   Unit16<float>* d = (Unit16<float>*)dst + base;
   Unit16<float> v[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) v[r] = load_unit<float, NT>(s + (uint64_t)r * 64 * 512);
+  for (int r = 0; r < 16; ++r) v[r] = load_unit<float, NT>(s + (uint64_t)r * 64 * ROWU);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) store_unit<float, NT>(d + (uint64_t)r * 64 * 512, v[r]);
+  for (int r = 0; r < 16; ++r) store_unit<float, NT>(d + (uint64_t)r * 64 * ROWU, v[r]);
 }
 
 }  // namespace fourier_hip
 
 // Copies `bytes` (a multiple of bytes_per_block, itself a multiple of 32 KiB) from src to dst `reps` times on `stream` and
 // reports the mean milliseconds per copy between two HIP events on that stream.  nt bit 0: streaming (non-temporal) loads
-// and stores, the cache policy of the pass kernels; bit 1: the column-tile shape of the passes instead of linear slabs.  Returns a fourier_hip status code.
+// and stores, the cache policy of the pass kernels; bit 1: the column-tile shape of the passes instead of linear slabs; bit 2 (with
+// bit 1): rows of 16 KiB (the f64 plan's shape; bytes a multiple of 16 MiB) instead of 8 KiB.  Returns a fourier_hip status code.
 // wgs_per_cu > 0 caps the resident workgroups per compute unit by giving every workgroup 160 KiB / wgs_per_cu of (unused)
 // dynamic LDS -- the pass kernels hold two workgroups per CU, a bare copy would hold four to eight.
 extern "C" int fourier_exp_copy_ceiling(const void* src, void* dst, uint64_t bytes, uint64_t bytes_per_block, int nt, int wgs_per_cu,
@@ -68,23 +72,33 @@ extern "C" int fourier_exp_copy_ceiling(const void* src, void* dst, uint64_t byt
   try {
     const hipStream_t st = (hipStream_t)stream;
     const unsigned blocks = (unsigned)(bytes / bytes_per_block);
-    hipEvent_t a, b;
-    HIP_CHECK(hipEventCreate(&a));
-    HIP_CHECK(hipEventCreate(&b));
-    const bool tile_shape = (nt & 2) != 0;  // bit 1: the passes' column-tile shape (bytes must be a multiple of 8 MiB)
-    if (tile_shape && bytes % ((uint64_t)8 << 20)) return ::fourier::c::FOURIER_HIP_INVALID_ARGUMENT;
+    const bool tile_shape = (nt & 2) != 0;  // bit 1: the passes' column-tile shape (bytes must be a multiple of 8 / 16 MiB)
+    const bool wide_rows = tile_shape && (nt & 4) != 0;
+    if (tile_shape && bytes % ((uint64_t)(wide_rows ? 16 : 8) << 20)) return ::fourier::c::FOURIER_HIP_INVALID_ARGUMENT;
+    struct Events {  // destroyed on every way out (the early return and a throwing HIP_CHECK leaked them)
+      hipEvent_t a = nullptr, b = nullptr;
+      ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } ev;
+    HIP_CHECK(hipEventCreate(&ev.a));
+    HIP_CHECK(hipEventCreate(&ev.b));
+    const hipEvent_t a = ev.a, b = ev.b;
     const unsigned tile_blocks = (unsigned)(bytes >> 17);  // 128 KiB per workgroup
     const size_t lds = wgs_per_cu > 0 ? ((size_t)160 * 1024 / (size_t)wgs_per_cu) & ~(size_t)1023 : 0;
     if (lds > 48 * 1024) {
-      raise_smem_limit((const void*)&copy_tile_kernel<true>, lds);
-      raise_smem_limit((const void*)&copy_tile_kernel<false>, lds);
+      raise_smem_limit((const void*)&copy_tile_kernel<true, 512>, lds);
+      raise_smem_limit((const void*)&copy_tile_kernel<false, 512>, lds);
+      raise_smem_limit((const void*)&copy_tile_kernel<true, 1024>, lds);
+      raise_smem_limit((const void*)&copy_tile_kernel<false, 1024>, lds);
       raise_smem_limit((const void*)&copy_slab_kernel<8, true>, lds);
       raise_smem_limit((const void*)&copy_slab_kernel<8, false>, lds);
     }
     auto launch = [&] {
-      if (tile_shape) {
-        if (nt & 1) copy_tile_kernel<true><<<tile_blocks, 512, lds, st>>>(src, dst);
-        else copy_tile_kernel<false><<<tile_blocks, 512, lds, st>>>(src, dst);
+      if (wide_rows) {
+        if (nt & 1) copy_tile_kernel<true, 1024><<<tile_blocks, 512, lds, st>>>(src, dst);
+        else copy_tile_kernel<false, 1024><<<tile_blocks, 512, lds, st>>>(src, dst);
+      } else if (tile_shape) {
+        if (nt & 1) copy_tile_kernel<true, 512><<<tile_blocks, 512, lds, st>>>(src, dst);
+        else copy_tile_kernel<false, 512><<<tile_blocks, 512, lds, st>>>(src, dst);
       } else if (nt & 1) copy_slab_kernel<8, true><<<blocks, 256, lds, st>>>(src, dst, bytes_per_block / 16);
       else copy_slab_kernel<8, false><<<blocks, 256, lds, st>>>(src, dst, bytes_per_block / 16);
     };
@@ -96,8 +110,6 @@ extern "C" int fourier_exp_copy_ceiling(const void* src, void* dst, uint64_t byt
     HIP_CHECK(hipEventSynchronize(b));
     float ms = 0;
     HIP_CHECK(hipEventElapsedTime(&ms, a, b));
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
     *ms_per_copy = ms / (float)reps;
     return ::fourier::c::FOURIER_HIP_OK;
   } catch (const EngineError& e) {

@@ -90,9 +90,17 @@ template <typename T> struct alignas(8) Unit8 { T a[8 / sizeof(T)]; };     // on
 //   FOURIER_NT_STORE = 2 (default): output stores are non-temporal -- the final pass's (+1%), and the intermediate
 //   ones of passes up to L = 1024 (+2%; the one-workgroup-per-CU L = 2048 passes lose 8% with them); 1 = final only
 //   FOURIER_ABLATE (timing experiments only, results are wrong): 1 = no butterflies / twiddles,
-//   2 = additionally no LDS exchange (pure load -> store), 3 = no inter-pass twiddle only
+//   2 = additionally no LDS exchange (pure load -> store), 3 = no inter-pass twiddle only, 4 = all arithmetic but the stage
+//   twiddles come from a constant instead of their table (no table loads inside the in-tile transform), 5 = all arithmetic but
+//   the per-thread factor of the inter-pass twiddle is a constant (no two-level table look-up between transform and store)
 #ifndef FOURIER_ABLATE
 #define FOURIER_ABLATE 0
+#endif
+//   FOURIER_SETPRIO = 1: the waves of the tile kernels raise their issue priority (s_setprio 3) while they issue a tile's global
+//   loads and stores and drop it (0) for the in-tile transform, so that a workgroup in a memory phase is not held up by its
+//   CU-mate's butterflies.  A/B knob (profiles/r05_s1_*): see DESIGN.md
+#ifndef FOURIER_SETPRIO
+#define FOURIER_SETPRIO 0
 #endif
 //   FOURIER_SPLIT_THRESHOLD: exchange buffers above this many bytes are exchanged as two planes (re, im):
 //   half the LDS per workgroup, twice the workgroups per CU (16 KiB measured best over 2^8..2^20, r01 sweep)
@@ -111,6 +119,12 @@ template <typename T> struct alignas(8) Unit8 { T a[8 / sizeof(T)]; };     // on
 #ifndef FOURIER_NT_STORE
 #define FOURIER_NT_STORE 2
 #endif
+
+template <int P> __device__ __forceinline__ void wave_priority() {
+#ifndef FOURIER_EMU
+  if constexpr (FOURIER_SETPRIO != 0) __builtin_amdgcn_s_setprio(P);
+#endif
+}
 
 // 16-byte global accesses (global_load_dwordx4 / global_store_dwordx4)
 template <typename T, bool NT> __device__ __forceinline__ Unit16<T> load_unit(const void* p) {

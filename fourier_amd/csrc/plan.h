@@ -194,6 +194,12 @@ template <typename T> class Plan {
       if (eng_inv_) eng_inv_->set_prefetch_last(v == 1);
       return 0;
     }
+    // the passes as their load / store skeleton (experiments library only; timing tool of bench.py's streaming ceiling, wrong results)
+    if (key == "skeleton" && (v == 0 || v == 1) && eng_ && !blu_) {
+      if (v == 1 && !eng_->has_skeleton()) return ::fourier::c::FOURIER_HIP_INVALID_ARGUMENT;
+      eng_->set_skeleton(v == 1);
+      return 0;
+    }
     // both passes in one launch with the intermediate in the XCD's L2 (2^16..2^18 f32, 2^15..2^17 f64); 0 where unavailable
     if (key == "l2_fused" && (v == 0 || v == 1)) {
       if (blu_ || !eng_ || (v == 1 && !eng_->has_l2fused())) return ::fourier::c::FOURIER_HIP_INVALID_ARGUMENT;
