@@ -251,7 +251,7 @@ template <typename T> class Pow2Engine {
     a.tw1 = ps.st->tw1.p; a.tw2 = rows ? ps.st->tw2.p : ps.st2->tw1.p;
     a.tw_lo = ps.tw_lo.p; a.tw_hi = ps.tw_hi.p;
     a.mul = wtab; a.blu_x = xtab; a.blu_n = n_user; a.blu_swap = inverse;
-    a.n = n_; a.scale = scale; a.nxcd = nxcd; a.total_cols = batch;
+    a.n = n_; a.scale = scale; a.nxcd = nxcd & 0xff; a.total_cols = batch;
     const uint64_t grid = rows ? (batch + blu_small_.COLS - 1) / blu_small_.COLS : batch;
     if (grid > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");
     PROF_BEGIN(prof, 0);
@@ -477,7 +477,8 @@ template <typename T> class Pow2Engine {
       a.n = n_; a.cn = ps.cn; a.s = ps.s; a.s_shift = (uint32_t)ilog2(ps.s);
       a.lo_bits = ps.lo_bits;
       a.nxcd = nxcd & 0xff;
-      a.xcd_interleave = (nxcd >> 8) & 3;
+      a.xcd_interleave = (nxcd >> 8) & 7;
+      a.walk_band = (nxcd >> 12) & 0xff; a.walk_group = (nxcd >> 20) & 0x7ff; a.walk_tf = nxcd >> 31;
       const bool blu_here = ps.has_blu && ((blu.io == IO_BLU_IN && p == 0) || (blu.io == IO_BLU_OUT && p + 1 == np));
       if (blu_here) {
         a.blu_x = blu.xtab; a.blu_n = blu.n; a.blu_swap = blu.swap;
@@ -567,7 +568,8 @@ template <typename T> class Pow2Engine {
     a.n = n_; a.cn = last.cn; a.s = last.s; a.s_shift = (uint32_t)ilog2(last.s);
     a.tiles = last.cn / conv_.COLS;
     a.nxcd = nxcd & 0xff;
-    a.xcd_interleave = (nxcd >> 8) & 3;
+    a.xcd_interleave = (nxcd >> 8) & 7;
+    a.walk_band = (nxcd >> 12) & 0xff; a.walk_group = (nxcd >> 20) & 0x7ff; a.walk_tf = nxcd >> 31;
     // this kernel (only) reads a per-transform table indexed like the data, the transformed chirp: let every XCD own an
     // eighth of the TILES of every transform, so that its 1/8 of the table (2 MiB of 16 at M = 2^21) stays in its L2
     // (with streaming stores: conv 4.5 vs 4.75 ms per 512 at C4; the plain passes lose 10-15 % under this order)

@@ -71,13 +71,12 @@ template <typename T> class TiledMixedEngine {
     return !factorise(n).empty();
   }
 
-  // launch shape of a tile pass of length L: the rules of TiledCfg (kernels_tiled.h), for a kernel compiled at run time
+  // launch shape of a tile pass of length L for a kernel compiled at run time: tiled_shape (mixed_schedule.h), the function the
+  // kernel's own TiledCfg is built from
   static TiledKernel shape_of(uint32_t L) {
+    const TileShape t = tiled_shape(L, (uint32_t)sizeof(cpx<T>));
     TiledKernel k;
-    k.L = L; k.cols = 128 / (uint32_t)sizeof(cpx<T>);
-    const uint32_t points = L * k.cols, ld = L | 1u, kh = (L + 15) / 16;
-    k.threads = points / 8 <= 256 ? 256 : (points / 8 <= 512 ? 512 : 1024);
-    k.smem = (((size_t)k.cols * ld * sizeof(cpx<T>) + 15) & ~(size_t)15) + (size_t)k.cols * (kh + 16) * sizeof(cpx<T>);
+    k.L = L; k.cols = t.cols; k.threads = t.threads; k.smem = t.smem;
     return k;
   }
   // rtc: plan option "specialise" -- the tile lengths may have prime factors up to 13, and a length without an ahead-of-time

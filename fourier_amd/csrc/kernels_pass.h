@@ -202,6 +202,19 @@ __device__ __forceinline__ uint32_t xcd_remap(const PassArgs& a, uint64_t blk64,
     const uint32_t band = slot / per_band, rem = slot % per_band;
     return (xcd * t_per_xcd + rem / tpb) * tiles + band * tpb + rem % tpb;
   }
+  if (a.xcd_interleave == 4 && tiles > 0 && a.walk_band > 0 && tiles % a.walk_band == 0 && nwg % (nx * tiles) == 0) {
+    // the general band walk: the XCD's contiguous range of whole transforms in groups of `walk_group`; inside a group band-major
+    // (`walk_band` adjacent tiles of every transform of the group, then the next band).  Workgroups that are resident together
+    // then work on walk_band * 128 bytes of every row of (resident tiles / walk_band) transforms instead of on whole rows of one.
+    const uint32_t tpx = nwg / (nx * tiles), bw = a.walk_band;
+    const uint32_t g = (a.walk_group == 0 || a.walk_group > tpx) ? tpx : a.walk_group;
+    if (tpx % g == 0) {
+      const uint32_t per_group = g * tiles, grp = slot / per_group, rem = slot % per_group;
+      const uint32_t per_band = g * bw, band = rem / per_band, rem2 = rem % per_band;
+      const uint32_t tr = a.walk_tf ? rem2 % g : rem2 / bw, tl = a.walk_tf ? rem2 / g : rem2 % bw;
+      return (xcd * tpx + grp * g + tr) * tiles + band * bw + tl;
+    }
+  }
   const uint32_t q = nwg / nx, r = nwg % nx;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }

@@ -15,17 +15,15 @@
 
 namespace fourier_hip {
 
-template <typename T, uint32_t L> struct TiledCfg {
-  static constexpr uint32_t COLS = 128 / (uint32_t)sizeof(cpx<T>);  // 16 (f32) / 8 (f64) columns: 128-byte row segments
-  // leading dimension of a column in LDS: odd, so that the COLS lanes of a row segment fall on different banks
-  static constexpr uint32_t LD = L | 1u;
+template <typename T, uint32_t L> struct TiledCfg {  // the rules: tiled_shape (mixed_schedule.h), shared with the host
+  static constexpr TileShape S = tiled_shape(L, (uint32_t)sizeof(cpx<T>));
+  static constexpr uint32_t COLS = S.cols;  // 16 (f32) / 8 (f64) columns: 128-byte row segments
+  static constexpr uint32_t LD = S.ld;      // odd leading dimension of a column in LDS
   static constexpr uint32_t POINTS = L * COLS;
-  static constexpr uint32_t NT = POINTS / 8 <= 256 ? 256 : (POINTS / 8 <= 512 ? 512 : 1024);  // about eight points per thread
-  // inter-pass twiddle of a tile: W^{i*k} = TA[col][k / 16] * TB[col][k % 16]
-  static constexpr uint32_t KH = (L + 15) / 16;
-  static constexpr size_t DATA_BYTES = (size_t)COLS * LD * sizeof(cpx<T>);
-  static constexpr size_t TAB_OFF = (DATA_BYTES + 15) & ~(size_t)15;
-  static constexpr size_t SMEM = TAB_OFF + (size_t)COLS * (KH + 16) * sizeof(cpx<T>);
+  static constexpr uint32_t NT = S.threads;  // about eight points per thread
+  static constexpr uint32_t KH = S.kh;       // inter-pass twiddle of a tile: W^{i*k} = TA[col][k / 16] * TB[col][k % 16]
+  static constexpr size_t TAB_OFF = S.tab_off;
+  static constexpr size_t SMEM = S.smem;
 };
 
 // One tile of one pass.  Columns: the first pass (s == 1) tiles the index i (m = n / L of them), later passes tile j (< s) at a
@@ -69,7 +67,9 @@ __global__ void __launch_bounds__((TiledCfg<T, L>::NT)) tiled_mixed_kernel_ct(Ti
       const uint32_t e = tid + it * NT;
       if (e < TENT) {
         const uint32_t c = e / (KH + 16), q = e - c * (KH + 16);
-        const uint64_t i = first ? (uint64_t)(c0 + c) : (uint64_t)i_row;
+        // (a masked column of a ragged last tile takes the last valid column's entries: its own index would reach past the
+        // end of the tw_hi table -- ADVICE round 4; the values are never used)
+        const uint64_t i = first ? (uint64_t)(c0 + c < ncols_total ? c0 + c : ncols_total - 1u) : (uint64_t)i_row;
         const uint64_t ex = i * (uint64_t)(q < KH ? 16u * q : q - KH);  // i * k < size
         tlo[it] = lo[ex & mask];
         thi[it] = hi[ex >> a.lo_bits];

@@ -202,4 +202,28 @@ template <typename T> constexpr bool mix_inplace(uint32_t n) {
 }
 
 
+// Launch shape of a column-tile pass of length L (kernels_tiled.h): ONE definition for the kernel (TiledCfg) and for the host,
+// which launches a tile kernel compiled at run time from these numbers (engine_tiled.h; ADVICE round 4: the two copies of the rule
+// could drift apart -- a block size or LDS size that differs from the kernel's compile-time one is silent corruption).
+// elem = sizeof(complex<T>): 8 / 16.
+struct TileShape {
+  uint32_t cols;     // 128-byte row segments: 16 (f32) / 8 (f64) columns
+  uint32_t ld;       // leading dimension of a column in LDS: odd, so that the lanes of a row segment fall on different banks
+  uint32_t threads;  // about eight points per thread
+  uint32_t kh;       // inter-pass twiddle of a tile: W^{i*k} = TA[col][k / 16] * TB[col][k % 16], kh = entries of TA per column
+  uint32_t tab_off;  // byte offset of TA behind the tile
+  uint32_t smem;     // bytes of LDS
+};
+constexpr TileShape tiled_shape(uint32_t L, uint32_t elem) {
+  TileShape t{};
+  t.cols = 128u / elem;
+  t.ld = L | 1u;
+  const uint32_t per8 = L * t.cols / 8u;
+  t.threads = per8 <= 256u ? 256u : (per8 <= 512u ? 512u : 1024u);
+  t.kh = (L + 15u) / 16u;
+  t.tab_off = (t.cols * t.ld * elem + 15u) & ~15u;
+  t.smem = t.tab_off + t.cols * (t.kh + 16u) * elem;
+  return t;
+}
+
 }  // namespace fourier_hip

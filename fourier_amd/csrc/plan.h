@@ -49,6 +49,11 @@ template <typename T> class Plan {
     DeviceGuard g(device_);
     if (is_pow2(n)) {
       eng_.reset(new Pow2Engine<T>(n, false, true));
+      // f32 2^20 = 1024 x 1024 (BASELINE configs[1]): every XCD walks its range of transforms in bands of eight adjacent tiles
+      // (1 KiB of every row of eight transforms in flight per XCD instead of whole 8 KiB rows of one) -- 23.07 against 23.50 ms and
+      // 23.05 against 23.70 ms per 4096 transforms on two boxes, bit-identical (profiles/r05_s2_*, r05_s3_c2_tile_walk_ab.jsonl);
+      // f64, the L = 2048 plans and the Bluestein inner passes lose 0 - 8 % with it (r05_s3_*, r05_s4_*) and keep the tile order
+      if (sizeof(T) == 4 && n == ((size_t)1 << 20) && !dev_env("FOURIER_NO_BAND_WALK")) nxcd_ = 8u | (4u << 8) | (8u << 12);
     } else if (tiled_before_pow2_tiles(n)) {
       // 2^a * 3^b with a >= 12 as TWO mixed-length tile passes instead of power-of-two tiles + odd passes (three or four round
       // trips): 1 - 25 % faster up to 384 x 384, slower from 512 x 432 on (profiles/r04_s8_pow2_tiles_plus_odd_passes_vs_mixed_tiles_ab.jsonl)
@@ -145,6 +150,13 @@ template <typename T> class Plan {
     if (key == "chunk_bytes" && v >= 0) { chunk_bytes_ = (size_t)v; return 0; }
     if (key == "scratch" && (v == 0 || v == 1)) { force_scratch_ = (v == 1); return 0; }
     if (key == "xcd_swizzle" && v >= 0 && v <= 4) { nxcd_ = v == 0 ? 1 : (8 | ((unsigned)(v - 1) << 8)); return 0; }
+    // the general band walk of the tile passes (xcd_remap mode 4): v = tiles per band | transforms per group << 8 (0 = the XCD's
+    // whole range) | transform-fastest << 19; v = 0 restores the default order
+    if (key == "tile_walk" && v >= 0 && v < (1 << 20)) {
+      const unsigned band = (unsigned)v & 0xff, group = ((unsigned)v >> 8) & 0x7ff, tf = ((unsigned)v >> 19) & 1;
+      nxcd_ = band == 0 ? 8u : (8u | (4u << 8) | (band << 12) | (group << 20) | (tf << 31));
+      return 0;
+    }
     if (key == "bluestein_fusion" && (v == 0 || v == 1)) {
       fused_ = (v == 1) && blu_ && eng_->can_fuse_bluestein();
       small_fused_ = (v == 1) && blu_ && eng_->enable_bluestein_small();
