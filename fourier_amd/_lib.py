@@ -17,7 +17,7 @@ LEGACY_SYMBOLS = [f"fourier_{op}_{s}" for s in SUFFIXES for op in ("create", "de
 EXT_SYMBOLS = [f"fourier_hip_{op}_{s}" for s in SUFFIXES
                for op in ("create", "size", "transform_batch", "reserve", "device", "synchronize", "transform_batch_host", "last_status", "set_option", "describe", "model_bytes",
                           "profile", "slot_names")] + [
-    "fourier_hip_status_string"]
+    "fourier_hip_status_string", "fourier_hip_set_default_option", "fourier_hip_get_default_option"]
 ALL_SYMBOLS = LEGACY_SYMBOLS + EXT_SYMBOLS
 
 
@@ -47,6 +47,11 @@ def bind(cdll, strict=True):
         f = getattr(cdll, f"fourier_hip_slot_names_{s}"); f.restype = cp; f.argtypes = [vp]
     cdll.fourier_hip_status_string.restype = cp
     cdll.fourier_hip_status_string.argtypes = [ci]
+    if strict or hasattr(cdll, "fourier_hip_set_default_option"):
+        cdll.fourier_hip_set_default_option.restype = ci
+        cdll.fourier_hip_set_default_option.argtypes = [cp, ll]
+        cdll.fourier_hip_get_default_option.restype = ll
+        cdll.fourier_hip_get_default_option.argtypes = [cp]
     return cdll
 
 

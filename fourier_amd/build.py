@@ -72,7 +72,8 @@ def translation_units():
         tus.append((f"kernels_onelaunch_{tag}", "kernels_onelaunch.cpp", d, "onelaunch"))
         tus.append((f"kernels_mixed_rt_{tag}", "kernels_mixed_rt.cpp", d, "mixed"))
         tus.append((f"kernels_misc_{tag}", "kernels_misc.cpp", d, "misc"))
-        tus.append((f"kernels_tiled_{tag}", "kernels_tiled.cpp", d, "mixed"))
+        for i in range(4):
+            tus.append((f"kernels_tiled_{tag}_{i}", "kernels_tiled.cpp", d + [f"-DFOURIER_TILED_SHARD={i}"], "mixed"))
         tus.append((f"kernels_experiments_{tag}", "kernels_experiments.cpp", d, "experiments"))
         tus.append((f"kernels_skeleton_{tag}", "kernels_skeleton.cpp", d, "experiments"))
     return tus

@@ -94,6 +94,33 @@ namespace fc = ::fourier::c;
 FOURIER_DEFINE_ABI(float, float)
 FOURIER_DEFINE_ABI(double, double)
 
+// ---- library-wide defaults for plans created afterwards
+namespace fourier_hip {
+namespace {
+std::atomic<int> g_specialise_policy{-1};  // -1: not decided yet (the environment is read on first use)
+}
+int specialise_policy() {
+  int v = g_specialise_policy.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("FOURIER_HIP_SPECIALISE");  // "0", "1", "2": for programs that cannot be changed to call the function
+    v = (e && *e >= '0' && *e <= '2' && !e[1]) ? *e - '0' : 1;
+    g_specialise_policy.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+void set_specialise_policy(int v) { g_specialise_policy.store(v, std::memory_order_relaxed); }
+}  // namespace fourier_hip
+
+extern "C" int fourier_hip_set_default_option(const char* key, long long v) {
+  if (!key) return fc::FOURIER_HIP_INVALID_ARGUMENT;
+  if (std::string(key) == "specialise_at_create" && v >= 0 && v <= 2) { set_specialise_policy((int)v); return fc::FOURIER_HIP_OK; }
+  return fc::FOURIER_HIP_INVALID_ARGUMENT;
+}
+extern "C" long long fourier_hip_get_default_option(const char* key) {
+  if (key && std::string(key) == "specialise_at_create") return specialise_policy();
+  return -1;
+}
+
 extern "C" const char* fourier_hip_status_string(int status) {
   switch (status) {
     case fc::FOURIER_HIP_OK: return "ok";

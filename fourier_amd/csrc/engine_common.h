@@ -8,6 +8,7 @@
 #endif
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -195,7 +196,16 @@ struct RtcKernel { void* fn = nullptr; };
 // mixed_radix_kernel_ct<float|double, n> compiled with hipRTC (cached per device, precision and length), its lds_bytes of LDS
 // declared statically; false + the reason where hipRTC or the compilation is not available
 // tile_pass: tiled_mixed_kernel_ct<T, n> (a column-tile pass of length n) instead of the whole-transform kernel
-bool rtc_mixed_kernel(bool f64, uint32_t n, size_t lds_bytes, RtcKernel& out, std::string& why, bool tile_pass = false);
+// allow_compile = false: only the process cache and the on-disk code-object cache are consulted (a few milliseconds)
+bool rtc_mixed_kernel(bool f64, uint32_t n, size_t lds_bytes, RtcKernel& out, std::string& why, bool tile_pass = false, bool allow_compile = true);
+// that kernel is in the process cache or has a file in the on-disk cache (no module is loaded)
+bool rtc_cached(bool f64, uint32_t n, size_t lds_bytes, bool tile_pass);
+// Library-wide policy for plans created from now on (fourier_hip_set_default_option "specialise_at_create", or the environment
+// variable FOURIER_HIP_SPECIALISE read once): 0 = a plan never picks a run-time kernel by itself, 1 (default) = a plan created for a
+// length with a specialised kernel in the on-disk cache loads it (no compilation ever happens implicitly), 2 = ... and compiles it
+// where the cache has none (about a second per new length and machine)
+int specialise_policy();
+void set_specialise_policy(int v);
 
 // ---------------------------------------------------------------------------------------------
 // Kernel registry.  Real<T> selects the precision; every function is defined once per precision in the translation unit
@@ -223,8 +233,10 @@ template <typename T> struct Real {};
   /* kernels_mixed_ct.cpp, compiled FOURIER_MIX_SHARDS times per precision (-DFOURIER_MIX_SHARD=i): shard i of the  */  \
   /* per-length kernels; false when shard i holds no kernel for length n                                           */  \
   FOURIER_MIX_SHARD_LIST(FOURIER_DECLARE_MIX_SHARD, T)                                                                 \
-  /* kernels_tiled.cpp: column-tile pass of mixed length L = 2^x * 3^y, 64 <= L <= 512; fn == nullptr: no such kernel */ \
+  /* kernels_tiled.cpp (4 shards): column-tile pass of length L, 64 <= L <= 512, prime factors up to 7; fn == nullptr: none */ \
   TiledKernel get_tiled_kernel(Real<T>, uint32_t L);                                                                   \
+  TiledKernel get_tiled_kernel_s0(Real<T>, uint32_t L); TiledKernel get_tiled_kernel_s1(Real<T>, uint32_t L);         \
+  TiledKernel get_tiled_kernel_s2(Real<T>, uint32_t L); TiledKernel get_tiled_kernel_s3(Real<T>, uint32_t L);         \
   /* kernels_experiments.cpp (experiments library) or env_product.cpp (product: nothing available) */                  \
   bool get_fused_kernel(Real<T>, int k, FusedInfo& info);                                                              \
   KernelInfo get_split_kernel(Real<T>, int L, int io);                                                                 \

@@ -106,16 +106,27 @@ template <typename T> class MixedEngine {
   // Plan option "specialise": compile this length's own kernel (mixed_radix_kernel_ct<T, n>, the form of the ahead-of-time
   // per-length kernels) with hipRTC and use it from now on.  Nothing to do where the plan already runs a per-length kernel.
   // Status: OK, or UNSUPPORTED (no hipRTC, or the compilation failed) -- the plan then keeps the kernel it had.
-  int specialise(std::string* why = nullptr) {
+  // LDS bytes of the specialised kernel of length n (the launch shape rules of mixed_schedule.h)
+  static size_t specialised_lds_bytes(uint32_t n) {
+    size_t tw_entries = 0;
+    std::vector<uint32_t> radices;
+    if (mix_tw_lds<T>(n) && factor(n, radices)) {
+      size_t cur = n;
+      for (const size_t R : radices) { tw_entries += cur; cur /= R; }
+    }
+    return (mix_inplace<T>(n) ? 1 : 2) * (size_t)mix_group<T>(n) * n * sizeof(cpx<T>) + tw_entries * sizeof(cpx<T>);
+  }
+  static bool specialised_kernel_cached(size_t n) { return n <= MAX_N && rtc_cached(sizeof(T) == 8, (uint32_t)n, specialised_lds_bytes((uint32_t)n), false); }
+  int specialise(std::string* why = nullptr, bool allow_compile = true) {
     if (rtc_.fn || per_length_) return ::fourier::c::FOURIER_HIP_OK;
     const uint32_t n = (uint32_t)n_;
     const uint32_t group = mix_group<T>(n), threads = mix_threads<T>(n);
     const size_t nbuf = mix_inplace<T>(n) ? 1 : 2;
-    const size_t smem = nbuf * (size_t)group * n * sizeof(cpx<T>) + (mix_tw_lds<T>(n) ? tw_entries_ * sizeof(cpx<T>) : 0);
+    const size_t smem = specialised_lds_bytes(n);
     std::string reason;
     RtcKernel k;
     if (smem > MAX_LDS) reason = "the length does not fit a compute unit's LDS";
-    else if (rtc_mixed_kernel(sizeof(T) == 8, n, smem, k, reason)) {
+    else if (rtc_mixed_kernel(sizeof(T) == 8, n, smem, k, reason, false, allow_compile)) {
       rtc_ = k; group_ = group; threads_ = threads; nbuf_ = nbuf;
       smem_ = 0;  // the specialised kernel declares its LDS statically
       return ::fourier::c::FOURIER_HIP_OK;

@@ -13,12 +13,8 @@ template <typename T> class TiledMixedEngine {
   static const std::vector<uint32_t>& menu() {
     static const std::vector<uint32_t> m = [] {
       std::vector<uint32_t> v;
-      for (uint32_t L = 64; L <= 512; ++L) {
-        uint32_t r = L;
-        while (r % 2 == 0) r /= 2;
-        while (r % 3 == 0) r /= 3;
-        if (r == 1 && get_tiled_kernel(Real<T>{}, L).fn) v.push_back(L);
-      }
+      for (uint32_t L = 64; L <= 512; ++L)  // every length with an ahead-of-time kernel: prime factors up to 7 (kernels_tiled.cpp)
+        if (get_tiled_kernel(Real<T>{}, L).fn) v.push_back(L);
       return v;
     }();
     return m;
@@ -71,6 +67,18 @@ template <typename T> class TiledMixedEngine {
     return !factorise(n).empty();
   }
 
+  // Lengths with a factor 5 or 7 and no prime factor above 7 beyond the whole-transform LDS kernels (the reference: Bluestein,
+  // fourier/src/lib.rs:38-42): two or three tile passes over the ahead-of-time menu -- 10^5 = 400 x 250, 44100 = 210 x 210, 10^6 =
+  // 100 x 100 x 100 (round 5; until then only under the plan option "specialise")
+  static bool handles_smooth(size_t n) {
+    if (n < 4096 || n > MAX_N || dev_env("FOURIER_NO_TILED_MIXED") || dev_env("FOURIER_NO_TILED_SMOOTH")) return false;
+    size_t p = n;
+    for (size_t q : {2, 3, 5, 7})
+      while (p % q == 0) p /= q;
+    if (p != 1 || (n % 5 != 0 && n % 7 != 0)) return false;
+    return !factorise(n).empty();
+  }
+
   // launch shape of a tile pass of length L for a kernel compiled at run time: tiled_shape (mixed_schedule.h), the function the
   // kernel's own TiledCfg is built from
   static TiledKernel shape_of(uint32_t L) {
@@ -81,7 +89,14 @@ template <typename T> class TiledMixedEngine {
   }
   // rtc: plan option "specialise" -- the tile lengths may have prime factors up to 13, and a length without an ahead-of-time
   // kernel is compiled with hipRTC (rtc.cpp); throws UNSUPPORTED where that is not possible
-  explicit TiledMixedEngine(size_t n, bool rtc = false) : n_(n) {
+  // every tile length of the run-time factorisation of n has an ahead-of-time kernel or a cached specialised one
+  static bool specialised_kernels_cached(size_t n) {
+    const std::vector<uint32_t> lens = factorise(n, true);
+    for (uint32_t L : lens)
+      if (!get_tiled_kernel(Real<T>{}, L).fn && !rtc_cached(sizeof(T) == 8, L, shape_of(L).smem, true)) return false;
+    return !lens.empty();
+  }
+  explicit TiledMixedEngine(size_t n, bool rtc = false, bool allow_compile = true) : n_(n) {
     const std::vector<uint32_t> lens = factorise(n, rtc);
     if (lens.empty()) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "no tile factorisation");
     uint64_t s = 1, size = n;
@@ -92,7 +107,7 @@ template <typename T> class TiledMixedEngine {
         if (!rtc) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "no tile kernel of this length");
         ps.k = shape_of(L);
         std::string why;
-        if (!rtc_mixed_kernel(sizeof(T) == 8, L, ps.k.smem, ps.rtc, why, true))
+        if (!rtc_mixed_kernel(sizeof(T) == 8, L, ps.k.smem, ps.rtc, why, true, allow_compile))
           throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "tile pass of length " + std::to_string(L) + ": " + why);
         ps.k.smem = 0;  // declared statically by the specialised kernel
         specialised_ = true;

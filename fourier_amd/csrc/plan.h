@@ -63,14 +63,46 @@ template <typename T> class Plan {
       // efficiency beat the one-workgroup-per-CU LDS kernel where both apply (3*2^12 f32: 23 % vs 14 %)
       eng_.reset(new Pow2Engine<T>(n));
     } else if (MixedEngine<T>::handles(n) && try_mixed(n)) {
+      // a length on the runtime-parameterised kernel takes its own kernel where the code-object cache has it (policy 2: compiles it)
+      if (specialise_policy() >= 1) (void)mix_->specialise(nullptr, specialise_policy() >= 2);
     } else if (TiledMixedEngine<T>::handles(n)) {
       tiled_.reset(new TiledMixedEngine<T>(n));  // two or three HBM round trips on column tiles of mixed length
     } else if (GenericEngine<T>::handles(n)) {
       gen_.reset(new GenericEngine<T>(n));       // what is left of 2^a*3^b, a < 12: one round trip per radix
+    } else if (TiledMixedEngine<T>::handles_smooth(n)) {
+      tiled_.reset(new TiledMixedEngine<T>(n));  // factors 5 / 7 beyond the LDS kernels: tile passes instead of Bluestein (round 5)
+    } else if (specialise_policy() >= 1 && specialised_route(n, specialise_policy() >= 2, nullptr)) {
+      // prime factors up to 13 without an ahead-of-time route: the kernels of an earlier "specialise" from the on-disk cache
     } else {
       init_bluestein();
     }
     refresh_desc();
+  }
+  // A length the default routes send to Bluestein although its prime factors stop at 13: its own LDS kernel (<= MAX_N points) or
+  // two / three column-tile passes, specialised at run time (rtc.cpp).  allow_compile = false: only where every kernel it needs is
+  // in the code-object cache.  true: mix_ / tiled_ is set.
+  bool specialised_route(size_t n, bool allow_compile, std::string* why) {
+    std::string local;
+    std::string& w = why ? *why : local;
+    if (is_pow2(n) || n < 2) { w = "a power of two"; return false; }
+    std::vector<uint32_t> radices;
+    if (n <= MixedEngine<T>::MAX_N) {
+      if (!MixedEngine<T>::factor(n, radices)) { w = "a prime factor above 13"; return false; }
+      if (!allow_compile && !MixedEngine<T>::specialised_kernel_cached(n)) { w = "not in the code-object cache"; return false; }
+      std::unique_ptr<MixedEngine<T>> m;
+      try { m.reset(new MixedEngine<T>(n, true)); } catch (const EngineError& e) { (void)hipGetLastError(); w = e.what(); return false; }
+      if (m->specialise(&w, allow_compile) != ::fourier::c::FOURIER_HIP_OK) return false;
+      mix_ = std::move(m);
+      return true;
+    }
+    if (n <= TiledMixedEngine<T>::MAX_N && !TiledMixedEngine<T>::factorise(n, true).empty()) {
+      if (!allow_compile && !TiledMixedEngine<T>::specialised_kernels_cached(n)) { w = "not in the code-object cache"; return false; }
+      try { tiled_.reset(new TiledMixedEngine<T>(n, true, allow_compile)); }
+      catch (const EngineError& e) { (void)hipGetLastError(); tiled_.reset(); w = e.what(); return false; }
+      return true;
+    }
+    w = "not a length whose prime factors stop at 13 with a kernel to specialise";
+    return false;
   }
   static bool tiled_before_pow2_tiles(size_t n) {
     if (!Pow2Engine<T>::handles_mixed(n) || dev_env("FOURIER_POW2_TILES_FIRST") || !TiledMixedEngine<T>::handles(n, true)) return false;
@@ -177,24 +209,11 @@ template <typename T> class Plan {
         return st;
       };
       if (mix_) { const int st = mix_->specialise(&why); refresh_desc(); return report(st); }
-      if (blu_ && n_ <= MixedEngine<T>::MAX_N && !is_pow2(n_)) {
-        std::vector<uint32_t> radices;
-        if (!MixedEngine<T>::factor(n_, radices)) { why = "a prime factor above 13"; return report(::fourier::c::FOURIER_HIP_UNSUPPORTED); }
-        std::unique_ptr<MixedEngine<T>> m;
-        try { m.reset(new MixedEngine<T>(n_, true)); } catch (const EngineError& e) { (void)hipGetLastError(); why = e.what(); return report(e.status); }
-        const int st = m->specialise(&why);
-        if (st != ::fourier::c::FOURIER_HIP_OK) return report(st);
-        mix_ = std::move(m);  // exec() takes the LDS route from here on; the Bluestein tables stay allocated but unused
-        refresh_desc();
-        return st;
+      if (blu_) {  // exec() takes the new route from here on; the Bluestein tables stay allocated but unused
+        if (specialised_route(n_, true, &why)) { refresh_desc(); return ::fourier::c::FOURIER_HIP_OK; }
+        return report(::fourier::c::FOURIER_HIP_UNSUPPORTED);
       }
-      if (blu_ && n_ > MixedEngine<T>::MAX_N && n_ <= TiledMixedEngine<T>::MAX_N && !TiledMixedEngine<T>::factorise(n_, true).empty()) {
-        // beyond one compute unit's LDS: two or three column-tile passes whose lengths may have prime factors up to 13
-        try { tiled_.reset(new TiledMixedEngine<T>(n_, true)); }
-        catch (const EngineError& e) { (void)hipGetLastError(); tiled_.reset(); why = e.what(); return report(e.status); }
-        refresh_desc();
-        return ::fourier::c::FOURIER_HIP_OK;
-      }
+      if (tiled_) return ::fourier::c::FOURIER_HIP_OK;  // ahead-of-time tile passes already: nothing to specialise
       why = "not a length whose prime factors stop at 13 with a kernel to specialise";
       return report(::fourier::c::FOURIER_HIP_UNSUPPORTED);
     }

@@ -6,23 +6,34 @@
 // run the runtime-parameterised kernel at 24-36 % of the HBM peak where a per-length kernel reaches 45-60 % (round 3).  hipRTC
 // closes that gap without an instantiation per length in the library: the four device headers are embedded in the library
 // (rtc_sources.inc, generated from the same files the build compiles), the program is an explicit instantiation of the one
-// kernel, the code object is loaded as a module and cached per (precision, length) for the life of the process.  About one
-// second per length, paid when the option is set, never on plan creation or in a transform call.  libhiprtc is loaded lazily
-// (dlopen): the library keeps libamdhip64 as its only link-time dependency, and where hipRTC is missing the option reports
-// FOURIER_HIP_UNSUPPORTED and the plan keeps its kernel.
+// kernel, the code object is loaded as a module and cached per (precision, length) for the life of the process -- and, round 5,
+// ON DISK: $FOURIER_HIP_CACHE_DIR, else $XDG_CACHE_HOME/fourier-hip, else $HOME/.cache/fourier-hip (an empty FOURIER_HIP_CACHE_DIR
+// switches the disk cache off), one file per (device architecture, precision, kind, length, LDS bytes, hash of the embedded headers
+// and compile options), written through a temporary file and rename().  About one second per length the first time on a machine,
+// a few milliseconds from the disk cache (no libhiprtc needed for that), nothing from the process cache.  libhiprtc is loaded
+// lazily (dlopen): the library keeps libamdhip64 as its only link-time dependency, and where hipRTC is missing and the cache has no
+// entry the caller gets FOURIER_HIP_UNSUPPORTED and the plan keeps its kernel.
 #include "engine_common.h"
 #include "mixed_schedule.h"
 
 #ifndef FOURIER_EMU
 #include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <cstdio>
 #include <mutex>
+#ifdef FOURIER_RTC_SOURCES_INC  // packaging/CMakeLists.txt generates the file into its build directory
+#include FOURIER_RTC_SOURCES_INC
+#else
 #include "rtc_sources.inc"
+#endif
 #endif
 
 namespace fourier_hip {
 
 #ifdef FOURIER_EMU
-bool rtc_mixed_kernel(bool, uint32_t, size_t, RtcKernel&, std::string& why, bool) { why = "no hipRTC under the CPU emulation"; return false; }
+bool rtc_mixed_kernel(bool, uint32_t, size_t, RtcKernel&, std::string& why, bool, bool) { why = "no hipRTC under the CPU emulation"; return false; }
+bool rtc_cached(bool, uint32_t, size_t, bool) { return false; }
 #else
 
 namespace {
@@ -61,17 +72,114 @@ struct Rtc {
 };
 std::mutex g_mu;
 std::map<std::pair<int, uint32_t>, RtcKernel> g_cache;  // ((device, f64, tile pass), n) -> loaded kernel; modules live as long as the process
+
+const char* const RTC_OPTIONS[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize"};
+constexpr int RTC_NUM_OPTIONS = 4;
+
+// ---- the on-disk cache
+std::string cache_dir() {
+  const char* e = getenv("FOURIER_HIP_CACHE_DIR");
+  if (e) return std::string(e);  // (empty: no disk cache)
+  if ((e = getenv("XDG_CACHE_HOME")) && *e) return std::string(e) + "/fourier-hip";
+  if ((e = getenv("HOME")) && *e) return std::string(e) + "/.cache/fourier-hip";
+  return std::string();
+}
+// FNV-1a over everything a code object depends on besides its key: the embedded headers and the compile options
+uint64_t sources_hash() {
+  static const uint64_t h = [] {
+    uint64_t x = 1469598103934665603ull;
+    auto eat = [&](const char* p) { for (; *p; ++p) { x ^= (unsigned char)*p; x *= 1099511628211ull; } x ^= 0xff; x *= 1099511628211ull; };
+    for (int i = 0; i < RTC_NUM_HEADERS; ++i) { eat(RTC_HEADER_NAMES[i]); eat(RTC_HEADER_SOURCES[i]); }
+    for (int i = 0; i < RTC_NUM_OPTIONS; ++i) eat(RTC_OPTIONS[i]);
+    return x;
+  }();
+  return h;
+}
+std::string cache_file(int dev, bool f64, uint32_t n, size_t lds_bytes, bool tile_pass) {
+  const std::string dir = cache_dir();
+  if (dir.empty()) return std::string();
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return std::string(); }
+  std::string arch = prop.gcnArchName;
+  for (char& c : arch) if (!isalnum((unsigned char)c)) c = '_';
+  char hash[24];
+  snprintf(hash, sizeof hash, "%016llx", (unsigned long long)sources_hash());
+  return dir + "/" + arch + "-" + (f64 ? "f64" : "f32") + "-" + (tile_pass ? "tile" : "whole") + "-n" + std::to_string(n) + "-lds" + std::to_string(lds_bytes) + "-" + hash + ".co";
+}
+void make_dirs(const std::string& dir) {
+  for (size_t i = 1; i <= dir.size(); ++i)
+    if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0755);
+}
+const char CACHE_MAGIC[] = "FOURIER-HIP-CO-1\n";
+// file: magic line, the kernel's lowered name, a newline, the code object
+bool read_cache(const std::string& path, std::string& lowered, std::vector<char>& code) {
+  FILE* f = path.empty() ? nullptr : fopen(path.c_str(), "rb");
+  if (!f) return false;
+  std::vector<char> all;
+  char buf[65536];
+  size_t got;
+  while ((got = fread(buf, 1, sizeof buf, f)) > 0) all.insert(all.end(), buf, buf + got);
+  fclose(f);
+  const size_t ml = sizeof(CACHE_MAGIC) - 1;
+  if (all.size() <= ml || memcmp(all.data(), CACHE_MAGIC, ml) != 0) return false;
+  const char* nl = (const char*)memchr(all.data() + ml, '\n', all.size() - ml);
+  if (!nl) return false;
+  lowered.assign((const char*)all.data() + ml, nl);
+  code.assign(nl + 1, (const char*)all.data() + all.size());
+  return !lowered.empty() && !code.empty();
+}
+void write_cache(const std::string& path, const std::string& lowered, const std::vector<char>& code) {
+  if (path.empty()) return;
+  make_dirs(path.substr(0, path.rfind('/')));
+  const std::string tmp = path + ".tmp" + std::to_string((long long)getpid());
+  FILE* f = fopen(tmp.c_str(), "wb");
+  if (!f) return;
+  bool ok = fwrite(CACHE_MAGIC, 1, sizeof(CACHE_MAGIC) - 1, f) == sizeof(CACHE_MAGIC) - 1 && fwrite(lowered.data(), 1, lowered.size(), f) == lowered.size() &&
+            fputc('\n', f) != EOF && fwrite(code.data(), 1, code.size(), f) == code.size();
+  ok = (fclose(f) == 0) && ok;
+  if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)unlink(tmp.c_str());
+}
+bool load_module(const std::vector<char>& code, const std::string& lowered, RtcKernel& out, std::string& why) {
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+  if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { why = "hipModuleLoadData failed"; (void)hipGetLastError(); return false; }
+  if (hipModuleGetFunction(&fn, mod, lowered.c_str()) != hipSuccess) { why = "hipModuleGetFunction failed"; (void)hipGetLastError(); (void)hipModuleUnload(mod); return false; }
+  out.fn = (void*)fn;
+  return true;
+}
+int cache_key(int dev, bool f64, bool tile_pass) { return (dev * 2 + (f64 ? 1 : 0)) * 2 + (tile_pass ? 1 : 0); }
 }  // namespace
 
-bool rtc_mixed_kernel(bool f64, uint32_t n, size_t lds_bytes, RtcKernel& out, std::string& why, bool tile_pass) {
-  static Rtc rtc;
-  if (!rtc.ok) { why = "libhiprtc not available"; return false; }
+bool rtc_cached(bool f64, uint32_t n, size_t lds_bytes, bool tile_pass) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (g_cache.count(std::make_pair(cache_key(dev, f64, tile_pass), n))) return true;
+  }
+  const std::string path = cache_file(dev, f64, n, lds_bytes, tile_pass);
+  return !path.empty() && access(path.c_str(), R_OK) == 0;
+}
+
+bool rtc_mixed_kernel(bool f64, uint32_t n, size_t lds_bytes, RtcKernel& out, std::string& why, bool tile_pass, bool allow_compile) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { why = "no device"; return false; }
   std::lock_guard<std::mutex> lock(g_mu);
-  const auto key = std::make_pair((dev * 2 + (f64 ? 1 : 0)) * 2 + (tile_pass ? 1 : 0), n);
+  const auto key = std::make_pair(cache_key(dev, f64, tile_pass), n);
   auto it = g_cache.find(key);
   if (it != g_cache.end()) { out = it->second; return true; }
+  const std::string path = cache_file(dev, f64, n, lds_bytes, tile_pass);
+  {  // the disk cache: no compiler needed
+    std::string lowered, err;
+    std::vector<char> code;
+    if (read_cache(path, lowered, code)) {
+      if (load_module(code, lowered, out, err)) { g_cache.emplace(key, out); return true; }
+      (void)unlink(path.c_str());  // a file this runtime cannot load: compile again
+    }
+  }
+  if (!allow_compile) { why = "not in the code-object cache (compilation not asked for)"; return false; }
+  static Rtc rtc;
+  if (!rtc.ok) { why = "libhiprtc not available"; return false; }
   const std::string real = f64 ? "double" : "float";
   // the whole-transform kernel of length n, or the column-tile pass of length n (kernels_tiled.h)
   const std::string kernel = tile_pass ? "tiled_mixed_kernel_ct" : "mixed_radix_kernel_ct", args = tile_pass ? "TiledArgs" : "MixArgs";
@@ -86,8 +194,10 @@ bool rtc_mixed_kernel(bool f64, uint32_t n, size_t lds_bytes, RtcKernel& out, st
     // the flags of fourier_amd/build.py (SLP packing of f32 math doubles the butterflies' live registers)
     // and the kernel's LDS footprint, which it declares statically (kernels_common.h: FOURIER_RTC_LDS_BYTES)
     const std::string lds = "-DFOURIER_RTC_LDS_BYTES=" + std::to_string(lds_bytes);
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", lds.c_str()};
-    if (rtc.compile(prog, 5, opts) != 0) {
+    const char* opts[RTC_NUM_OPTIONS + 1];
+    for (int i = 0; i < RTC_NUM_OPTIONS; ++i) opts[i] = RTC_OPTIONS[i];
+    opts[RTC_NUM_OPTIONS] = lds.c_str();
+    if (rtc.compile(prog, RTC_NUM_OPTIONS + 1, opts) != 0) {
       size_t ls = 0;
       rtc.log_size(prog, &ls);
       std::string log(ls, '\0');
@@ -101,11 +211,8 @@ bool rtc_mixed_kernel(bool f64, uint32_t n, size_t lds_bytes, RtcKernel& out, st
     if (rtc.code_size(prog, &cs) != 0 || cs == 0) { why = "hiprtcGetCodeSize failed"; break; }
     std::vector<char> code(cs);
     if (rtc.code(prog, code.data()) != 0) { why = "hiprtcGetCode failed"; break; }
-    hipModule_t mod = nullptr;
-    hipFunction_t fn = nullptr;
-    if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { why = "hipModuleLoadData failed"; (void)hipGetLastError(); break; }
-    if (hipModuleGetFunction(&fn, mod, low) != hipSuccess) { why = "hipModuleGetFunction failed"; (void)hipGetLastError(); (void)hipModuleUnload(mod); break; }
-    out.fn = (void*)fn;
+    if (!load_module(code, low, out, why)) break;
+    write_cache(path, low, code);
     g_cache.emplace(key, out);
     ok = true;
   } while (false);

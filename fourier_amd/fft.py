@@ -198,6 +198,17 @@ class Fft:
                 pass
 
 
+def set_default_option(key, value):
+    """Library-wide default for plans created afterwards (include/fourier.h: fourier_hip_set_default_option), e.g.
+    ("specialise_at_create", 2): lengths whose prime factors stop at 13 get their own kernels compiled inside create_fft_*."""
+    if _lib.lib().fourier_hip_set_default_option(key.encode(), int(value)) != 0:
+        raise FourierError(f"bad default option {key}={value}")
+
+
+def get_default_option(key):
+    return int(_lib.lib().fourier_hip_get_default_option(key.encode()))
+
+
 def create_fft_f32(size, device=-1):
     """fourier/src/lib.rs:31-43."""
     return Fft(size, "f32", device)

@@ -90,18 +90,27 @@ enum {
  * (fourier/src/lib.rs:31-60): Stockham autosort for 2^a * 3^b as in the reference (`Autosort::new`, autosort/mod.rs:104-134),
  * Bluestein chirp-z (fourier-algorithms/src/bluesteins.rs) otherwise -- with one extension: SOME lengths that the reference
  * sends to Bluestein run as direct Stockham passes here (closer to the exact DFT than the chirp-z route, within the same
- * tolerance).  The routes, in the order they are tried:
- *   powers of two                                   big-radix Stockham passes (one, two or three HBM round trips)
- *   2^a * 3^b, a >= 12                              the same passes over 2^a, then radix-27 / 9 / 3 passes
- *   2^a * 3^b * 5^c * 7^d * 11^e * 13^f that fit one compute unit's LDS (<= 20480 points in f32, 10240 in f64) AND have a
- *     kernel: every 2^a * 3^b; every such length with factors 5 (and the instantiated ones with a factor 7) has a per-length
- *     kernel; any other length of this family up to 8192 points runs the runtime-parameterised kernel (f64 with a factor 11
- *     or 13: up to 2048 points); the rest of the family takes Bluestein
- *   2^a * 3^b, a < 12, beyond the LDS limit         one Stockham pass per radix in global memory (27 / 9 / 3, then 16 / 8 / 4 / 2)
- *   every other length                              Bluestein over a power-of-two inner transform
- * `fourier_hip_describe_*` names the route a handle took ("stockham 1024x1024", "stockham mixed-radix 5.5.5.8",
- * "stockham global-pass 27.27.27.3", "bluestein M=... inner ..."); rely on it, not on this list, where the accuracy class
- * (direct versus chirp-z) matters.  NULL on failure. */
+ * tolerance).  The routes, in the order they are tried (fourier_amd/csrc/plan.h, Plan::Plan), with the string
+ * `fourier_hip_describe_*` returns for each (followed by " f32" / " f64"):
+ *   powers of two                                   "stockham <L1>[x<L2>[x<L3>]]", "stockham <L1>x<L2> one-launch", "stockham tiny(<n>)":
+ *                                                   big-radix Stockham passes, one, two or three HBM round trips
+ *   2^a * 3^b, a >= 12, N = L1 x L2 with both tile  "stockham mixed tiles <L1>x<L2>": two column-tile passes of mixed length
+ *     lengths <= 384 (12288 ... 147456)
+ *   2^a * 3^b, a >= 12, every other length          "stockham <L1>x...x<27|9|3>": the power-of-two passes over 2^a, then radix-27 / 9 / 3 passes
+ *   2^a * 3^b * 5^c * 7^d * 11^e * 13^f that fit    "stockham mixed-radix <r1>.<r2>...." (+ " specialised" for a kernel compiled at run time):
+ *     one compute unit's LDS (<= 20480 points in    every 2^a * 3^b; every such length with factors 5 (and the instantiated ones with a
+ *     f32, 10240 in f64) AND have a kernel          factor 7) has a per-length kernel; any other length of this family up to 8192 points runs
+ *                                                   the runtime-parameterised kernel (f64 with a factor 11 or 13: up to 2048 points)
+ *   2^a * 3^b, a < 12, beyond the LDS limit, with   "stockham mixed tiles <L1>x<L2>[x<L3>]": two or three column-tile passes of mixed length
+ *     N = L1 x L2 (x L3), every L in 64 ... 512
+ *   2^a * 3^b, a < 12, without such a factorisation "stockham global-pass <r1>.<r2>....": one Stockham pass per radix in global memory
+ *   2^a * 3^b * 5^c * 7^d with c + d >= 1 beyond    "stockham mixed tiles <L1>x<L2>[x<L3>]" (round 5; 10^5 = 400x250, 44100 = 210x210,
+ *     the LDS kernels, N = L1 x L2 (x L3), every      10^6 = 100x100x100): column-tile passes whose lengths have prime factors up to 7
+ *     L in 64 ... 512
+ *   prime factors up to 13, no route above, and     "stockham mixed-radix ... specialised" / "stockham mixed tiles ... specialised": kernels
+ *     its run-time kernels in the code-object cache   compiled by an earlier "specialise" (below) -- see fourier_hip_set_default_option
+ *   every other length                              "bluestein M=<M> inner <power-of-two plan>[ fused]": chirp-z over a power-of-two transform
+ * Rely on `fourier_hip_describe_*`, not on this list, where the accuracy class (direct versus chirp-z) matters.  NULL on failure. */
 struct fourier_fft_float *fourier_hip_create_float(FOURIER_SIZE_TYPE size, int device);
 struct fourier_fft_double *fourier_hip_create_double(FOURIER_SIZE_TYPE size, int device);
 
@@ -163,15 +172,17 @@ int fourier_hip_last_status_float(const FOURIER_STRUCT fourier_fft_float *);
 int fourier_hip_last_status_double(const FOURIER_STRUCT fourier_fft_double *);
 const char *fourier_hip_status_string(int status);
 
-/* Tunables (return FOURIER_HIP_OK or FOURIER_HIP_INVALID_ARGUMENT; "specialise" also FOURIER_HIP_UNSUPPORTED):
+/* Tunables (return FOURIER_HIP_OK or FOURIER_HIP_INVALID_ARGUMENT; "specialise" also FOURIER_HIP_UNSUPPORTED).  A handle is Send, not
+ * Sync, as in the reference (RefCell scratch, autosort/mod.rs:54): fourier_hip_set_option_* must not run concurrently with a
+ * transform or another call on the SAME handle ("specialise" swaps the engine the plan executes with).
  *   "chunk_bytes"  bytes of one batch chunk pushed through all passes before the next chunk starts
  *                  (keeps the inter-pass intermediate inside the 256 MiB Infinity Cache); 0 = whole batch
  *   "scratch"      1 = always route the intermediate through the plan's reused scratch buffer,
  *                  0 = use the output buffer as intermediate when out of place (default)
  *   "xcd_swizzle"  1 (default) = XCD-aware workgroup->tile mapping (each XCD owns a contiguous run of transforms),
  *                  2 = XCDs interleaved over adjacent transforms, 3 = each XCD owns an eighth of every transform's
- *                  tiles, 4 = contiguous transforms per XCD walked band-major (all measured slower or equal, kept
- *                  for experiments), 0 = plain blockIdx order
+ *                  tiles, 4 = contiguous transforms per XCD walked band-major (the others measured slower or equal,
+ *                  4 is "tile_walk" with bands of an eighth of a row), 0 = plain blockIdx order
  *   "bluestein_fusion" 1 (default where the inner FFT has >= 2 passes) = chirp steps fused into the inner passes
  *   "host_chunk_bytes" bytes of one chunk of fourier_hip_transform_batch_host_* (default 32 MiB, four in flight)
  *   "bluestein_conv"   1 (default with bluestein_fusion) = the forward inner FFT's last pass, the multiply by the
@@ -188,8 +199,12 @@ const char *fourier_hip_status_string(int status);
  *                  FOURIER_HIP_UNSUPPORTED -- the plan keeps its route -- for any other length, where libhiprtc is not
  *                  installed, or where the compilation fails.  Beyond the LDS limit (up to 2^26 points) the option replaces a
  *                  Bluestein plan by two or three column-tile passes whose lengths have prime factors up to 13 (10^5 = 400 x 250,
- *                  44100 = 210 x 210), compiled the same way, where such a factorisation exists.  Never happens implicitly: creating a plan and transforming
- *                  never compile anything.  Same tolerance class as the default route, not the same bits.
+ *                  44100 = 210 x 210), compiled the same way, where such a factorisation exists.  Compiled code objects are kept in an
+ *                  on-disk cache (below), so a length costs its second once per machine.  Compilation never happens implicitly unless
+ *                  the library-wide default "specialise_at_create" is raised to 2 (fourier_hip_set_default_option).  Same tolerance
+ *                  class as the default route, not the same bits.
+ *   "tile_walk"    order in which an XCD walks the column tiles of its transforms: tiles per band | transforms per group << 8 | 1 << 19
+ *                  for transform-fastest; 0 = tile-major (the default except f32 N = 2^20, which walks bands of eight tiles)
  *   "l2_fused"     (lib/libfourier_experiments.so only; INVALID_ARGUMENT in the product library; so is
  *                  "last_pass_prefetch", the persistent prefetching last pass of DESIGN.md section 4) 1 = run both
  *                  passes of a two-pass plan in ONE launch with the intermediate parked in the XCD's L2 (persistent
@@ -200,6 +215,24 @@ const char *fourier_hip_status_string(int status);
  *                  windows per XCD) and "l2_fused_grid" (persistent workgroups) tune it. */
 int fourier_hip_set_option_float(FOURIER_STRUCT fourier_fft_float *, const char *key, long long value);
 int fourier_hip_set_option_double(FOURIER_STRUCT fourier_fft_double *, const char *key, long long value);
+
+/* Library-wide defaults for plans created AFTERWARDS (any thread; plans that exist keep what they have).  The one key:
+ *   "specialise_at_create"  what `create` does for a length whose prime factors stop at 13 and that has no ahead-of-time route
+ *                  (it would run the runtime-parameterised LDS kernel or Bluestein):
+ *                    0  nothing: run-time kernels only through fourier_hip_set_option_*(h, "specialise", 1)
+ *                    1  (default) load its specialised kernels where the on-disk code-object cache holds ALL of them (a few
+ *                       milliseconds; nothing is ever compiled implicitly) -- a length specialised once is fast in every later process
+ *                    2  ... and compile what the cache lacks (hipRTC, about a second per new length and machine, inside `create`)
+ *                  so that a drop-in caller of fourier_create_float / create_fft_f32 reaches the specialised kernels with one call at
+ *                  start-up, or with NO code change through the environment variable FOURIER_HIP_SPECIALISE=0|1|2 (read once, before the
+ *                  first plan; the function overrides it).
+ * Environment the library reads, all of it: FOURIER_HIP_VERBOSE (error text on stderr), FOURIER_HIP_SPECIALISE (above) and the
+ * location of the code-object cache: $FOURIER_HIP_CACHE_DIR, else $XDG_CACHE_HOME/fourier-hip, else $HOME/.cache/fourier-hip (an EMPTY
+ * FOURIER_HIP_CACHE_DIR switches the disk cache off).  Cache files are keyed by device architecture, precision, kernel kind, length
+ * and a hash of the embedded kernel sources and compile options: a library update never loads a stale kernel.
+ * Returns FOURIER_HIP_OK or FOURIER_HIP_INVALID_ARGUMENT (unknown key / value); _get_ returns the value or -1. */
+int fourier_hip_set_default_option(const char *key, long long value);
+long long fourier_hip_get_default_option(const char *key);
 
 /* Human-readable plan description ("stockham 1024x1024 ..."), valid until the handle is destroyed. */
 const char *fourier_hip_describe_float(const FOURIER_STRUCT fourier_fft_float *);

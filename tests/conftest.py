@@ -9,6 +9,16 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+# Hermetic plans: the library's default ("specialise_at_create" = 1) makes `create` pick up run-time kernels that an earlier
+# test -- or an earlier run on this machine -- left in the on-disk code-object cache.  The suite pins the policy to 0 (read once,
+# before the first plan) and points the cache at a directory of its own; the tests of the cache and of the policy set both
+# themselves (fourier_hip_set_default_option / subprocesses).
+import tempfile  # noqa: E402
+
+os.environ.setdefault("FOURIER_HIP_SPECIALISE", "0")
+os.environ.setdefault("FOURIER_HIP_CACHE_DIR", tempfile.mkdtemp(prefix="fourier-hip-test-cache-"))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 

@@ -20,7 +20,7 @@ def declared_symbols():
     text = open(os.path.join(ROOT, "include", "fourier.h")).read()
     text = text[: text.index("Header-only C++ RAII wrapper")]
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(fourier_(?:hip_)?[a-z_]+_(?:float|double)|fourier_hip_status_string)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(fourier_(?:hip_)?[a-z_]+_(?:float|double)|fourier_hip_status_string|fourier_hip_[sg]et_default_option)\s*\(", text)))
 
 
 def test_header_declares_the_reference_abi():

@@ -7,6 +7,7 @@ Tolerances (SURVEY.md section 8c / BASELINE.md section 3):
   f32 pow2 (N=4096, 2^20, 2^22): rel-L2 <= 1e-6, max <= 2e-6*max|X| ; f64 N=2^20: 5e-14 / 1e-13
   Bluestein f32 N=999983: rel-L2 <= 2e-6, max <= 4e-6*max|X|
 """
+import json
 import os
 
 import numpy as np
@@ -240,7 +241,7 @@ def test_bluestein_fusion_matches_unfused(torch, fa):
             assert np.array_equal(gpu_batch(torch, fa, fused, x, code, inplace=True), a), (n, code)
 
 
-@pytest.mark.parametrize("n,dtype,tol", [(20002, np.complex64, 2e-6), (40000, np.complex64, 2e-6), (65537, np.complex64, 2e-6),
+@pytest.mark.parametrize("n,dtype,tol", [(20002, np.complex64, 2e-6), (40001, np.complex64, 2e-6), (65537, np.complex64, 2e-6),
                                          (999983, np.complex64, 2e-6), (2200000, np.complex64, 2e-6),
                                          (10001, np.complex128, 5e-11), (70001, np.complex128, 5e-11),
                                          (999983, np.complex128, 1e-9)])
@@ -705,7 +706,7 @@ def test_independent_plans_on_concurrent_host_threads(torch, fa, oracle):
     (ctypes drops the GIL around the calls); every result must match the single-threaded one."""
     import threading
 
-    sizes = [1 << 16, 40000, 4096, 729]
+    sizes = [1 << 16, 40001, 4096, 729]
     xs = {n: np.stack([hash_uniform(300 + b, n) for b in range(4)]).astype(np.complex64) for n in sizes}
     refs = {n: gpu_batch(torch, fa, make(fa, n, np.complex64), xs[n], 0) for n in sizes}
     errors = []
@@ -760,7 +761,7 @@ def test_batched_transform_is_graph_capturable(torch, fa, oracle):
     """After a warm-up call (which sizes the plan's scratch), the batched entry point is pure stream-ordered
     launches: it can be captured into a HIP graph and replayed on new data (pow2 two-pass, one-launch and
     Bluestein conv plans)."""
-    for n in (1 << 16, 4096, 40000):
+    for n in (1 << 16, 4096, 40001):
         plan = make(fa, n, np.complex64)
         x0 = np.stack([hash_uniform(900 + b, n) for b in range(3)]).astype(np.complex64)
         x1 = np.stack([hash_uniform(950 + b, n) for b in range(3)]).astype(np.complex64)
@@ -863,7 +864,7 @@ def test_error_behaviour(torch, fa):
     with pytest.raises(TypeError):
         plan.fft_in_place(torch.zeros(8, dtype=torch.complex128, device="cuda"))
     # empty batch: a successful no-op for every plan family
-    for n, opts in ((8, ()), (4096, ()), (1 << 16, ()), (96, ()), (3 * 4096, ()), (100, ()), (102, ()), (40000, ())):
+    for n, opts in ((8, ()), (4096, ()), (1 << 16, ()), (96, ()), (3 * 4096, ()), (100, ()), (102, ()), (40001, ())):
         p = fa.create_fft_f32(n)
         for k, v in opts:
             p.set_option(k, v)
@@ -1110,6 +1111,99 @@ def test_prefetching_last_pass_matches_the_plain_last_pass(torch, fa, fa_exp, or
         torch.cuda.empty_cache()
 
 
+def test_lengths_with_factors_5_and_7_beyond_the_lds_kernels_run_as_tile_passes_by_default(torch, fa, oracle):
+    """Round 5: tile-pass kernels for every length 64 ... 512 whose prime factors stop at 7 are compiled ahead of time, so that the
+    lengths the reference sends to Bluestein (fourier/src/lib.rs:38-42) but that factor into two or three such tile lengths take
+    direct Stockham passes from plain create_fft_*: 10^5, 44100, 48000, 96000, 10^6, 9800 (between the runtime kernel's reach and
+    the LDS limit), a ragged case (tile length without a factor 16).  Values against the oracle (chirp-z) and the f64 truth."""
+    for n, dtype, want in ((100000, np.complex64, "400x250"), (44100, np.complex64, "210x210"), (1000000, np.complex64, "100x100x100"),
+                           (48000, np.complex64, None), (96000, np.complex64, None), (9800, np.complex64, "100x98"), (30870, np.complex64, None),
+                           (100000, np.complex128, "400x250"), (44100, np.complex128, "210x210"), (5 * 7 * 7 * 7 * 7 * 3, np.complex128, None)):
+        plan = make(fa, n, dtype)
+        d = plan.describe()
+        assert "stockham mixed tiles" in d and "specialised" not in d, (n, d)
+        if want:
+            assert "mixed tiles " + want in d, (n, d)
+        x = np.stack([hash_normal(2700 + b, n) for b in range(3)]).astype(dtype)
+        tol = 2e-6 if dtype == np.complex64 else 1e-9  # f64: the ORACLE's unreduced chirp angle (bluesteins.rs:10,31,57)
+        for code in range(5):
+            ref = oracle.transform_batch(x, code)
+            a = gpu_batch(torch, fa, plan, x, code)
+            assert rel_l2(a, ref) <= tol, (n, dtype, code, rel_l2(a, ref))
+            assert rel_l2(gpu_batch(torch, fa, plan, x, code, inplace=True), ref) <= tol, (n, dtype, code)
+        truth = torch.fft.fft(torch.from_numpy(x).to(torch.complex128)).numpy()
+        assert rel_l2(gpu_batch(torch, fa, plan, x, 0), truth) <= (4e-7 if dtype == np.complex64 else 3e-15), (n, dtype)
+
+
+def test_code_object_cache_and_the_library_wide_specialise_policy(torch, fa, oracle, tmp_path, monkeypatch):
+    """Round 5: a drop-in caller reaches the specialised kernels without a per-handle call.
+    "specialise_at_create" = 2 (fourier_hip_set_default_option, or FOURIER_HIP_SPECIALISE=2 in the environment of a program that
+    cannot be changed) compiles a length's own kernel inside create and leaves the code object in the on-disk cache; the default
+    policy 1 loads it from there in any later process -- in milliseconds, without libhiprtc --, policy 0 never does; a cache file
+    that cannot be loaded is discarded and compiled again."""
+    import shutil
+    import subprocess
+    import sys
+
+    if not (os.path.exists("/opt/rocm/lib/libhiprtc.so") or shutil.which("hipcc")):
+        pytest.skip("libhiprtc not installed")
+    cache = tmp_path / "co-cache"
+    monkeypatch.setenv("FOURIER_HIP_CACHE_DIR", str(cache))
+    prev = fa.get_default_option("specialise_at_create")
+    try:
+        fa.set_default_option("specialise_at_create", 0)
+        assert "specialised" not in make(fa, 5005, np.complex64).describe()
+        fa.set_default_option("specialise_at_create", 1)  # cache only: the cache is empty, nothing may be compiled
+        assert "specialised" not in make(fa, 5005, np.complex64).describe() and not (cache.exists() and list(cache.iterdir()))
+        fa.set_default_option("specialise_at_create", 2)
+        for n, dtype, kind in ((5005, np.complex64, "mixed-radix"), (1001, np.complex128, "mixed-radix"), (9009, np.complex64, "mixed-radix"),
+                               (57200, np.complex64, "mixed tiles")):
+            plan = make(fa, n, dtype)
+            assert kind in plan.describe() and "specialised" in plan.describe(), plan.describe()
+            x = np.stack([hash_normal(2800 + b, n) for b in range(5)]).astype(dtype)
+            assert rel_l2(gpu_batch(torch, fa, plan, x, 0), oracle.transform_batch(x, 0)) <= (2e-6 if dtype == np.complex64 else 5e-11)
+        assert make(fa, 1013, np.complex64).describe().startswith("bluestein")  # not of the family: its default route, no error
+        files = sorted(p.name for p in cache.iterdir())
+        assert len(files) == 5 and all(f.endswith(".co") and "gfx950" in f for f in files), files  # 57200 = 260 x 220: two tile kernels
+        with pytest.raises(fa.FourierError):
+            fa.set_default_option("specialise_at_create", 3)
+        with pytest.raises(fa.FourierError):
+            fa.set_default_option("no_such_key", 1)
+    finally:
+        fa.set_default_option("specialise_at_create", prev)
+    # later processes: the default policy (no variable), policy 0, policy 2 on a length the cache does not hold; timing of a cache hit
+    prog = ("import os, sys, time, json; sys.path.insert(0, %r); import fourier_amd as fa\n"
+            "fa.create_fft_f32(4096)\n"  # the HIP runtime and the library are up before the clock starts
+            "t0 = time.perf_counter(); p = fa.create_fft_f32(5005); dt = time.perf_counter() - t0\n"
+            "print(json.dumps({'d5005': p.describe(), 'create_s': dt, 'd3003': fa.create_fft_f32(3003).describe(), 'policy': fa.get_default_option('specialise_at_create')}))\n"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    def child(policy):
+        env = {k: v for k, v in os.environ.items() if k != "FOURIER_HIP_SPECIALISE"}
+        env["FOURIER_HIP_CACHE_DIR"] = str(cache)
+        if policy is not None:
+            env["FOURIER_HIP_SPECIALISE"] = policy
+        out = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    r = child(None)
+    assert r["policy"] == 1 and "specialised" in r["d5005"] and "specialised" not in r["d3003"], r
+    assert r["create_s"] < 0.25, r  # a cache hit: read 1 file, load 1 module (a compilation takes about a second)
+    r = child("0")
+    assert r["policy"] == 0 and "specialised" not in r["d5005"], r
+    r = child("2")
+    assert "specialised" in r["d5005"] and "specialised" in r["d3003"], r
+    # a damaged cache file is discarded, not trusted
+    victim = next(p for p in cache.iterdir() if "-n5005-" in p.name)
+    victim.write_bytes(b"FOURIER-HIP-CO-1\nnot_a_kernel\n" + b"\x00" * 100)
+    fa.set_default_option("specialise_at_create", 1)
+    try:
+        # the process cache still holds the kernel of this process; a fresh process must fall back to its default route, silently
+        r = child(None)
+        assert "specialised" not in r["d5005"] and not victim.exists(), r
+    finally:
+        fa.set_default_option("specialise_at_create", prev)
+
+
 def test_plan_option_specialise_compiles_the_lengths_own_kernel_with_hiprtc(torch, fa, oracle):
     """Plan option "specialise" (rtc.cpp): a length whose prime factors stop at 13 but that has no ahead-of-time per-length
     kernel gets mixed_radix_kernel_ct<T, n> compiled with hipRTC on request.  Lengths on the runtime-parameterised kernel
@@ -1139,9 +1233,10 @@ def test_plan_option_specialise_compiles_the_lengths_own_kernel_with_hiprtc(torc
             assert rel_l2(a, ref) <= tol, (n, dtype, code, rel_l2(a, ref))
             assert rel_l2(gpu_batch(torch, fa, base, x, code), a) <= tol, (n, dtype, code)
             assert np.array_equal(gpu_batch(torch, fa, spec, x, code, inplace=True), a), (n, dtype, code)
-    # beyond one compute unit's LDS: column-tile passes whose lengths may have prime factors up to 13 (Bluestein by default)
-    for n, dtype, want in ((100000, np.complex64, "400x250"), (44100, np.complex64, "210x210"), (1000000, np.complex64, "100x100x100"),
-                           (100000, np.complex128, "400x250")):
+    # beyond one compute unit's LDS: column-tile passes whose lengths may have prime factors up to 13 (Bluestein by default where a
+    # tile length has a factor 11 or 13: the ahead-of-time tile kernels stop at 7)
+    for n, dtype, want in ((143000, np.complex64, "440x325"), (57200, np.complex64, "260x220"),
+                           (143000, np.complex128, "440x325")):
         x = np.stack([hash_normal(2600 + b, n) for b in range(3)]).astype(dtype)
         base, spec = make(fa, n, dtype), make(fa, n, dtype)
         assert "bluestein" in base.describe()
@@ -1155,6 +1250,11 @@ def test_plan_option_specialise_compiles_the_lengths_own_kernel_with_hiprtc(torc
             assert rel_l2(gpu_batch(torch, fa, spec, x, code, inplace=True), ref) <= tol, (n, dtype, code)
         truth = torch.fft.fft(torch.from_numpy(x).to(torch.complex128)).numpy()
         assert rel_l2(gpu_batch(torch, fa, spec, x, 0), truth) <= (4e-7 if dtype == np.complex64 else 3e-15), (n, dtype)
+    # a plan on ahead-of-time tile passes has nothing to specialise: OK, unchanged
+    plan = make(fa, 100000, np.complex64)
+    desc = plan.describe()
+    plan.set_option("specialise", 1)
+    assert plan.describe() == desc and "specialised" not in desc
     for n in (1013, 17017, 4096, 999983):  # not of the family (17017 = 17 * 1001): refused, and the plan is untouched
         plan = make(fa, n, np.complex64)
         desc = plan.describe()
