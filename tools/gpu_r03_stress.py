@@ -19,12 +19,15 @@ def _smooth(limit, primes):
         vals = {v * p ** e for v in vals for e in range(0, 16) if v * p ** e <= limit}
     return vals
 smooth13 = sorted(v for v in _smooth(18432, [2, 3, 5, 7, 11, 13]) if any(v % p == 0 for p in (5, 7, 11, 13)))  # the prime-radix LDS kernels
+# round 5: lengths with factors 5 / 7 beyond the LDS kernels (ahead-of-time tile passes): a random 120 of the 7-smooth lengths up to 3e6
+smooth7_big = sorted(v for v in _smooth(3_000_000, [2, 3, 5, 7]) if v > 8192 and (v % 5 == 0 or v % 7 == 0))
+smooth7_big = sorted({int(v) for v in rng.choice(smooth7_big, size=min(120, len(smooth7_big)), replace=False)})
 others = sorted({int(v) for v in np.concatenate([rng.integers(2, 5000, 150), rng.integers(5000, 200000, 80), rng.integers(200000, 3000000, 25)])})
 worst = {}
 fails = 0
 t0 = time.time()
 count = 0
-for n in smooth + smooth13 + others:
+for n in smooth + smooth13 + smooth7_big + others:
     for dtype, tol in ((np.complex64, 2e-6), (np.complex128, 1e-9 if n > 100000 else 5e-11)):
         if dtype == np.complex128 and rng.random() < 0.5:
             continue
