@@ -60,6 +60,7 @@ mod hip {
         fn fourier_hip_last_status_float(p: *const FourierFftFloat) -> c_int;
         fn fourier_hip_last_status_double(p: *const FourierFftDouble) -> c_int;
         fn fourier_hip_status_string(status: c_int) -> *const c_char;
+        fn fourier_hip_set_default_option(key: *const c_char, value: i64) -> c_int;
     }
 
     /// Inverse of `convert_transform` (fourier-ffi/src/lib.rs:3-12).
@@ -85,6 +86,23 @@ mod hip {
         }
         let message = unsafe { std::ffi::CStr::from_ptr(fourier_hip_status_string(status)) }.to_string_lossy().into_owned();
         Err(HipError { status, message })
+    }
+
+    /// Library-wide policy for plans created afterwards (include/fourier.h, `fourier_hip_set_default_option`): what `create_fft_*`
+    /// does for a length whose prime factors stop at 13 and that has no ahead-of-time route.
+    #[derive(Debug, Clone, Copy, PartialEq, Eq)]
+    pub enum SpecialiseAtCreate {
+        /// run-time kernels are never picked up by `create`
+        Never = 0,
+        /// (the library's default) load them where the on-disk code-object cache holds them; nothing is compiled implicitly
+        FromCache = 1,
+        /// ... and compile what the cache lacks, inside `create` (about a second per new length and machine)
+        Compile = 2,
+    }
+    /// One call at start-up gives every later `create_fft_f32/f64` the specialised kernels (the environment variable
+    /// `FOURIER_HIP_SPECIALISE=0|1|2` does the same for a program that cannot be changed).
+    pub fn set_specialise_at_create(policy: SpecialiseAtCreate) -> Result<(), HipError> {
+        check(unsafe { fourier_hip_set_default_option(b"specialise_at_create\0".as_ptr() as *const c_char, policy as i64) })
     }
 
     macro_rules! hip_plan {
@@ -184,7 +202,7 @@ mod hip {
 }
 
 #[cfg(feature = "hip")]
-pub use hip::{HipError, HipFft32, HipFft64};
+pub use hip::{set_specialise_at_create, HipError, HipFft32, HipFft64, SpecialiseAtCreate};
 
 /// Create a complex-valued FFT over `f32` with the specified size (signature of `fourier/src/lib.rs:31`).
 #[cfg(feature = "hip")]

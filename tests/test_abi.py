@@ -108,7 +108,7 @@ def test_rust_shim_names_only_exported_symbols(libpath):
     block = src[src.index('extern "C" {'):]
     block = block[:block.index("\n    }")]
     names = set(re.findall(r"fn (fourier_\w+)\(", block))
-    assert len(names) == 21, sorted(names)
+    assert len(names) == 22, sorted(names)
     exported = set(subprocess.run(["nm", "-D", "--defined-only", libpath], capture_output=True, text=True).stdout.split())
     header = open(os.path.join(root, "include", "fourier.h")).read()
     for n in sorted(names):

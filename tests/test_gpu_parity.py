@@ -995,9 +995,16 @@ def test_lengths_with_prime_factors_5_to_13_run_as_stockham_passes(torch, fa, or
         per_length = (m == 1 or n in (49, 343, 2401, 16807)) and n * np.dtype(dtype).itemsize <= 160 * 1024  # 2^a*3^b*5^c, 7^k
         f64_wide_13 = dtype == np.complex128 and n > 2048 and (n % 11 == 0 or n % 13 == 0)  # does not fit the registers
         if not per_length and (n > 8192 or f64_wide_13):  # the runtime-parameterised kernel stops at 8192 points
-            assert "bluestein" in plan.describe(), plan.describe()
-            continue
-        assert plan.describe().startswith("stockham mixed-radix"), plan.describe()
+            m7 = n
+            while m7 % 2 == 0 or m7 % 3 == 0 or m7 % 5 == 0 or m7 % 7 == 0:
+                m7 //= 2 if m7 % 2 == 0 else (3 if m7 % 3 == 0 else (5 if m7 % 5 == 0 else 7))
+            if m7 != 1:  # a factor 11 / 13 beyond the LDS kernels
+                assert "bluestein" in plan.describe(), plan.describe()
+                continue
+            # round 5: prime factors up to 7 beyond the LDS kernels -- ahead-of-time tile passes (f64 15625 = 125 x 125, 20480 = 160 x 128)
+            assert plan.describe().startswith("stockham mixed tiles"), plan.describe()
+        else:
+            assert plan.describe().startswith("stockham mixed-radix"), plan.describe()
         xs = np.tile(x.astype(dtype), ((batch + 6) // 7, 1))[:batch]
         truth = np.fft.fft(x.astype(np.complex128), axis=1)
         for code in range(5):

@@ -2,7 +2,7 @@
 # Round 3: HBM-side traffic counters for the BASELINE configurations that had none (C3, C4, C5 chunk), per kernel.
 # Separate rocprofv3 --pmc passes (FETCH_SIZE needs 3 of the 4 TCC slots, WRITE_SIZE 2; MI355X_MICROARCH.md), no trace
 # domains next to --pmc.  Output: gpurun_out/pmc_<cfg>_<set>/..., summary gpurun_out/pmc_traffic_<cfg>.json
-# (tools/collect_profiles.py-style correction: KB units, FETCH_SIZE x 2 on gfx950 for 16 B/lane streams).
+# (the correction of /opt/skills/guides/MI355X_MICROARCH.md: KB units, FETCH_SIZE x 2 on gfx950 for 16 B/lane streams).
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out

@@ -2,7 +2,7 @@
 # Round 5 evidence session: parity at HEAD, smoke, bench (default line with the streaming ceiling and the flat per-config scalars;
 # f64; C5 full job through a 1-rank RCCL group), rocprofv3 kernel trace over the default bench and the other BASELINE
 # configurations, the PMC traffic passes (one counter set per run) over C2 / C3 / C4 / C5 chunk, the size sweeps, one stress seed.
-# Everything lands in gpurun_out/ (tools/collect_profiles.py copies it to profiles/r05_<session>_*).
+# Everything lands in gpurun_out/ (tools/collect_session.sh <tag> copies it to profiles/<tag>_*).
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
