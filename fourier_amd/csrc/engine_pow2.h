@@ -121,6 +121,10 @@ template <typename T> class Pow2Engine {
       // length 2048) instead of three at 256 x 256 x 128.  f32: 27.4-30.0 vs 34.1-34.8 ms per 512 transforms (default);
       // f64: 30.8-35.2 vs 33.5-33.8 ms per 256, no consistent gain (opt-in) -- profiles/r02_s16_plan_2p23_ab.jsonl
       lens = {12, 11};
+    } else if (k == 20 && plain && p3 == 1 && dev_env("FOURIER_PLAN_2048x512")) {
+      // experiment (round 5): 2^20 = 2048 x 512 instead of 1024 x 1024 -- row strides of 4 KiB (first pass) and 16 KiB (last pass) instead
+      // of 8 KiB + 8 KiB, the stride the column-tile copy streams slowest at (profiles/r05_s6_stride_bench.jsonl)
+      lens = {11, 9};
     } else if (k <= 22) {
       lens = {(k + 1) / 2, k / 2};
     } else if (k <= 30) {

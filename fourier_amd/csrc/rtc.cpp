@@ -98,10 +98,21 @@ uint64_t sources_hash() {
 std::string cache_file(int dev, bool f64, uint32_t n, size_t lds_bytes, bool tile_pass) {
   const std::string dir = cache_dir();
   if (dir.empty()) return std::string();
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return std::string(); }
-  std::string arch = prop.gcnArchName;
-  for (char& c : arch) if (!isalnum((unsigned char)c)) c = '_';
+  static std::mutex mu;
+  static std::map<int, std::string> archs;  // device -> its architecture string (a property query costs about a millisecond)
+  std::string arch;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = archs.find(dev);
+    if (it == archs.end()) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return std::string(); }
+      std::string a = prop.gcnArchName;
+      for (char& c : a) if (!isalnum((unsigned char)c)) c = '_';
+      it = archs.emplace(dev, a).first;
+    }
+    arch = it->second;
+  }
   char hash[24];
   snprintf(hash, sizeof hash, "%016llx", (unsigned long long)sources_hash());
   return dir + "/" + arch + "-" + (f64 ? "f64" : "f32") + "-" + (tile_pass ? "tile" : "whole") + "-n" + std::to_string(n) + "-lds" + std::to_string(lds_bytes) + "-" + hash + ".co";

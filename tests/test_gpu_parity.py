@@ -1199,6 +1199,13 @@ def test_code_object_cache_and_the_library_wide_specialise_policy(torch, fa, ora
     assert r["policy"] == 0 and "specialised" not in r["d5005"], r
     r = child("2")
     assert "specialised" in r["d5005"] and "specialised" in r["d3003"], r
+    # a cache directory that cannot be created, or none at all (empty variable): compilation still works, nothing is cached
+    for bad in ("/proc/fourier-hip-no-such-dir/x", ""):
+        env = {k: v for k, v in os.environ.items() if k != "FOURIER_HIP_SPECIALISE"}
+        env.update(FOURIER_HIP_CACHE_DIR=bad, FOURIER_HIP_SPECIALISE="2")
+        out = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert "specialised" in json.loads(out.stdout.strip().splitlines()[-1])["d5005"], (bad, out.stdout)
     # a damaged cache file is discarded, not trusted
     victim = next(p for p in cache.iterdir() if "-n5005-" in p.name)
     victim.write_bytes(b"FOURIER-HIP-CO-1\nnot_a_kernel\n" + b"\x00" * 100)
