@@ -998,7 +998,15 @@ def test_lengths_with_prime_factors_5_to_13_run_as_stockham_passes(torch, fa, or
             m7 = n
             while m7 % 2 == 0 or m7 % 3 == 0 or m7 % 5 == 0 or m7 % 7 == 0:
                 m7 //= 2 if m7 % 2 == 0 else (3 if m7 % 3 == 0 else (5 if m7 % 5 == 0 else 7))
-            if m7 != 1:  # a factor 11 / 13 beyond the LDS kernels
+            def _s7(v):
+                for p in (2, 3, 5, 7):
+                    while v % p == 0:
+                        v //= p
+                return v == 1
+            menu = [L for L in range(64, 513) if _s7(L)]
+            tiles2 = any(n % a == 0 and 64 <= n // a <= a and _s7(n // a) for a in menu)
+            tiles3 = any(n % a == 0 and (n // a) % b == 0 and 64 <= n // a // b <= b <= a and _s7(n // a // b) for a in menu for b in menu)
+            if m7 != 1 or not (tiles2 or tiles3):  # a factor 11 / 13 beyond the LDS kernels, or no split into tile lengths (f64 7^5 = 343 x 49)
                 assert "bluestein" in plan.describe(), plan.describe()
                 continue
             # round 5: prime factors up to 7 beyond the LDS kernels -- ahead-of-time tile passes (f64 15625 = 125 x 125, 20480 = 160 x 128)
