@@ -96,12 +96,6 @@ template <typename T> struct alignas(8) Unit8 { T a[8 / sizeof(T)]; };     // on
 #ifndef FOURIER_ABLATE
 #define FOURIER_ABLATE 0
 #endif
-//   FOURIER_SETPRIO = 1: the waves of the tile kernels raise their issue priority (s_setprio 3) while they issue a tile's global
-//   loads and stores and drop it (0) for the in-tile transform, so that a workgroup in a memory phase is not held up by its
-//   CU-mate's butterflies.  A/B knob (profiles/r05_s1_*): see DESIGN.md
-#ifndef FOURIER_SETPRIO
-#define FOURIER_SETPRIO 0
-#endif
 //   FOURIER_SPLIT_THRESHOLD: exchange buffers above this many bytes are exchanged as two planes (re, im):
 //   half the LDS per workgroup, twice the workgroups per CU (16 KiB measured best over 2^8..2^20, r01 sweep)
 //   FOURIER_ROWS_STAGED: the shortest whole-transform kernels (f32 64, f64 32) move their data between global memory and
@@ -119,12 +113,6 @@ template <typename T> struct alignas(8) Unit8 { T a[8 / sizeof(T)]; };     // on
 #ifndef FOURIER_NT_STORE
 #define FOURIER_NT_STORE 2
 #endif
-
-template <int P> __device__ __forceinline__ void wave_priority() {
-#ifndef FOURIER_EMU
-  if constexpr (FOURIER_SETPRIO != 0) __builtin_amdgcn_s_setprio(P);
-#endif
-}
 
 // 16-byte global accesses (global_load_dwordx4 / global_store_dwordx4)
 template <typename T, bool NT> __device__ __forceinline__ Unit16<T> load_unit(const void* p) {

@@ -466,7 +466,6 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
   if constexpr (FOURIER_TABS_AFTER_LOADS == 0) fill_tabs();
 
   // ---- load: register r <- row th + Q*r
-  wave_priority<3>();
   cpx<T> x[VEC][16];
   constexpr bool STAGED = IN_ROWS && C::ROWS_STAGED;
   // staged rows: thread (th, cg) owns transform v*CG + cg of the tile (not cg*VEC + v), so that each half of the tile --
@@ -628,7 +627,6 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
   }
 
   // ---- in-tile DFT_L: register r <- row th + Q*r  ==>  register r holds output index k = th + Q*r
-  wave_priority<0>();
   tile_core<T, L, CG, MODE>(x, th, cg, tid, smem, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw2);
   // now register r holds output index k = th + Q*r of columns (cg*VEC + v)
   // ---- inter-pass twiddle W_size^{i*k} = W^{i*th} * tabU[col][r]
@@ -647,7 +645,6 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
 
   // ---- store
   before_store();
-  wave_priority<3>();
   const T scale = (T)a.scale;
   if constexpr (STAGED) {
     cpx<T>* stage = (cpx<T>*)smem;
@@ -805,22 +802,6 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
 #ifndef FOURIER_CONV_W_BATCH
 #define FOURIER_CONV_W_BATCH 8  // loads of the w table in flight per thread
 #endif
-// A/B knob: the second workgroup of every CU's FIRST resident pair (blocks 256 .. 511 of the grid: block b runs on XCD b % 8, an
-// XCD deals its first 32 blocks to its 32 CUs and the next 32 to the same CUs again) sleeps FOURIER_CONV_DEPHASE x 8128 cycles
-// before its first load, so that the two co-resident workgroups of a CU start half a tile period apart
-#ifndef FOURIER_CONV_DEPHASE
-#define FOURIER_CONV_DEPHASE 0
-#endif
-__device__ __forceinline__ void conv_dephase() {
-#ifndef FOURIER_EMU
-  if constexpr (FOURIER_CONV_DEPHASE != 0) {
-    if (blockIdx.x >= 256 && blockIdx.x < 512) {
-#pragma unroll 1
-      for (int i = 0; i < FOURIER_CONV_DEPHASE; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-  }
-#endif
-}
 // ---- Bluestein middle (bluesteins.rs:236-239): LAST pass of the forward inner FFT, (.) w, and FIRST pass of
 // the inverse inner FFT in ONE launch.  The last forward pass (R = L, s = M/L) leaves X[j + (M/L)*k] of its
 // column tile in registers; an inverse FFT whose first pass has the same length (R = L, s = 1, m = M/L) reads
@@ -855,8 +836,6 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16)
   if constexpr (FOURIER_TABS_AFTER_LOADS == 0) fill_tabs();
 
   // forward LAST pass: rows th + Q*r (stride cn) of columns c0 + cg*VEC + v
-  conv_dephase();
-  wave_priority<3>();
   cpx<T> x[VEC][16];
   int th = tid / CG, cg = tid % CG;
   {
@@ -871,10 +850,8 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16)
     }
   }
   if constexpr (FOURIER_TABS_AFTER_LOADS != 0) fill_tabs();
-  wave_priority<0>();
   tile_core<T, L, CG, MODE_LAST>(x, th, cg, tid, smem, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw2);
   // register r holds X[c + cn*(th + Q*r)]: (.) w (FFT'd chirp, 1/M folded in), then the inverse's leading swap
-  wave_priority<FOURIER_SETPRIO == 2 ? 3 : 0>();
   {
     int t = tid;
     FOURIER_LAUNDER(t);
@@ -896,7 +873,6 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16)
           }
         });
   }
-  wave_priority<0>();
   __syncthreads();  // every read of the last exchange is done before the buffer is rewritten
   // inverse FIRST pass on the same tile (columns i = c0 + ..., s = 1), thread mapping switches to th-fastest
   {
@@ -914,7 +890,6 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16)
     for (int r = 0; r < 16; ++r) x[v][r] = cmul(x[v][r], cmul(base, tu[r]));
   }
   // transposed store: column i's L outputs are contiguous
-  wave_priority<3>();
   if constexpr (VEC == 2 && Q % 2 == 0 && FOURIER_PAIRED_ROW_STORES != 0) {
     if constexpr (sizeof(T) == 4) {
       cpx<T>* p0 = out + (c0 + (uint64_t)(cg * VEC)) * L;

@@ -85,11 +85,6 @@ VARIANTS = {
     "abl3": ["-DFOURIER_ABLATE=3"],
     "abl4": ["-DFOURIER_ABLATE=4"],  # stage twiddles from a constant (no table loads inside the in-tile transform)
     "abl5": ["-DFOURIER_ABLATE=5"],  # per-thread inter-pass twiddle factor from a constant (no two-level look-up)
-    "setprio": ["-DFOURIER_SETPRIO=1"],
-    "setprio2": ["-DFOURIER_SETPRIO=2"],  # conv kernel: the w loads at high priority as well
-    "conv_dephase2": ["-DFOURIER_CONV_DEPHASE=2"],
-    "conv_dephase4": ["-DFOURIER_CONV_DEPHASE=4"],
-    "conv_dephase4_setprio": ["-DFOURIER_CONV_DEPHASE=4", "-DFOURIER_SETPRIO=1"],
 }
 
 
