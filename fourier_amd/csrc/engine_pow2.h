@@ -393,7 +393,7 @@ template <typename T> class Pow2Engine {
 
   void run(const cpx<T>* in, cpx<T>* out, cpx<T>* scratch, size_t batch, bool inverse, double scale, const cpx<T>* mul,
            bool force_scratch, hipStream_t stream, Profiler* prof = nullptr, int slot0 = 0, unsigned nxcd = 8,
-           BluIO blu = BluIO()) const {
+           BluIO blu = BluIO(), unsigned nxcd_last = 0) const {  // nxcd_last != 0: the tile order of the LAST pass alone
     if (batch == 0) return;
     // N = 16 (and f32 N = 32) also run one lane per transform; their ROWS pass only serves Bluestein M = 16 / 32
     const bool lane_per_transform = tiny_ || n_ == 16 || (n_ == 32 && sizeof(T) == 4);
@@ -429,7 +429,7 @@ template <typename T> class Pow2Engine {
       dst[np - 1] = out;
     }
     for (size_t p = 0; p < np; ++p)
-      launch_pass(p, src[p], dst[p], batch, inverse, scale, stream, prof, slot0 + (int)p, nxcd, blu);
+      launch_pass(p, src[p], dst[p], batch, inverse, scale, stream, prof, slot0 + (int)p, (nxcd_last && p + 1 == np && np >= 2) ? nxcd_last : nxcd, blu);
     apply_mul(out, batch, mul, inverse, scale, stream, prof, slot0 + (int)np - 1);
   }
 
@@ -482,7 +482,7 @@ template <typename T> class Pow2Engine {
       a.lo_bits = ps.lo_bits;
       a.nxcd = nxcd & 0xff;
       a.xcd_interleave = (nxcd >> 8) & 7;
-      a.walk_band = (nxcd >> 12) & 0xff; a.walk_group = (nxcd >> 20) & 0x7ff; a.walk_tf = nxcd >> 31;
+      a.walk_band = (nxcd >> 12) & 0xff; a.walk_group = (nxcd >> 20) & 0x3ff; a.walk_tf = nxcd >> 30;
       const bool blu_here = ps.has_blu && ((blu.io == IO_BLU_IN && p == 0) || (blu.io == IO_BLU_OUT && p + 1 == np));
       if (blu_here) {
         a.blu_x = blu.xtab; a.blu_n = blu.n; a.blu_swap = blu.swap;
@@ -573,7 +573,7 @@ template <typename T> class Pow2Engine {
     a.tiles = last.cn / conv_.COLS;
     a.nxcd = nxcd & 0xff;
     a.xcd_interleave = (nxcd >> 8) & 7;
-    a.walk_band = (nxcd >> 12) & 0xff; a.walk_group = (nxcd >> 20) & 0x7ff; a.walk_tf = nxcd >> 31;
+    a.walk_band = (nxcd >> 12) & 0xff; a.walk_group = (nxcd >> 20) & 0x3ff; a.walk_tf = nxcd >> 30;
     // this kernel (only) reads a per-transform table indexed like the data, the transformed chirp: let every XCD own an
     // eighth of the TILES of every transform, so that its 1/8 of the table (2 MiB of 16 at M = 2^21) stays in its L2
     // (with streaming stores: conv 4.5 vs 4.75 ms per 512 at C4; the plain passes lose 10-15 % under this order)

@@ -211,8 +211,9 @@ __device__ __forceinline__ uint32_t xcd_remap(const PassArgs& a, uint64_t blk64,
     if (tpx % g == 0) {
       const uint32_t per_group = g * tiles, grp = slot / per_group, rem = slot % per_group;
       const uint32_t per_band = g * bw, band = rem / per_band, rem2 = rem % per_band;
-      const uint32_t tr = a.walk_tf ? rem2 % g : rem2 / bw, tl = a.walk_tf ? rem2 / g : rem2 % bw;
-      return (xcd * tpx + grp * g + tr) * tiles + band * bw + tl;
+      const uint32_t tr = (a.walk_tf & 1) ? rem2 % g : rem2 / bw, tl = (a.walk_tf & 1) ? rem2 / g : rem2 % bw;
+      // (walk_tf bit 1, A/B: a band holds every (tiles / bw)-th tile instead of bw adjacent ones)
+      return (xcd * tpx + grp * g + tr) * tiles + ((a.walk_tf & 2) ? band + (tiles / bw) * tl : band * bw + tl);
     }
   }
   const uint32_t q = nwg / nx, r = nwg % nx;

@@ -184,9 +184,14 @@ template <typename T> class Plan {
     if (key == "xcd_swizzle" && v >= 0 && v <= 4) { nxcd_ = v == 0 ? 1 : (8 | ((unsigned)(v - 1) << 8)); return 0; }
     // the general band walk of the tile passes (xcd_remap mode 4): v = tiles per band | transforms per group << 8 (0 = the XCD's
     // whole range) | transform-fastest << 19; v = 0 restores the default order
-    if (key == "tile_walk" && v >= 0 && v < (1 << 20)) {
-      const unsigned band = (unsigned)v & 0xff, group = ((unsigned)v >> 8) & 0x7ff, tf = ((unsigned)v >> 19) & 1;
-      nxcd_ = band == 0 ? 8u : (8u | (4u << 8) | (band << 12) | (group << 20) | (tf << 31));
+    if (key == "tile_walk_last" && v >= 0 && v < (1 << 21)) {  // the same encoding, for the last pass of a plain multi-pass plan alone (0 = as the others)
+      const unsigned band = (unsigned)v & 0xff, group = ((unsigned)v >> 8) & 0x3ff, tf = ((unsigned)v >> 19) & 3;
+      nxcd_last_ = band == 0 ? 0u : (8u | (4u << 8) | (band << 12) | (group << 20) | (tf << 30));
+      return 0;
+    }
+    if (key == "tile_walk" && v >= 0 && v < (1 << 21)) {
+      const unsigned band = (unsigned)v & 0xff, group = ((unsigned)v >> 8) & 0x3ff, tf = ((unsigned)v >> 19) & 3;  // bit 20: strided bands (A/B)
+      nxcd_ = band == 0 ? 8u : (8u | (4u << 8) | (band << 12) | (group << 20) | (tf << 30));
       return 0;
     }
     if (key == "bluestein_fusion" && (v == 0 || v == 1)) {
@@ -354,7 +359,8 @@ template <typename T> class Plan {
     if (!blu_) {
       for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const size_t nb = std::min(chunk, batch - b0);
-        eng_->run(in + b0 * n_, out + b0 * n_, (cpx<T>*)scratch_.p, nb, inverse, scale, nullptr, force_scratch_, stream, prof, 0, nxcd_);
+        eng_->run(in + b0 * n_, out + b0 * n_, (cpx<T>*)scratch_.p, nb, inverse, scale, nullptr, force_scratch_, stream, prof, 0, nxcd_,
+                  typename Pow2Engine<T>::BluIO(), nxcd_last_);
       }
       return;
     }
@@ -666,7 +672,7 @@ template <typename T> class Plan {
   bool fused_ = false;  // Bluestein: chirp steps fused into the inner passes
   bool small_fused_ = false;  // Bluestein with M <= 2^15: everything in one launch
   bool conv_ = false, conv_ok_ = false;  // Bluestein: forward LAST + (.)w + inverse FIRST in one launch
-  unsigned nxcd_ = 8;
+  unsigned nxcd_ = 8, nxcd_last_ = 0;
   mutable int status_ = 0;
   std::string desc_;
 };

@@ -204,7 +204,9 @@ const char *fourier_hip_status_string(int status);
  *                  the library-wide default "specialise_at_create" is raised to 2 (fourier_hip_set_default_option).  Same tolerance
  *                  class as the default route, not the same bits.
  *   "tile_walk"    order in which an XCD walks the column tiles of its transforms: tiles per band | transforms per group << 8 | 1 << 19
- *                  for transform-fastest; 0 = tile-major (the default except f32 N = 2^20, which walks bands of eight tiles)
+ *                  for transform-fastest | 1 << 20 for strided bands (every (tiles / band)-th tile instead of adjacent ones; measured slower);
+ *                  0 = tile-major (the default except f32 N = 2^20, which walks bands of eight tiles).  "tile_walk_last": the same encoding
+ *                  for the LAST pass of a plain multi-pass plan alone (0 = as the other passes)
  *   "l2_fused"     (lib/libfourier_experiments.so only; INVALID_ARGUMENT in the product library; so is
  *                  "last_pass_prefetch", the persistent prefetching last pass of DESIGN.md section 4) 1 = run both
  *                  passes of a two-pass plan in ONE launch with the intermediate parked in the XCD's L2 (persistent

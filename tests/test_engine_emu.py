@@ -421,14 +421,14 @@ def test_chunking_and_scratch_options_do_not_change_results(fa):
             plan.set_option("xcd_swizzle", mode)
             assert np.array_equal(run_batch(plan, x2, 0), base2), (n2, batch2, mode)
         # the general band walk (round 5; the default order of f32 2^20): tiles per band | transforms per group << 8 | transform-fastest << 19
-        for walk in (1, 4, 8, 16, 4 | 1 << 8, 2 | 2 << 8, 8 | 1 << 19, 4 | 2 << 8 | 1 << 19, 3, 0):  # (3 does not divide the tiles: the plain order)
+        for walk in (1, 4, 8, 16, 4 | 1 << 8, 2 | 2 << 8, 8 | 1 << 19, 4 | 2 << 8 | 1 << 19, 8 | 1 << 20, 4 | 3 << 19, 3, 0):  # (3 does not divide the tiles: the plain order)
             plan = make(fa, n2, np.complex64)
             plan.set_option("tile_walk", walk)
             assert np.array_equal(run_batch(plan, x2, 0), base2), (n2, batch2, walk)
     with pytest.raises(fa.FourierError):
         make(fa, n, np.complex64).set_option("xcd_swizzle", 5)
     with pytest.raises(fa.FourierError):
-        make(fa, n, np.complex64).set_option("tile_walk", 1 << 20)
+        make(fa, n, np.complex64).set_option("tile_walk", 1 << 21)
 
 
 def test_out_of_memory_for_the_scratch_falls_back_to_smaller_chunks(fa, monkeypatch):
