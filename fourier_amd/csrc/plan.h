@@ -202,6 +202,19 @@ template <typename T> class Plan {
     if (key == "bluestein_conv" && (v == 0 || v == 1)) { conv_ = (v == 1) && conv_ok_; return 0; }
     if (key == "bluestein_chirp_compute" && (v == 0 || v == 1)) { chirp_compute_ = (v == 1) && chirp_p_.p != nullptr; return 0; }
     if (key == "host_chunk_bytes" && v > 0) { host_chunk_bytes_ = (size_t)v; return 0; }
+    // the reference's unreduced chirp angle (build_chirp_tables): rebuilds the x and w tables now; the chirp-in pass then READS the
+    // table (its computed chirp is built on exact exponents).  Not while a transform is in flight on this handle.
+    if (key == "bluestein_reference_chirp" && (v == 0 || v == 1)) {
+      if (!blu_) return ::fourier::c::FOURIER_HIP_INVALID_ARGUMENT;
+      if ((v == 1) != reference_chirp_) {
+        HIP_CHECK(hipDeviceSynchronize());  // the tables are replaced in place
+        build_chirp_tables(v == 1);
+        reference_chirp_ = (v == 1);
+        if (reference_chirp_) { chirp_compute_saved_ = chirp_compute_; chirp_compute_ = false; }
+        else chirp_compute_ = chirp_compute_saved_;
+      }
+      return 0;
+    }
     // "specialise" = 1: compile this length's own LDS mixed-radix kernel with hipRTC (about a second, now) and run it from the
     // next call on -- for a length whose prime factors stop at 13, that fits a compute unit's LDS and has no ahead-of-time
     // per-length kernel (it runs the runtime-parameterised kernel, or Bluestein beyond that kernel's reach).  A plan that
@@ -545,18 +558,8 @@ template <typename T> class Plan {
       }
       conv_ = conv_ok_ = true;
     }
-    // chirp exp(-i*pi*k^2/n), angle reduced exactly with k^2 mod 2n (the reference leaves it
-    // unreduced, bluesteins.rs:10,31,57; the reduction only removes f64 argument error)
-    std::vector<double> cr(n_), ci(n_);
+    build_chirp_tables(false);
     const uint64_t two_n = 2 * (uint64_t)n_;
-    for (size_t k = 0; k < n_; ++k) {
-      const uint64_t r = (uint64_t)(((unsigned __int128)k * k) % two_n);
-      const double ang = M_PI * (double)r / (double)n_;
-      cr[k] = std::cos(ang); ci[k] = -std::sin(ang);
-    }
-    std::vector<cpx<T>> x(n_);
-    for (size_t k = 0; k < n_; ++k) x[k] = {(T)cr[k], (T)ci[k]};  // x_fwd, bluesteins.rs:51-61
-    xtab_.upload(x);
     if (fused_ && !small_fused_) {
       // Tables for the chirp-in pass that computes the chirp instead of reading x (a quarter of that pass's traffic):
       // index k = row*cn + b  =>  x[k] = W_2n^{(row*cn)^2} * W_2n^{b^2} * W_n^{cn*row*b}; exact exponents, f64 trig, cast.
@@ -587,8 +590,31 @@ template <typename T> class Plan {
       // work) are 5-17 % SLOWER.  So: a long first pass and a table beyond an XCD's L2.
       chirp_compute_ = eng_->first_len() >= 1024 && n_ * ELEM >= ((size_t)4 << 20);
     }
-    // w = FFT_M(conj chirp, mirrored) (bluesteins.rs:18-48), evaluated in f64 on the host, with the
-    // inner IFFT's 1/M (bluesteins.rs:239 -> mod.rs:383) folded in.
+  }
+  // The chirp x[k] = exp(-i*pi*k^2/n) (bluesteins.rs:51-61) and w = FFT_M(conj chirp, mirrored) (bluesteins.rs:18-48), evaluated in f64 on
+  // the host and cast (twiddle.rs:7-19 style), the inner IFFT's 1/M (bluesteins.rs:239 -> mod.rs:383) folded into w.
+  // reference_angle = false (default): the angle is reduced exactly, k^2 mod 2n, before the trigonometry -- the reference leaves it
+  // unreduced (bluesteins.rs:10,31,57: theta = k^2 * pi / n in f64, up to pi * n radians), which costs it about n * 1e-16 of
+  // absolute angle error (2e-10 at n = 10^6: invisible in f32, the whole error budget in f64).  true (plan option
+  // "bluestein_reference_chirp"): the reference's own expression, for a caller who wants the reference's f64 RESULTS rather than the
+  // exact DFT: the engine then agrees with the CPU restatement to f64 rounding instead of to 1e-9 (tests: test_bluestein_reference_chirp).
+  void build_chirp_tables(bool reference_angle) {
+    std::vector<double> cr(n_), ci(n_);
+    const uint64_t two_n = 2 * (uint64_t)n_;
+    for (size_t k = 0; k < n_; ++k) {
+      double ang;
+      if (reference_angle) {
+        const double index = (double)k * (double)k;  // (i as f64).powi(2), bluesteins.rs:31,57
+        ang = index * M_PI / (double)n_;             // bluesteins.rs:10
+      } else {
+        const uint64_t r = (uint64_t)(((unsigned __int128)k * k) % two_n);
+        ang = M_PI * (double)r / (double)n_;
+      }
+      cr[k] = std::cos(ang); ci[k] = -std::sin(ang);
+    }
+    std::vector<cpx<T>> x(n_);
+    for (size_t k = 0; k < n_; ++k) x[k] = {(T)cr[k], (T)ci[k]};  // x_fwd, bluesteins.rs:51-61
+    xtab_.upload(x);
     std::vector<double> wr(m_, 0.0), wi(m_, 0.0);
     for (size_t k = 0; k < n_; ++k) {
       wr[k] = cr[k]; wi[k] = -ci[k];
@@ -662,6 +688,7 @@ template <typename T> class Plan {
   DevBuf xtab_, wtab_;
   DevBuf chirp_p_, chirp_u_, tn_lo_, tn_hi_;  // chirp-in pass computing the chirp (init_bluestein)
   uint32_t tn_bits_ = 0;
+  bool reference_chirp_ = false, chirp_compute_saved_ = false;  // option "bluestein_reference_chirp"
   bool chirp_compute_ = false;  // option "bluestein_chirp_compute"
   mutable DevBuf scratch_, work_, hostio_;
   mutable PinnedBuf pinned_;

@@ -191,6 +191,12 @@ const char *fourier_hip_status_string(int status);
  *                  exact-exponent cross term) instead of reading the N-entry chirp table, a quarter of that pass's
  *                  memory traffic; default 1 where it was measured faster (first pass of length >= 1024 and a table
  *                  of >= 4 MiB, e.g. N = 999983), else 0.  Same tolerance class, not the same bits.
+ *   "bluestein_reference_chirp" 1 = build the chirp tables from the reference's own expression, theta = k^2 * pi / N evaluated UNREDUCED in
+ *                  f64 (bluesteins.rs:10,31,57), instead of from k^2 mod 2N reduced exactly: for a caller who wants the reference's f64
+ *                  results rather than the exact DFT.  The reference's form costs it N * 1e-16 of angle -- 1.7e-10 of the result at
+ *                  N = 999983 --; with the option the engine agrees with the reference's arithmetic to f64 rounding (1e-15), without it with
+ *                  the exact DFT to 1e-15 (profiles/r05_s18_reference_chirp.jsonl).  Rebuilds two tables on the host, synchronises the device;
+ *                  the chirp-in pass then reads its table ("bluestein_chirp_compute" off).  Default 0.  INVALID_ARGUMENT on a non-Bluestein plan.
  *   "specialise"   1 = compile this length's own LDS mixed-radix kernel with hipRTC, now (about a second, once per length,
  *                  device and process), and run it from the next call on.  For a length whose prime factors stop at 13, that
  *                  fits a compute unit's LDS and has no ahead-of-time per-length kernel -- by default it runs the

@@ -313,6 +313,23 @@ def test_bluestein_conv_kernel_matches_separate_passes(fa, oracle):
             assert np.array_equal(run_batch(conv, x, code, inplace=True), a), (n, code)
 
 
+def test_bluestein_reference_chirp_option(fa, oracle):
+    """Plan option "bluestein_reference_chirp": tables from the reference's unreduced angle k^2 * pi / N (bluesteins.rs:10,31,57) -- the engine
+    then equals the CPU restatement to f64 rounding where by default it equals the exact DFT (the GPU test runs the large lengths)."""
+    for n in (73, 1013, 20011):
+        x = np.stack([hash_normal(30 + b, n) for b in range(2)]).astype(np.complex128)
+        plan = make(fa, n, np.complex128)
+        base = run_batch(plan, x, 0)
+        assert rel_l2(base, np.fft.fft(x, axis=1)) <= 5e-15
+        plan.set_option("bluestein_reference_chirp", 1)
+        for code in (0, 1):
+            assert rel_l2(run_batch(plan, x, code), oracle.transform_batch(x, code)) <= 5e-15, (n, code)
+        plan.set_option("bluestein_reference_chirp", 0)
+        assert np.array_equal(run_batch(plan, x, 0), base)
+    with pytest.raises(fa.FourierError):
+        make(fa, 1024, np.complex128).set_option("bluestein_reference_chirp", 1)
+
+
 def test_bluestein_chirp_in_pass_computes_the_chirp(fa, oracle):
     """The fused chirp-in first pass builds x[k] = exp(-i*pi*k^2/N) from a row table, a column table and an exact-exponent
     cross term (option bluestein_chirp_compute, default on) instead of reading the N-entry table: both against the

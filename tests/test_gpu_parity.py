@@ -264,6 +264,42 @@ def test_bluestein_conv_kernel_vs_separate_passes_and_oracle(torch, fa, oracle, 
             assert rel_l2(a, ref) <= tol, (n, code, rel_l2(a, ref))
 
 
+def test_bluestein_reference_chirp_reproduces_the_reference_to_f64_rounding(torch, fa, oracle):
+    """Where this engine and the reference differ in f64 Bluestein, the difference is the REFERENCE's: it evaluates the chirp angle
+    k^2 * pi / N unreduced in f64 (bluesteins.rs:10,31,57), which costs N * 1e-16 of angle -- 1.7e-10 of the result at N = 999983 --,
+    the engine reduces k^2 mod 2N exactly first.  Plan option "bluestein_reference_chirp" builds the tables from the reference's own
+    expression: the engine then agrees with the CPU restatement to f64 ROUNDING (1e-15 class) on every Bluestein route -- the one-launch
+    kernels, the fused passes with the conv kernel, C4's length --, forward and inverse, while by default it agrees with the exact DFT
+    to 1e-15 and with the oracle only as well as the oracle does (which is what the 1e-9 tolerances elsewhere in this file allow for)."""
+    for n in (1013, 10007, 65537, 250007, 999983):
+        x = np.stack([hash_normal(900 + b, n) for b in range(2)]).astype(np.complex128)
+        truth = torch.fft.fft(torch.from_numpy(x)).numpy()
+        ref = oracle.transform_batch(x, 0, nthreads=2)
+        oracle_err = rel_l2(ref, truth)
+        plan = make(fa, n, np.complex128)
+        assert "bluestein" in plan.describe()
+        got = gpu_batch(torch, fa, plan, x, 0)
+        assert rel_l2(got, truth) <= 5e-15, (n, rel_l2(got, truth))              # the engine: the exact DFT
+        assert rel_l2(got, ref) <= 1.5 * oracle_err + 1e-14, (n, rel_l2(got, ref))  # ... as far from the oracle as the oracle is from it
+        plan.set_option("bluestein_reference_chirp", 1)
+        for code in (0, 1, 4):
+            r = oracle.transform_batch(x, code, nthreads=2)
+            g = gpu_batch(torch, fa, plan, x, code)
+            assert rel_l2(g, r) <= 5e-15, (n, code, rel_l2(g, r))               # the reference's results, to rounding
+            assert np.array_equal(gpu_batch(torch, fa, plan, x, code, inplace=True), g), (n, code)
+        assert abs(rel_l2(gpu_batch(torch, fa, plan, x, 0), truth) - oracle_err) <= 0.2 * oracle_err + 1e-14  # ... and its error
+        plan.set_option("bluestein_reference_chirp", 0)
+        assert np.array_equal(gpu_batch(torch, fa, plan, x, 0), got), n          # back to the default tables, bit for bit
+    with pytest.raises(fa.FourierError):
+        make(fa, 4096, np.complex128).set_option("bluestein_reference_chirp", 1)  # not a Bluestein plan
+    # f32: the angle error is far below f32 resolution; the option changes nothing measurable
+    x = np.stack([hash_normal(910 + b, 10007) for b in range(2)]).astype(np.complex64)
+    plan = make(fa, 10007, np.complex64)
+    a = gpu_batch(torch, fa, plan, x, 0)
+    plan.set_option("bluestein_reference_chirp", 1)
+    assert rel_l2(gpu_batch(torch, fa, plan, x, 0), a) <= 2e-7
+
+
 def test_random_sizes_batches_codes_vs_oracle(torch, fa, oracle):
     """Seeded random sweep over every plan family: random size (1..70000), batch, transform code, precision,
     in/out of place, against the CPU restatement of the reference."""
