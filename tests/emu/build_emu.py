@@ -13,8 +13,12 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "fourier_amd", "csrc")
-OUT = os.path.join(HERE, "libfourier_emu.so")
-OBJDIR = os.path.join(HERE, "obj")
+# FOURIER_EMU_ASAN=1: the same library instrumented with AddressSanitizer (tools/asan_emu.sh: every global, LDS and table access of the
+# emulated kernels and every host-side buffer of the plan layer is bounds-checked while the CPU tests run)
+ASAN = os.environ.get("FOURIER_EMU_ASAN") == "1"
+OUT = os.path.join(HERE, "libfourier_emu_asan.so" if ASAN else "libfourier_emu.so")
+OBJDIR = os.path.join(HERE, "obj_asan" if ASAN else "obj")
+SAN = ["-fsanitize=address", "-fno-omit-frame-pointer", "-g1"] if ASAN else []
 
 
 def deps():
@@ -36,13 +40,13 @@ def compile_and_link(out):
         objs.append(obj)
         if os.path.exists(obj) and os.path.getmtime(obj) >= max(newest_header, os.path.getmtime(srcp)):
             continue
-        jobs.append(["g++", "-O2", "-std=c++17", "-DFOURIER_EMU", "-include", os.path.join(HERE, "hipemu.h"), "-fPIC", "-pthread"] + defs +
+        jobs.append(["g++", "-O1" if ASAN else "-O2", "-std=c++17", "-DFOURIER_EMU", "-include", os.path.join(HERE, "hipemu.h"), "-fPIC", "-pthread"] + SAN + defs +
                     ["-c", srcp, "-o", obj])
     with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, os.cpu_count() or 1)) as ex:
         for rc in ex.map(lambda cmd: subprocess.call(cmd), jobs):
             if rc:
                 raise RuntimeError("emulator build failed")
-    subprocess.check_call(["g++", "-shared", "-pthread", "-o", out] + objs)
+    subprocess.check_call(["g++", "-shared", "-pthread"] + SAN + ["-o", out] + objs)
 
 
 def build():
