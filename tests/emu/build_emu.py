@@ -15,10 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "fourier_amd", "csrc")
 # FOURIER_EMU_ASAN=1: the same library instrumented with AddressSanitizer (tools/asan_emu.sh: every global, LDS and table access of the
 # emulated kernels and every host-side buffer of the plan layer is bounds-checked while the CPU tests run)
-ASAN = os.environ.get("FOURIER_EMU_ASAN") == "1"
-OUT = os.path.join(HERE, "libfourier_emu_asan.so" if ASAN else "libfourier_emu.so")
-OBJDIR = os.path.join(HERE, "obj_asan" if ASAN else "obj")
-SAN = ["-fsanitize=address", "-fno-omit-frame-pointer", "-g1"] if ASAN else []
+ASAN = os.environ.get("FOURIER_EMU_ASAN") in ("1", "2")  # 2: + UndefinedBehaviorSanitizer (reports go to stderr, the run continues)
+UBSAN = os.environ.get("FOURIER_EMU_ASAN") == "2"
+OUT = os.path.join(HERE, ("libfourier_emu_asan_ubsan.so" if UBSAN else "libfourier_emu_asan.so") if ASAN else "libfourier_emu.so")
+OBJDIR = os.path.join(HERE, ("obj_asan_ubsan" if UBSAN else "obj_asan") if ASAN else "obj")
+SAN = ["-fsanitize=address" + (",undefined" if UBSAN else ""), "-fno-omit-frame-pointer", "-g1"] if ASAN else []
 
 
 def deps():
