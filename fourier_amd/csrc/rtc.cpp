@@ -18,6 +18,7 @@
 
 #ifndef FOURIER_EMU
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <cstdio>
@@ -119,13 +120,16 @@ std::string cache_file(int dev, bool f64, uint32_t n, size_t lds_bytes, bool til
 }
 void make_dirs(const std::string& dir) {
   for (size_t i = 1; i <= dir.size(); ++i)
-    if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0755);
+    if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), i == dir.size() ? 0700 : 0755);
 }
 const char CACHE_MAGIC[] = "FOURIER-HIP-CO-1\n";
 // file: magic line, the kernel's lowered name, a newline, the code object
 bool read_cache(const std::string& path, std::string& lowered, std::vector<char>& code) {
   FILE* f = path.empty() ? nullptr : fopen(path.c_str(), "rb");
   if (!f) return false;
+  // a code object is executed on the device: only a regular file that belongs to this user and that nobody else may write is trusted
+  struct stat st;
+  if (fstat(fileno(f), &st) != 0 || !S_ISREG(st.st_mode) || st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) { fclose(f); return false; }
   std::vector<char> all;
   char buf[65536];
   size_t got;
@@ -143,8 +147,9 @@ void write_cache(const std::string& path, const std::string& lowered, const std:
   if (path.empty()) return;
   make_dirs(path.substr(0, path.rfind('/')));
   const std::string tmp = path + ".tmp" + std::to_string((long long)getpid());
-  FILE* f = fopen(tmp.c_str(), "wb");
-  if (!f) return;
+  const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL, 0600);
+  FILE* f = fd >= 0 ? fdopen(fd, "wb") : nullptr;
+  if (!f) { if (fd >= 0) close(fd); return; }
   bool ok = fwrite(CACHE_MAGIC, 1, sizeof(CACHE_MAGIC) - 1, f) == sizeof(CACHE_MAGIC) - 1 && fwrite(lowered.data(), 1, lowered.size(), f) == lowered.size() &&
             fputc('\n', f) != EOF && fwrite(code.data(), 1, code.size(), f) == code.size();
   ok = (fclose(f) == 0) && ok;

@@ -237,7 +237,8 @@ int fourier_hip_set_option_double(FOURIER_STRUCT fourier_fft_double *, const cha
  * Environment the library reads, all of it: FOURIER_HIP_VERBOSE (error text on stderr), FOURIER_HIP_SPECIALISE (above) and the
  * location of the code-object cache: $FOURIER_HIP_CACHE_DIR, else $XDG_CACHE_HOME/fourier-hip, else $HOME/.cache/fourier-hip (an EMPTY
  * FOURIER_HIP_CACHE_DIR switches the disk cache off).  Cache files are keyed by device architecture, precision, kernel kind, length
- * and a hash of the embedded kernel sources and compile options: a library update never loads a stale kernel.
+ * and a hash of the embedded kernel sources and compile options: a library update never loads a stale kernel.  A cache file is trusted only if
+ * it is a regular file owned by the calling user that no one else may write (files are created 0600 in a 0700 directory).
  * Returns FOURIER_HIP_OK or FOURIER_HIP_INVALID_ARGUMENT (unknown key / value); _get_ returns the value or -1. */
 int fourier_hip_set_default_option(const char *key, long long value);
 long long fourier_hip_get_default_option(const char *key);

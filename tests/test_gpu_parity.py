@@ -1250,8 +1250,14 @@ def test_code_object_cache_and_the_library_wide_specialise_policy(torch, fa, ora
         out = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         assert "specialised" in json.loads(out.stdout.strip().splitlines()[-1])["d5005"], (bad, out.stdout)
-    # a damaged cache file is discarded, not trusted
+    # a cache file somebody else could have written is not trusted (a code object runs on the device): ignored, left alone
     victim = next(p for p in cache.iterdir() if "-n5005-" in p.name)
+    victim.chmod(0o666)
+    r = child(None)
+    assert "specialised" not in r["d5005"] and victim.exists(), r
+    victim.chmod(0o600)
+    assert "specialised" in child(None)["d5005"]
+    # a damaged cache file is discarded, not trusted
     victim.write_bytes(b"FOURIER-HIP-CO-1\nnot_a_kernel\n" + b"\x00" * 100)
     fa.set_default_option("specialise_at_create", 1)
     try:
