@@ -19,11 +19,16 @@ template <typename T> class TiledMixedEngine {
     }();
     return m;
   }
+  // longest tile pass: 512 points ahead of time; 1024 for a kernel compiled at run time (a 16-column f32 / 8-column f64 tile of 1024 rows is
+  // 128 KiB of LDS, one 1024-thread workgroup per CU: 2.4 - 3.2 TB/s per pass against 4.2 - 4.9 for the short tiles -- level with a three-pass
+  // plan of short tiles, but it reaches lengths that have no split into factors of 64 ... 512 at all: 5^8 = 625 x 625 15 % of the HBM peak
+  // against 9 % as Bluestein, 500000 = 800 x 625 18 % against 11 %, profiles/r05_s21_long_tiles_ab.jsonl)
+  static uint32_t max_len(bool rtc) { return rtc ? 1024u : 512u; }
   // every length a tile pass can have once it is compiled at run time (plan option "specialise"): prime factors up to 13
   static const std::vector<uint32_t>& menu_rtc() {
     static const std::vector<uint32_t> m = [] {
       std::vector<uint32_t> v;
-      for (uint32_t L = 64; L <= 512; ++L) {
+      for (uint32_t L = 64; L <= max_len(true); ++L) {
         uint32_t r = L;
         for (uint32_t p : {2u, 3u, 5u, 7u, 11u, 13u})
           while (r % p == 0) r /= p;
@@ -41,7 +46,7 @@ template <typename T> class TiledMixedEngine {
     for (uint32_t a : m) {
       if (n % a) continue;
       const size_t r = n / a;
-      if (r <= 512 && r >= 64 && r <= a && std::find(m.begin(), m.end(), (uint32_t)r) != m.end() && a < best_max) {
+      if (r <= max_len(rtc) && r >= 64 && r <= a && std::find(m.begin(), m.end(), (uint32_t)r) != m.end() && a < best_max) {
         best = {a, (uint32_t)r};
         best_max = a;
       }

@@ -204,8 +204,8 @@ const char *fourier_hip_status_string(int status);
  *                  that kernel's reach, Bluestein.  OK and unchanged for a plan that already runs a per-length kernel;
  *                  FOURIER_HIP_UNSUPPORTED -- the plan keeps its route -- for any other length, where libhiprtc is not
  *                  installed, or where the compilation fails.  Beyond the LDS limit (up to 2^26 points) the option replaces a
- *                  Bluestein plan by two or three column-tile passes whose lengths have prime factors up to 13 (10^5 = 400 x 250,
- *                  44100 = 210 x 210), compiled the same way, where such a factorisation exists.  Compiled code objects are kept in an
+ *                  Bluestein plan by two or three column-tile passes whose lengths (64 ... 1024 points) have prime factors up to 13
+ *                  (143000 = 440 x 325, 5^8 = 625 x 625), compiled the same way, where such a factorisation exists.  Compiled code objects are kept in an
  *                  on-disk cache (below), so a length costs its second once per machine.  Compilation never happens implicitly unless
  *                  the library-wide default "specialise_at_create" is raised to 2 (fourier_hip_set_default_option).  Same tolerance
  *                  class as the default route, not the same bits.

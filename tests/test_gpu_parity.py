@@ -1299,8 +1299,9 @@ def test_plan_option_specialise_compiles_the_lengths_own_kernel_with_hiprtc(torc
             assert np.array_equal(gpu_batch(torch, fa, spec, x, code, inplace=True), a), (n, dtype, code)
     # beyond one compute unit's LDS: column-tile passes whose lengths may have prime factors up to 13 (Bluestein by default where a
     # tile length has a factor 11 or 13: the ahead-of-time tile kernels stop at 7)
+    # (500000 = 2^5 * 5^6 and 5^8 have no split into factors of 64 ... 512: tile passes of up to 1024 points, run-time kernels only)
     for n, dtype, want in ((143000, np.complex64, "440x325"), (57200, np.complex64, "260x220"),
-                           (143000, np.complex128, "440x325")):
+                           (143000, np.complex128, "440x325"), (500000, np.complex64, "800x625"), (390625, np.complex128, "625x625")):
         x = np.stack([hash_normal(2600 + b, n) for b in range(3)]).astype(dtype)
         base, spec = make(fa, n, dtype), make(fa, n, dtype)
         assert "bluestein" in base.describe()
