@@ -5,6 +5,13 @@
 
 namespace fourier_hip {
 
+// register rows of a one-launch chirp-z kernel that carry user data: 8 of 16 (2n <= M: the upper half of the work array is padding on
+// the way in and beyond the user array on the way out; see bluestein_rows_kernel).  FOURIER_BLU_PRUNE=0 (A/B): all 16, as until round 5
+#ifndef FOURIER_BLU_PRUNE
+#define FOURIER_BLU_PRUNE 1
+#endif
+constexpr int BLU_ROWS = FOURIER_BLU_PRUNE ? 8 : 16;
+
 // ---- mid sizes N = L1 x L2 <= 2^15 (f32) / 2^14 (f64): BOTH Stockham passes in one launch ----
 // One workgroup owns one whole transform in registers (N/16 points per ... 16 points x VEC per thread),
 // so HBM sees it once in and once out instead of twice: pass A = column FFT of length L1 over the
@@ -161,11 +168,19 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
   const BufRsrc rc = make_rsrc(a.blu_x, n * (uint32_t)sizeof(cpx<T>));
   constexpr int RB = 4;  // rows per batch: RB chirp values and RB * VEC data elements in flight per thread
   constexpr uint32_t ES = (uint32_t)sizeof(cpx<T>);
+  // M = L >= 2n - 1 and L even give n <= L/2 (bluesteins.rs:110; the engine checks it): positions th + Q*r with r >= 8 are padding on
+  // the way in and beyond the user array on the way out.  Registers 8 .. 15 are therefore CONSTANT zeros here -- the first radix-16
+  // stage of the forward transform folds to half its additions at compile time, half the loads are never issued -- and are neither
+  // multiplied nor stored at the end, which lets the compiler drop half of the inverse transform's last stage (round 5)
   cpx<T> x[VEC][16];
   {
     const int th = tid % Q, cg = tid / Q;
 #pragma unroll
-    for (int r0 = 0; r0 < 16; r0 += RB) {
+    for (int v = 0; v < VEC; ++v)
+#pragma unroll
+      for (int r = BLU_ROWS; r < 16; ++r) x[v][r] = cpx<T>{(T)0, (T)0};
+#pragma unroll
+    for (int r0 = 0; r0 < BLU_ROWS; r0 += RB) {
       cpx<T> c[RB];
 #pragma unroll
       for (int q = 0; q < RB; ++q) c[q] = buf_load_elem<T>(rc, (uint32_t)(th + Q * (r0 + q)) * ES);  // 0 beyond n
@@ -225,7 +240,7 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
   FOURIER_LAUNDER(t);
   const int th = t % Q, cg = t / Q;
 #pragma unroll
-  for (int r0 = 0; r0 < 16; r0 += RB) {
+  for (int r0 = 0; r0 < BLU_ROWS; r0 += RB) {  // (registers 8 .. 15 hold outputs beyond the user array)
     cpx<T> c[RB];
 #pragma unroll
     for (int q = 0; q < RB; ++q) c[q] = buf_load_elem<T>(rc, (uint32_t)(th + Q * (r0 + q)) * ES);
@@ -331,14 +346,20 @@ __global__ void __launch_bounds__(FOURIER_TWOLEVEL_NT(T, L1, L2), FOURIER_MIN_WA
   const int th = tid / CG1, cg = tid % CG1;
   const uint32_t voff = (uint32_t)((th * L2 + cg * VEC) * sizeof(cpx<T>));
   constexpr uint32_t ROWB = (uint32_t)(Q1 * L2 * sizeof(cpx<T>));  // register r holds index (th + Q1*r)*L2 + cg*VEC + v
+  // (2n <= M: registers 8 .. 15 -- indices from M/2 on -- are padding on the way in and beyond the user array on the way out: constant
+  // zeros that fold the first radix-16 stage, never loaded, never multiplied by the chirp, never stored; see bluestein_rows_kernel)
   cpx<T> x[VEC][16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
+  for (int v = 0; v < VEC; ++v)
+#pragma unroll
+    for (int r = BLU_ROWS; r < 16; ++r) x[v][r] = cpx<T>{(T)0, (T)0};
+#pragma unroll
+  for (int r = 0; r < BLU_ROWS; ++r) {
     const Unit16<T> u = buf_load_unit<T>(ri, voff + (uint32_t)r * ROWB);
 #pragma unroll
     for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
   }
-  units_batched<T, 8>([&](int r) { return buf_load_unit<T>(rc, voff + (uint32_t)r * ROWB); },
+  units_batched_rows<T, 8, BLU_ROWS>([&](int r) { return buf_load_unit<T>(rc, voff + (uint32_t)r * ROWB); },
                       [&](int r, const Unit16<T>& c) {
 #pragma unroll
                         for (int v = 0; v < VEC; ++v) {
@@ -374,7 +395,7 @@ __global__ void __launch_bounds__(FOURIER_TWOLEVEL_NT(T, L1, L2), FOURIER_MIN_WA
     int tb = tid;
     FOURIER_LAUNDER(tb);
     const uint32_t soff = (uint32_t)(((tb / CG1) * L2 + (tb % CG1) * VEC) * sizeof(cpx<T>));
-    units_batched<T, 8>([&](int r) { return buf_load_unit<T>(rc, soff + (uint32_t)r * ROWB); },
+    units_batched_rows<T, 8, BLU_ROWS>([&](int r) { return buf_load_unit<T>(rc, soff + (uint32_t)r * ROWB); },
                         [&](int r, const Unit16<T>& c) {
                           Unit16<T> u;
 #pragma unroll

@@ -108,10 +108,11 @@ __device__ __forceinline__ void lds_exchange(RegTile<T, L, CG>& x, unsigned char
 // Sixteen table units, one per register row of a tile, applied B at a time: the B loads of a batch are issued back to
 // back, then consumed.  Left to itself hipcc (128-VGPR budget, 64 of them the tile) issues ONE load, waits for it,
 // multiplies, and only then issues the next -- sixteen exposed L2 / HBM latencies per tile.
-template <typename T, int B, typename Ld, typename Use>
-__device__ __forceinline__ void units_batched(const Ld& ld, const Use& use) {
+// (NR: the register rows that take part -- 16, or 8 where the upper half of a chirp-z work array is padding)
+template <typename T, int B, int NR, typename Ld, typename Use>
+__device__ __forceinline__ void units_batched_rows(const Ld& ld, const Use& use) {
 #pragma unroll
-  for (int r0 = 0; r0 < 16; r0 += B) {
+  for (int r0 = 0; r0 < NR; r0 += B) {
     Unit16<T> u[B];
 #pragma unroll
     for (int q = 0; q < B; ++q) u[q] = ld(r0 + q);
@@ -121,6 +122,8 @@ __device__ __forceinline__ void units_batched(const Ld& ld, const Use& use) {
     FOURIER_SCHED_FENCE();
   }
 }
+template <typename T, int B, typename Ld, typename Use>
+__device__ __forceinline__ void units_batched(const Ld& ld, const Use& use) { units_batched_rows<T, B, 16>(ld, use); }
 
 // x[v][k] *= t[k], k = 1..15 (t[0] = 1): the stage twiddles of one thread, sixteen consecutive table entries.  All of
 // them (f64: half of them) are loaded in one batch -- under FOURIER_STAGE_TW_BATCHED; otherwise hipcc picks the grouping

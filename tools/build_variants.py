@@ -83,6 +83,7 @@ VARIANTS = {
     "abl1": ["-DFOURIER_ABLATE=1"],
     "abl2": ["-DFOURIER_ABLATE=2"],
     "abl3": ["-DFOURIER_ABLATE=3"],
+    "blu_prune_off": ["-DFOURIER_BLU_PRUNE=0"],
     "abl4": ["-DFOURIER_ABLATE=4"],  # stage twiddles from a constant (no table loads inside the in-tile transform)
     "abl5": ["-DFOURIER_ABLATE=5"],  # per-thread inter-pass twiddle factor from a constant (no two-level look-up)
 }
