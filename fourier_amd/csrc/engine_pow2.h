@@ -433,6 +433,77 @@ template <typename T> class Pow2Engine {
     apply_mul(out, batch, mul, inverse, scale, stream, prof, slot0 + (int)np - 1);
   }
 
+  // ---- the two passes of a two-pass plan software-pipelined over two internal streams (plan option "stream_pipeline")
+  // The batch is cut into chunks of `chunk` transforms; the intermediate of a chunk lives in one of `slots` slots of a small
+  // plan-owned ring instead of the output array.  Stream A runs pass 0 of chunk k+1 while stream B runs pass 1 of chunk k; the only
+  // ordering is event to event (a slot is written after its previous tenant has been read, read after it has been written) -- no
+  // in-kernel synchronisation.  The reference ping-pongs between two whole buffers (autosort/mod.rs:335-379); this is the same
+  // ping-pong with a buffer of a few chunks.  In-place calls need no batch-sized scratch this way.  The caller's stream is
+  // forked into A and B and joined again, so the call stays stream-ordered (and capturable).
+  struct StreamPipe {
+    hipStream_t sa = nullptr, sb = nullptr;
+    hipEvent_t fork = nullptr, join_a = nullptr, join_b = nullptr;
+    std::vector<hipEvent_t> written, drained;  // per slot: pass 0 has written it / pass 1 has read it
+    DevBuf ring;
+    void ensure(size_t slots, size_t slot_bytes) {
+      if (!sa) {
+        HIP_CHECK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&join_a, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&join_b, hipEventDisableTiming));
+      }
+      while (written.size() < slots) {
+        hipEvent_t w = nullptr, d = nullptr;
+        HIP_CHECK(hipEventCreateWithFlags(&w, hipEventDisableTiming));
+        written.push_back(w);
+        HIP_CHECK(hipEventCreateWithFlags(&d, hipEventDisableTiming));
+        drained.push_back(d);
+      }
+      ring.ensure(slots * slot_bytes);
+    }
+    ~StreamPipe() {
+      for (hipEvent_t e : written) (void)hipEventDestroy(e);
+      for (hipEvent_t e : drained) (void)hipEventDestroy(e);
+      for (hipEvent_t e : {fork, join_a, join_b}) if (e) (void)hipEventDestroy(e);
+      for (hipStream_t s : {sa, sb}) if (s) (void)hipStreamDestroy(s);
+    }
+  };
+  bool can_pipeline() const { return !tiny_ && passes_.size() == 2 && passes_[0]->mode == MODE_FIRST && passes_[1]->mode == MODE_LAST && !last_is_split(); }
+  void reserve_pipeline(size_t chunk, size_t slots) const { pipe_.ensure(slots, chunk * n_ * sizeof(cpx<T>)); }
+  // one_stream (A/B control): the same chunked walk through the ring, both passes on ONE internal stream, nothing overlapped
+  void run_pipelined(const cpx<T>* in, cpx<T>* out, size_t batch, size_t chunk, size_t slots, bool inverse, double scale,
+                     hipStream_t stream, unsigned nxcd, unsigned nxcd_last, bool one_stream = false) const {
+    if (batch == 0) return;
+    chunk = std::max<size_t>(1, std::min(chunk, batch));
+    slots = std::max<size_t>(2, slots);
+    reserve_pipeline(chunk, slots);
+    StreamPipe& sp = pipe_;
+    const hipStream_t sa = sp.sa, sb = one_stream ? sp.sa : sp.sb;
+    HIP_CHECK(hipEventRecord(sp.fork, stream));
+    HIP_CHECK(hipStreamWaitEvent(sa, sp.fork, 0));
+    if (sb != sa) HIP_CHECK(hipStreamWaitEvent(sb, sp.fork, 0));
+    size_t k = 0;
+    for (size_t b0 = 0; b0 < batch; b0 += chunk, ++k) {
+      const size_t nb = std::min(chunk, batch - b0), slot = k % slots;
+      cpx<T>* mid = (cpx<T>*)sp.ring.p + slot * chunk * n_;
+      if (sb != sa && k >= slots) HIP_CHECK(hipStreamWaitEvent(sa, sp.drained[slot], 0));
+      launch_pass(0, in + b0 * n_, mid, nb, inverse, scale, sa, nullptr, 0, nxcd);
+      if (sb != sa) {
+        HIP_CHECK(hipEventRecord(sp.written[slot], sa));
+        HIP_CHECK(hipStreamWaitEvent(sb, sp.written[slot], 0));
+      }
+      launch_pass(1, mid, out + b0 * n_, nb, inverse, scale, sb, nullptr, 1, nxcd_last ? nxcd_last : nxcd);
+      if (sb != sa) HIP_CHECK(hipEventRecord(sp.drained[slot], sb));
+    }
+    HIP_CHECK(hipEventRecord(sp.join_a, sa));
+    HIP_CHECK(hipStreamWaitEvent(stream, sp.join_a, 0));
+    if (sb != sa) {
+      HIP_CHECK(hipEventRecord(sp.join_b, sb));
+      HIP_CHECK(hipStreamWaitEvent(stream, sp.join_b, 0));
+    }
+  }
+
   // Pointwise multiplier on the M-point spectrum of a forward, unscaled transform (bluesteins.rs:236-239): its own sweep.
   // Only the unfused Bluestein options take it (bluestein_fusion = 0, bluestein_conv = 0); the default plans multiply
   // inside fft_conv_kernel / the one-launch kernels.  profile() adds its time to the slot of the last forward pass.
@@ -600,6 +671,7 @@ template <typename T> class Pow2Engine {
   unsigned fused_grid_ = 0, fused_depth_ = 2;
   mutable DevBuf fused_window_, fused_ctrl_;
   mutable PinnedBuf fused_flag_;  // ctrl[1] (abort flag) of the last fused launch, read back before the call returns
+  mutable StreamPipe pipe_;       // option "stream_pipeline": the two internal streams, their events and the ring
   std::string desc_override_;
   std::vector<std::unique_ptr<Pass>> passes_;
   std::map<int, std::unique_ptr<StageTables<T>>> stage_;

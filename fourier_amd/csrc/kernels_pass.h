@@ -4,7 +4,7 @@
 #pragma once
 #include "kernels_common.h"
 
-namespace fourier_hip {
+FOURIER_KERNELS_BEGIN
 
 // ---- tile configuration ----
 template <typename T, int L, int CG> struct TileCfg {
@@ -57,6 +57,10 @@ __device__ __forceinline__ void lds_exchange(RegTile<T, L, CG>& x, unsigned char
   using C = TileCfg<T, L, CG>;
   constexpr int VEC = C::VEC, Q = C::Q;
   if constexpr (C::SPLIT) {
+    // two rounds of 8-byte units through a buffer of half the tile: the re plane, then the im plane, of the VEC columns of a unit -- or,
+    // for f32 under FOURIER_SPLIT_BY_COLUMN, column 0 then column 1 as whole complex numbers: the same slots, sizes and bank pattern,
+    // but a unit then IS the packed (re, im) register pair of the packed-arithmetic kernels (no v_mov to gather / scatter halves)
+    constexpr bool BY_COLUMN = FOURIER_SPLIT_BY_COLUMN != 0 && VEC == 2;
     Unit8<T>* lds = (Unit8<T>*)smem;
 #pragma unroll
     for (int plane = 0; plane < 2; ++plane) {
@@ -64,8 +68,11 @@ __device__ __forceinline__ void lds_exchange(RegTile<T, L, CG>& x, unsigned char
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         Unit8<T> u;
+        if constexpr (BY_COLUMN) { u.a[0] = x[plane][r].re; u.a[1] = x[plane][r].im; }
+        else {
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) u.a[v] = plane ? x[v][r].im : x[v][r].re;
+          for (int v = 0; v < VEC; ++v) u.a[v] = plane ? x[v][r].im : x[v][r].re;
+        }
         Unit8<T>* p = lds + C::template unit_index<LAYOUT>(wpos(r), cg_w);
         LDS_NOTE(p, 8, true, site + plane);
         *p = u;
@@ -76,9 +83,12 @@ __device__ __forceinline__ void lds_exchange(RegTile<T, L, CG>& x, unsigned char
         const Unit8<T>* p = lds + C::template unit_index<LAYOUT>(th_r + Q * r, cg_r);
         LDS_NOTE(p, 8, false, site + 2 + plane);
         const Unit8<T> u = *p;
+        if constexpr (BY_COLUMN) { x[plane][r].re = u.a[0]; x[plane][r].im = u.a[1]; }
+        else {
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          if (plane) x[v][r].im = u.a[v]; else x[v][r].re = u.a[v];
+          for (int v = 0; v < VEC; ++v) {
+            if (plane) x[v][r].im = u.a[v]; else x[v][r].re = u.a[v];
+          }
         }
       }
     }
@@ -780,6 +790,7 @@ template <int L, int MODE, int CG = 8> struct PassPolicy {
   // 64-byte-wide tiles (CG = 4): two workgroups share every 128-byte line, the second one must find it in the L2, so
   // no streaming hint (L = 2048 first pass: 6.5 vs 7.6 ms per 1024 transforms of 2^21, r01 session 11)
   static constexpr int LD = (MODE != MODE_ROWS && CG < 8) ? POL_PLAIN
+                            : (FOURIER_NT_LOAD == 3 && MODE == MODE_LAST) ? POL_SC1  // A/B (round 6): last-pass loads that bypass the L1 only
                             : ((MODE == MODE_FIRST && FOURIER_NT_LOAD != 0) || FOURIER_NT_LOAD == 2) ? POL_NT : POL_PLAIN;
   // MODE_ROWS: a wave's element stores only form whole lines for L >= 256; below that they rely on L2
   // write-combining and a non-temporal hint is a 2-6x loss (N = 16..64, r01 session 9)
@@ -909,4 +920,4 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16)
   }
 }
 
-}  // namespace fourier_hip
+FOURIER_KERNELS_END  // namespace fourier_hip

@@ -202,6 +202,14 @@ template <typename T> class Plan {
     if (key == "bluestein_conv" && (v == 0 || v == 1)) { conv_ = (v == 1) && conv_ok_; return 0; }
     if (key == "bluestein_chirp_compute" && (v == 0 || v == 1)) { chirp_compute_ = (v == 1) && chirp_p_.p != nullptr; return 0; }
     if (key == "host_chunk_bytes" && v > 0) { host_chunk_bytes_ = (size_t)v; return 0; }
+    // the two passes of a two-pass power-of-two plan software-pipelined over two internal streams with the intermediate in a small
+    // ring (Pow2Engine::run_pipelined): v = transforms per chunk | ring slots << 16 | one-stream control << 24; 0 = off
+    if (key == "stream_pipeline" && v >= 0 && v < (1 << 25)) {
+      if (v != 0 && (blu_ || !eng_ || !eng_->can_pipeline())) return ::fourier::c::FOURIER_HIP_INVALID_ARGUMENT;
+      pipe_chunk_ = (size_t)(v & 0xffff); pipe_slots_ = (size_t)((v >> 16) & 0xff); pipe_one_stream_ = ((v >> 24) & 1) != 0;
+      if (pipe_chunk_ && pipe_slots_ < 2) pipe_slots_ = 2;
+      return 0;
+    }
     // the reference's unreduced chirp angle (build_chirp_tables): rebuilds the x and w tables now; the chirp-in pass then READS the
     // table (its computed chirp is built on exact exponents).  Not while a transform is in flight on this handle.
     if (key == "bluestein_reference_chirp" && (v == 0 || v == 1)) {
@@ -314,6 +322,7 @@ template <typename T> class Plan {
       }
     };
     if (!blu_) {
+      if (pipe_chunk_) { eng_->reserve_pipeline(std::min(pipe_chunk_, batch), pipe_slots_); return batch; }
       if (eng_->l2fused_enabled()) { eng_->reserve_l2fused(chunk); return chunk; }
       const bool need = eng_->needs_scratch(in_place) || (force_scratch_ && eng_->num_passes() >= 2);
       if (need) reserve([&](size_t c) { scratch_.ensure(c * n_ * ELEM); });
@@ -370,6 +379,10 @@ template <typename T> class Plan {
       return;
     }
     if (!blu_) {
+      if (pipe_chunk_ && (!prof || in_place)) {  // (a profiled out-of-place call times the kernels one by one on the caller's stream)
+        eng_->run_pipelined(in, out, batch, pipe_chunk_, pipe_slots_, inverse, scale, stream, nxcd_, nxcd_last_, pipe_one_stream_);
+        return;
+      }
       for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const size_t nb = std::min(chunk, batch - b0);
         eng_->run(in + b0 * n_, out + b0 * n_, (cpx<T>*)scratch_.p, nb, inverse, scale, nullptr, force_scratch_, stream, prof, 0, nxcd_,
@@ -696,6 +709,8 @@ template <typename T> class Plan {
   size_t chunk_bytes_ = 0;
   size_t host_chunk_bytes_ = HOST_CHUNK_BYTES;  // exec_host_batch: bytes of one streamed chunk
   bool force_scratch_ = false;
+  size_t pipe_chunk_ = 0, pipe_slots_ = 0;  // option "stream_pipeline"
+  bool pipe_one_stream_ = false;
   bool fused_ = false;  // Bluestein: chirp steps fused into the inner passes
   bool small_fused_ = false;  // Bluestein with M <= 2^15: everything in one launch
   bool conv_ = false, conv_ok_ = false;  // Bluestein: forward LAST + (.)w + inverse FIRST in one launch

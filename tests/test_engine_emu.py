@@ -448,6 +448,27 @@ def test_chunking_and_scratch_options_do_not_change_results(fa):
         make(fa, n, np.complex64).set_option("tile_walk", 1 << 21)
 
 
+def test_stream_pipeline_option_is_bit_identical_and_needs_no_batch_sized_scratch(fa):
+    """Plan option "stream_pipeline" (round 6): the two passes of a two-pass plan chunk by chunk over two internal streams with the
+    intermediate in a small ring -- the same kernels on the same data, so the same bits, out of place and in place, for chunk
+    sizes that do and do not divide the batch; refused where the plan is not a plain two-pass plan."""
+    for n, batch, dtype in ((1 << 16, 11, np.complex64), (1 << 16, 5, np.complex128)):
+        x = np.stack([hash_normal(900 + b, n) for b in range(batch)]).astype(dtype)
+        base = run_batch(make(fa, n, dtype), x, 0)
+        base_inv = run_batch(make(fa, n, dtype), x, 1)
+        for chunk, slots, one in ((1, 2, 0), (2, 3, 0), (4, 2, 0), (3, 4, 1), (64, 2, 0)):
+            plan = make(fa, n, dtype)
+            plan.set_option("stream_pipeline", chunk | slots << 16 | one << 24)
+            assert np.array_equal(run_batch(plan, x, 0), base), (n, chunk, slots)
+            assert np.array_equal(run_batch(plan, x, 0, inplace=True), base), (n, chunk, slots)
+            assert np.array_equal(run_batch(plan, x, 1, inplace=True), base_inv), (n, chunk, slots)
+            plan.set_option("stream_pipeline", 0)
+            assert np.array_equal(run_batch(plan, x, 0), base)
+    for n in (4096, 1000, 40001, 1 << 24):  # one launch, LDS mixed radix, Bluestein, three passes
+        with pytest.raises(fa.FourierError):
+            make(fa, n, np.complex64).set_option("stream_pipeline", 2 | 2 << 16)
+
+
 def test_out_of_memory_for_the_scratch_falls_back_to_smaller_chunks(fa, monkeypatch):
     """An in-place call needs a scratch of one chunk (default: the whole batch).  When the device cannot give that
     much the engine halves the chunk until the allocation fits instead of failing; same bits as the unchunked run."""

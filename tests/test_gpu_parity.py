@@ -655,6 +655,35 @@ def test_reserve_then_capture_without_warmup(torch, fa, oracle):
     assert rel_l2(d.cpu().numpy(), oracle.transform_batch(x, oracle.FFT)) <= 1e-6
 
 
+def test_stream_pipeline_option_on_the_gpu(torch, fa, oracle):
+    """Plan option "stream_pipeline" (round 6): pass 0 of chunk k+1 on one internal stream beside pass 1 of chunk k on another,
+    ordered by events only, intermediate in a plan-owned ring.  Real concurrency here (the emulator runs it serially): the same
+    bits as the two whole-batch launches, out of place and in place, repeated calls reusing ring and events, ragged last chunk,
+    inside the caller's stream order (the input is produced and the output consumed on the caller's stream without a sync)."""
+    for n, batch, dtype in ((1 << 20, 37, np.complex64), (1 << 16, 203, np.complex64), (1 << 18, 21, np.complex128)):
+        cdt = torch.complex64 if dtype == np.complex64 else torch.complex128
+        x = torch.from_numpy(hash_normal(61, batch * n).astype(dtype).reshape(batch, n)).cuda()
+        base = torch.empty_like(x)
+        make(fa, n, dtype).transform(x, base, fa.Transform.Fft)
+        torch.cuda.synchronize()
+        for chunk, slots, one in ((1, 2, 0), (4, 3, 0), (8, 2, 0), (5, 4, 1), (64, 2, 0)):
+            plan = make(fa, n, dtype)
+            plan.set_option("stream_pipeline", chunk | slots << 16 | one << 24)
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    xs = x * 1.0        # produced on the caller's stream right before the call
+                    y = torch.zeros_like(x)
+                    plan.transform(xs, y, fa.Transform.Fft)
+                    ok = torch.equal(torch.view_as_real(y), torch.view_as_real(base))  # consumed on the caller's stream right after it
+                    assert ok, (n, chunk, slots, one)
+                plan.transform_in_place(xs, fa.Transform.Fft)
+                assert torch.equal(torch.view_as_real(xs), torch.view_as_real(base)), (n, chunk, slots, "in place")
+            side.synchronize()
+        del x, base
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("log2n,dtype,tol", [(27, np.complex64, 1e-6), (26, np.complex128, 5e-14), (30, np.complex64, 1.5e-6)])
 def test_largest_three_pass_sizes_known_answers(torch, fa, log2n, dtype, tol):
     """2^26 .. 2^30 (three passes, 1..8 GiB per transform): too long for the CPU oracle, so pinned by known answers

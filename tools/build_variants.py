@@ -85,7 +85,10 @@ VARIANTS = {
     "abl3": ["-DFOURIER_ABLATE=3"],
     "blu_prune_off": ["-DFOURIER_BLU_PRUNE=0"],
     "abl4": ["-DFOURIER_ABLATE=4"],  # stage twiddles from a constant (no table loads inside the in-tile transform)
-    "abl5": ["-DFOURIER_ABLATE=5"],  # per-thread inter-pass twiddle factor from a constant (no two-level look-up)
+    "abl5": ["-DFOURIER_ABLATE=5"],
+    "onelaunch_scalar": ["-DFOURIER_ONELAUNCH_PK=0"],  # round 6: the one-launch kernels (2^11..2^15, chirp-z M <= 2^15) without packed f32 arithmetic
+    "ld_last_sc1": ["-DFOURIER_NT_LOAD=3"],  # round 6, stream pipeline: pass-1 loads sc1 / intermediate stores plain
+    "st_mid_plain_ld_last_sc1": ["-DFOURIER_NT_LOAD=3", "-DFOURIER_NT_STORE=1"],  # per-thread inter-pass twiddle factor from a constant (no two-level look-up)
 }
 
 
