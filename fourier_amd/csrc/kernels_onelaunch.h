@@ -95,43 +95,9 @@ __device__ __forceinline__ void twolevel_core(cpx<T> (*x)[16], int tid, unsigned
   int tb = tid;
   FOURIER_LAUNDER(tb);  // phase B's mapping is derived here, not at the top of the kernel (see tile_core)
   const int th2 = tb / CG2, cg2 = tb % CG2;
-  constexpr bool BY_COLUMN = CB::SPLIT && FOURIER_SPLIT_BY_COLUMN != 0 && VEC == 2;
-  if constexpr (BY_COLUMN) {
-    // split transposes of f32 tiles under FOURIER_SPLIT_BY_COLUMN (packed arithmetic: an element is the register pair (re, im)): two
-    // rounds of WHOLE complex numbers through the half-size buffer -- round p moves the columns k1 of parity p.  k1 = th + Q1*r has
-    // the parity of th (Q1 is even), so in round p the threads of that parity write all sixteen of their elements and every thread
-    // reads the sixteen elements of its column cg2*2 + p: the same number of LDS instructions as the re / im split, 8 bytes each.
-    static_assert(Q1 % 2 == 0, "column parity = thread parity");
-    Unit8<T>* lds = (Unit8<T>*)smem;
-    __syncthreads();  // the reads of phase A's exchange are done
-#pragma unroll
-    for (int plane = 0; plane < 2; ++plane) {
-      if (plane == 1) __syncthreads();
-      if ((th & 1) == plane) {
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          const int i = cg * VEC + v;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            Unit8<T>* p = lds + twolevel_tr_unit<L2, VEC>(i, (th + Q1 * r) / VEC);
-            LDS_NOTE(p, 8, true, site + 8 + plane);
-            Unit8<T> u;
-            u.a[0] = xr[v][r].re; u.a[1] = xr[v][r].im;
-            *p = u;
-          }
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const Unit8<T>* p = lds + twolevel_tr_unit<L2, VEC>(th2 + Q2 * r, cg2);
-        LDS_NOTE(p, 8, false, site + 10 + plane);
-        const Unit8<T> u = *p;
-        xr[plane][r].re = u.a[0]; xr[plane][r].im = u.a[1];
-      }
-    }
-    __syncthreads();
-  } else {
+  // (the planes stay under packed arithmetic too: a transpose changes which elements share a unit, so whole complex numbers cannot go through
+  // the half-size buffer in two rounds without a second register tile; the packed kernels pay two v_mov per 8-byte read here)
+  {
     constexpr bool SPLIT = CB::SPLIT;
     __syncthreads();  // the reads of phase A's exchange are done
 #pragma unroll
