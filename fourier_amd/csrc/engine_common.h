@@ -173,7 +173,7 @@ typedef void (*TiledKernelFn)(TiledArgs);
 // a tile pass of mixed length L: columns per tile, threads, LDS bytes
 struct TiledKernel { TiledKernelFn fn = nullptr; uint32_t L = 0, cols = 0, threads = 0; size_t smem = 0; };
 // a mixed-radix LDS kernel with its launch shape: transforms per workgroup, LDS buffers of `group` transforms, threads
-struct MixKernel { MixKernelFn fn; uint32_t group; size_t nbuf; uint32_t threads; bool tw_lds = false; };  // tw_lds: + the twiddle tables
+struct MixKernel { MixKernelFn fn; uint32_t group; size_t nbuf; uint32_t threads; };
 
 static inline int ilog2(uint64_t v) { int l = 0; while ((1ull << l) < v) ++l; return l; }
 static inline bool is_pow2(uint64_t v) { return v && !(v & (v - 1)); }

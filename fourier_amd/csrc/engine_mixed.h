@@ -32,7 +32,7 @@ template <typename T> class MixedEngine {
     // runtime-parameterised: about 1024 points per workgroup up to 1024 points, then one transform per workgroup -- 256 threads
     // x 4 / 8 points up to 2048 points, 512 x 8 up to 4096, 1024 x 8 up to 8192 (1024 x 4 for 2049..4096 measured slower than
     // 256 x 16: 3125 f32 19 % against 24 %, r03_s22)
-    Kernel k{nullptr, (uint32_t)std::max<size_t>(1, 1024 / n), 1, 256, false};
+    Kernel k{nullptr, (uint32_t)std::max<size_t>(1, 1024 / n), 1, 256};
     const int maxp = (n % 11 == 0 || n % 13 == 0) ? 13 : ((n % 5 == 0 || n % 7 == 0) ? 7 : 3);
     const size_t pts = k.group * n;
     const Real<T> real{};
@@ -91,7 +91,7 @@ template <typename T> class MixedEngine {
     const Kernel k = pick_kernel(n);
     fn_ = k.fn; group_ = k.group; nbuf_ = k.nbuf; threads_ = k.threads;
     per_length_ = (k.group == mix_group<T>((uint32_t)n) && k.threads == mix_threads<T>((uint32_t)n) && fn_ != nullptr && !is_runtime_kernel(k));
-    smem_ = nbuf_ * (size_t)group_ * n * sizeof(cpx<T>) + (k.tw_lds ? tw.size() * sizeof(cpx<T>) : 0);  // + the tables staged in LDS
+    smem_ = nbuf_ * (size_t)group_ * n * sizeof(cpx<T>);
     if (smem_ > MAX_LDS) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "mixed-radix length needs the per-length kernel");
     raise_smem_limit((const void*)fn_, smem_);
   }
@@ -108,13 +108,7 @@ template <typename T> class MixedEngine {
   // Status: OK, or UNSUPPORTED (no hipRTC, or the compilation failed) -- the plan then keeps the kernel it had.
   // LDS bytes of the specialised kernel of length n (the launch shape rules of mixed_schedule.h)
   static size_t specialised_lds_bytes(uint32_t n) {
-    size_t tw_entries = 0;
-    std::vector<uint32_t> radices;
-    if (mix_tw_lds<T>(n) && factor(n, radices)) {
-      size_t cur = n;
-      for (const size_t R : radices) { tw_entries += cur; cur /= R; }
-    }
-    return (mix_inplace<T>(n) ? 1 : 2) * (size_t)mix_group<T>(n) * n * sizeof(cpx<T>) + tw_entries * sizeof(cpx<T>);
+    return (mix_inplace<T>(n) ? 1 : 2) * (size_t)mix_group<T>(n) * n * sizeof(cpx<T>);
   }
   static bool specialised_kernel_cached(size_t n) { return n <= MAX_N && rtc_cached(sizeof(T) == 8, (uint32_t)n, specialised_lds_bytes((uint32_t)n), false); }
   int specialise(std::string* why = nullptr, bool allow_compile = true) {

@@ -75,28 +75,31 @@ static __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) { retur
 
 // second __launch_bounds__ argument = min waves per SIMD: ask for two workgroups per CU
 // (2*NT/64 waves over 4 SIMDs), which caps the kernel at 128 VGPRs for NT = 512.
-#ifndef FOURIER_MIN_WAVES
 #define FOURIER_MIN_WAVES(NT) ((NT) >= 1024 ? 4 : ((NT) >= 256 ? (NT) / 128 : 1))
-#endif
 
-// A translation unit that compiles these templates with packed f32 arithmetic (FOURIER_PK_F32, see below) gets them in an inline
-// namespace of its own: the same template names then are different entities from those of the other translation units (no two
-// definitions of one entity in a library that links both), while every unqualified use stays as it is.
-#ifdef FOURIER_PK_F32
+// ABLATION builds (timing experiments, WRONG results: FOURIER_ABLATE = 1 no butterflies / twiddles, 2 = additionally no LDS exchange --
+// pure load -> store --, 3 = no inter-pass twiddle only, 4 = stage twiddles from a constant, 5 = per-thread inter-pass factor from a
+// constant) exist only as experiments translation units (-DFOURIER_EXPERIMENTS_TU: kernels_skeleton.cpp, the abl* builds of
+// tools/build_variants.py); every other translation unit compiles the arithmetic in whatever its command line says.
+#if !defined(FOURIER_EXPERIMENTS_TU) || !defined(FOURIER_ABLATE)
+#undef FOURIER_ABLATE
+#define FOURIER_ABLATE 0
+#endif
+// A translation unit that compiles these templates DIFFERENTLY -- packed f32 arithmetic (FOURIER_PK_F32, below), an ablation -- gets them
+// in an inline namespace of its own: the same template names then are different entities from those of the other translation units (no
+// two definitions of one entity in a library that links both), while every unqualified use stays as it is.
+#if defined(FOURIER_PK_F32)
 #define FOURIER_KERNELS_BEGIN namespace fourier_hip { inline namespace pk_f32 {
 #define FOURIER_KERNELS_END } }
+#define FOURIER_SPLIT_BY_COLUMN 1  // split LDS exchanges of f32 tiles by column instead of by re / im plane (kernels_pass.h lds_exchange)
+#elif FOURIER_ABLATE != 0
+#define FOURIER_KERNELS_BEGIN namespace fourier_hip { inline namespace ablated {
+#define FOURIER_KERNELS_END } }
+#define FOURIER_SPLIT_BY_COLUMN 0
 #else
 #define FOURIER_KERNELS_BEGIN namespace fourier_hip {
 #define FOURIER_KERNELS_END }
-#endif
-
-// split LDS exchanges of f32 tiles by column instead of by re / im plane (kernels_pass.h lds_exchange): with packed arithmetic
-#ifndef FOURIER_SPLIT_BY_COLUMN
-#ifdef FOURIER_PK_F32
-#define FOURIER_SPLIT_BY_COLUMN 1
-#else
 #define FOURIER_SPLIT_BY_COLUMN 0
-#endif
 #endif
 
 FOURIER_KERNELS_BEGIN
@@ -104,35 +107,16 @@ FOURIER_KERNELS_BEGIN
 template <typename T> struct alignas(16) Unit16 { T a[16 / sizeof(T)]; };  // VEC interleaved complex
 template <typename T> struct alignas(8) Unit8 { T a[8 / sizeof(T)]; };     // one plane of VEC columns
 
-// Build-time knobs (tools/build_variants.py A/B-tests them on the GPU):
-//   FOURIER_NT_LOAD  = 2 (default): the data loads of every pass are non-temporal (each element is read once per
-//   pass; -10% on the last pass of the 2^20 plan, r01 session 8); 1 = first pass only, 0 = none
-//   FOURIER_NT_STORE = 2 (default): output stores are non-temporal -- the final pass's (+1%), and the intermediate
-//   ones of passes up to L = 1024 (+2%; the one-workgroup-per-CU L = 2048 passes lose 8% with them); 1 = final only
-//   FOURIER_ABLATE (timing experiments only, results are wrong): 1 = no butterflies / twiddles,
-//   2 = additionally no LDS exchange (pure load -> store), 3 = no inter-pass twiddle only, 4 = all arithmetic but the stage
-//   twiddles come from a constant instead of their table (no table loads inside the in-tile transform), 5 = all arithmetic but
-//   the per-thread factor of the inter-pass twiddle is a constant (no two-level table look-up between transform and store)
-#ifndef FOURIER_ABLATE
-#define FOURIER_ABLATE 0
-#endif
-//   FOURIER_SPLIT_THRESHOLD: exchange buffers above this many bytes are exchanged as two planes (re, im):
-//   half the LDS per workgroup, twice the workgroups per CU (16 KiB measured best over 2^8..2^20, r01 sweep)
-//   FOURIER_ROWS_STAGED: the shortest whole-transform kernels (f32 64, f64 32) move their data between global memory and
-//     registers through LDS (16-byte units, whole lines per instruction) instead of element accesses that cover
-//     32 bytes of a line per instruction.
-#ifndef FOURIER_ROWS_STAGED
-#define FOURIER_ROWS_STAGED 1
-#endif
-#ifndef FOURIER_SPLIT_THRESHOLD
-#define FOURIER_SPLIT_THRESHOLD (16 * 1024)
-#endif
-#ifndef FOURIER_NT_LOAD
-#define FOURIER_NT_LOAD 2
-#endif
-#ifndef FOURIER_NT_STORE
-#define FOURIER_NT_STORE 2
-#endif
+// Settled by A/B on the GPU (the knobs they were are profiles/r06_removed_ab_knobs.patch):
+//   cache policy: the data loads of every pass are non-temporal (each element is read once per pass; -10 % on the last pass of the
+//   2^20 plan, r01 session 8), and so are the final stores (+1 %) and the intermediate stores of passes up to L = 1024 and of the
+//   narrow-tile first passes of length 2048 / 4096 (+2 %, -3..-6 % on those passes; the one-workgroup-per-CU L = 2048 passes lose 8 %
+//   with them) -- PassPolicy in kernels_pass.h;
+//   SPLIT_THRESHOLD: exchange buffers above this many bytes are exchanged as two planes (re, im; f32 packed builds: two columns):
+//   half the LDS per workgroup, twice the workgroups per CU (16 KiB measured best over 2^8..2^20, r01 sweep);
+//   the shortest whole-transform kernels (f32 64, f64 32) move their data between global memory and registers through LDS
+//   (16-byte units, whole lines per instruction) instead of element accesses that cover 32 bytes of a line per instruction.
+constexpr size_t SPLIT_THRESHOLD = 16 * 1024;
 
 // 16-byte global accesses (global_load_dwordx4 / global_store_dwordx4)
 template <typename T, bool NT> __device__ __forceinline__ Unit16<T> load_unit(const void* p) {

@@ -303,7 +303,7 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
           if (a.blu_swap) y = {y.im, y.re};
           u.a[2 * v] = y.re * scale; u.a[2 * v + 1] = y.im * scale;
         }
-        buf_store_unit<T, FOURIER_BLU_OUT_ST_NT ? STAUX : BUF_PLAIN>(ro, voff + (uint32_t)r * rowb, u);
+        buf_store_unit<T, BUF_PLAIN>(ro, voff + (uint32_t)r * rowb, u);
       }
     } else {
       // output row of register r: j0 + s * (L*i + th + Q*r); the uniform part goes into the descriptor base
@@ -330,7 +330,7 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
       const uint32_t voff = (uint32_t)((pc0 + (uint64_t)(cg * VEC) + a.s * (uint64_t)th) * sizeof(cpx<T>));
       const uint32_t rowb = (uint32_t)(a.s * (uint64_t)Q * sizeof(cpx<T>));
 #pragma unroll
-      for (int r = 0; r < 8; ++r) c[r] = FOURIER_AB_CHIRP_LOAD(rc, voff + (uint32_t)r * rowb);
+      for (int r = 0; r < 8; ++r) c[r] = buf_load_unit<T>(rc, voff + (uint32_t)r * rowb);
     }
   };
 

@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(256) odd_last_kernel(OddArgs a) {
       }
       v.a[2 * c] = y.re; v.a[2 * c + 1] = y.im;
     }
-    if (last) store_unit<T, FOURIER_NT_STORE != 0>(out + (uint64_t)k * a.s, v);
+    if (last) store_unit<T, true>(out + (uint64_t)k * a.s, v);
     else store_unit<T, false>(out + (uint64_t)k * a.s, v);
   }
 }

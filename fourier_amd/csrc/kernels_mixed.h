@@ -132,30 +132,23 @@ template <typename T, int R> __device__ __forceinline__ void ref_butterfly(cpx<T
 // batch are only 8-byte aligned, which global_load/store_dwordx4 tolerate).  MAXU: compile-time bound of the units of a workgroup.
 // Up to eight units per thread are LOADED before the first of them is written: as a plain loop (`for u: lds[u] = g[u]`) hipcc
 // emits load, s_waitcnt vmcnt(0), ds_write per iteration -- one exposed HBM latency per 16 bytes of a thread's share (three per
-// workgroup at 768 points; FOURIER_MIX_COPY_BATCHED=0 restores that form for A/B).
-#ifndef FOURIER_MIX_COPY_BATCHED
-#define FOURIER_MIX_COPY_BATCHED 1
-#endif
+// workgroup at 768 points: +4 ... 22 % once batched, round 4).
 template <typename T, uint32_t NT, uint32_t MAXU, uint32_t CH = 8>  // CH: units of a thread in flight together
 __device__ __forceinline__ void copy_in_units(cpx<T>* lds, const cpx<T>* g, uint32_t units) {
   constexpr uint32_t VEC = 16 / (uint32_t)sizeof(cpx<T>);
-  if constexpr (FOURIER_MIX_COPY_BATCHED == 0) {
-    for (uint32_t u = threadIdx.x; u < units; u += NT) *(Unit16<T>*)(lds + u * VEC) = load_unit_a8<T>(g + u * VEC);
-  } else {
-    constexpr uint32_t IT = (MAXU + NT - 1) / NT;
+  constexpr uint32_t IT = (MAXU + NT - 1) / NT;
 #pragma unroll
-    for (uint32_t c0 = 0; c0 < IT; c0 += CH) {
-      Unit16<T> w[CH];
+  for (uint32_t c0 = 0; c0 < IT; c0 += CH) {
+    Unit16<T> w[CH];
 #pragma unroll
-      for (uint32_t q = 0; q < CH; ++q) {
-        const uint32_t u = threadIdx.x + (c0 + q) * NT;
-        if (c0 + q < IT && u < units) w[q] = load_unit_a8<T>(g + u * VEC);
-      }
+    for (uint32_t q = 0; q < CH; ++q) {
+      const uint32_t u = threadIdx.x + (c0 + q) * NT;
+      if (c0 + q < IT && u < units) w[q] = load_unit_a8<T>(g + u * VEC);
+    }
 #pragma unroll
-      for (uint32_t q = 0; q < CH; ++q) {
-        const uint32_t u = threadIdx.x + (c0 + q) * NT;
-        if (c0 + q < IT && u < units) *(Unit16<T>*)(lds + u * VEC) = w[q];
-      }
+    for (uint32_t q = 0; q < CH; ++q) {
+      const uint32_t u = threadIdx.x + (c0 + q) * NT;
+      if (c0 + q < IT && u < units) *(Unit16<T>*)(lds + u * VEC) = w[q];
     }
   }
 }
@@ -163,40 +156,29 @@ __device__ __forceinline__ void copy_in_units(cpx<T>* lds, const cpx<T>* g, uint
 template <typename T, uint32_t NT, uint32_t MAXU, uint32_t CH = 8>
 __device__ __forceinline__ void copy_out_units(cpx<T>* g, const cpx<T>* lds, uint32_t units, bool scaled, T scale) {
   constexpr uint32_t VEC = 16 / (uint32_t)sizeof(cpx<T>);
-  constexpr uint32_t IT = FOURIER_MIX_COPY_BATCHED ? (MAXU + NT - 1) / NT : 0;
+  constexpr uint32_t IT = (MAXU + NT - 1) / NT;
   // (the thread index behind a launder: the addresses below are then computed here, not shared with copy_in_units and carried -- or
   // spilled, under the register caps of the runtime-parameterised kernels -- across every pass)
   uint32_t tix = threadIdx.x;
   FOURIER_LAUNDER(tix);
-  if constexpr (FOURIER_MIX_COPY_BATCHED == 0) {
-    for (uint32_t u = tix; u < units; u += NT) {
-      Unit16<T> v = *(const Unit16<T>*)(lds + u * VEC);
-      if (scaled) {
 #pragma unroll
-        for (uint32_t c = 0; c < 2 * VEC; ++c) v.a[c] = v.a[c] * scale;
-      }
-      store_unit_a8<T>(g + u * VEC, v);
+  for (uint32_t c0 = 0; c0 < IT; c0 += CH) {
+    Unit16<T> w[CH];
+#pragma unroll
+    for (uint32_t q = 0; q < CH; ++q) {
+      const uint32_t u = tix + (c0 + q) * NT;
+      if (c0 + q < IT && u < units) w[q] = *(const Unit16<T>*)(lds + u * VEC);
     }
-  } else {
 #pragma unroll
-    for (uint32_t c0 = 0; c0 < IT; c0 += CH) {
-      Unit16<T> w[CH];
+    for (uint32_t q = 0; q < CH; ++q) {
+      const uint32_t u = tix + (c0 + q) * NT;
+      if (c0 + q < IT && u < units) {
+        Unit16<T> v = w[q];
+        if (scaled) {
 #pragma unroll
-      for (uint32_t q = 0; q < CH; ++q) {
-        const uint32_t u = tix + (c0 + q) * NT;
-        if (c0 + q < IT && u < units) w[q] = *(const Unit16<T>*)(lds + u * VEC);
-      }
-#pragma unroll
-      for (uint32_t q = 0; q < CH; ++q) {
-        const uint32_t u = tix + (c0 + q) * NT;
-        if (c0 + q < IT && u < units) {
-          Unit16<T> v = w[q];
-          if (scaled) {
-#pragma unroll
-            for (uint32_t c = 0; c < 2 * VEC; ++c) v.a[c] = v.a[c] * scale;
-          }
-          store_unit_a8<T>(g + u * VEC, v);
+          for (uint32_t c = 0; c < 2 * VEC; ++c) v.a[c] = v.a[c] * scale;
         }
+        store_unit_a8<T>(g + u * VEC, v);
       }
     }
   }
@@ -275,9 +257,7 @@ __device__ __forceinline__ void mixed_pass(cpx<T>* __restrict__ buf, const cpx<T
 // NT threads, PPT points per thread: group * n <= NT * PPT (128 x 8 / 256 x 4 / 256 x 8 up to 2048 points, 512 x 8 up to 4096, 1024 x 8 up to 8192).
 // The second launch bound (waves per SIMD) is what makes hipcc economise: left at 128 threads and no bound it spends 119
 // VGPRs on the f32 radix-7 instantiation, which halves the resident workgroups of a latency-bound kernel.
-#ifndef FOURIER_MIX_RT_WAVES
 #define FOURIER_MIX_RT_WAVES(T, MAXP, PPT) ((sizeof(T) == 4 ? ((MAXP) <= 7 ? ((PPT) <= 4 ? 6 : ((PPT) <= 8 ? 5 : 4)) : 4) : ((MAXP) <= 7 ? ((PPT) <= 4 ? 4 : ((PPT) <= 8 ? 3 : 4)) : 2)))
-#endif
 template <typename T, int MAXP, int PPT, int NT>
 __global__ void __launch_bounds__(NT, FOURIER_MIX_RT_WAVES(T, MAXP, PPT)) mixed_radix_kernel(MixArgs a) {
   FOURIER_DYN_SMEM(smem);
@@ -338,11 +318,11 @@ __global__ void __launch_bounds__(NT, FOURIER_MIX_RT_WAVES(T, MAXP, PPT)) mixed_
 // own rules; the tile passes of kernels_tiled.h run COLS = GROUP columns at a padded leading dimension)
 // LIN: the layout (mix_out_layout) of the data this pass reads
 template <typename T, uint32_t N, uint32_t SIZE, uint32_t STRIDE, uint32_t TWOFF, bool FIRST_PASS, uint32_t GROUP = mix_group<T>(N),
-          uint32_t NT_ = mix_threads<T>(N), uint32_t LD = N, bool TWL = false, bool GIO = false, uint32_t LIN = 0>
+          uint32_t NT_ = mix_threads<T>(N), uint32_t LD = N, bool GIO = false, uint32_t LIN = 0>
 struct MixPassesCT {
-  // entry (butterfly i, output k) of a pass's table of m butterflies: the reference's layout [i][k] (mod.rs:24-46), or -- TWL, the
-  // copy staged in LDS by stage_tables() -- transposed [k][i]
-  static __device__ __forceinline__ constexpr uint32_t tw_at(uint32_t i, uint32_t k, uint32_t r, uint32_t m) { return TWL ? k * m + i : i * r + k; }
+  // entry (butterfly i, output k) of a pass's table of m butterflies: the reference's layout [i][k] (mod.rs:24-46).  (A transposed copy
+  // staged in LDS where a workgroup's transforms share the tables was built and measured: no gain; profiles/r06_removed_ab_knobs.patch)
+  static __device__ __forceinline__ constexpr uint32_t tw_at(uint32_t i, uint32_t k, uint32_t r, uint32_t m) { (void)m; return i * r + k; }
   static constexpr uint32_t R = mix_next_radix(N, SIZE, FIRST_PASS), M = SIZE / R, NT = NT_;
   static constexpr bool PAIR = ((R == 3 || R == 5) && SIZE >= R * R && (SIZE / R) % R == 0 && mix_pairs<T>(N, R));
   // two consecutive radix-R passes (R = 3, 5) on one LDS round trip: the R butterflies (i + M2*k2, j), k2 < R, of this pass
@@ -451,21 +431,10 @@ struct MixPassesCT {
     finish(x, tw, q, fwd, w3, w8, y, out_off);
   }
 
-  using Next = MixPassesCT<T, N, OUT_SIZE, OUT_STRIDE, OUT_TWOFF, false, GROUP, NT_, LD, TWL, GIO, LOUT>;
+  using Next = MixPassesCT<T, N, OUT_SIZE, OUT_STRIDE, OUT_TWOFF, false, GROUP, NT_, LD, GIO, LOUT>;
   // entries of all tables from this pass on (the host uploads them back to back, mod.rs:24-46)
   static constexpr uint32_t table_end() {
     if constexpr (LAST) return OUT_TWOFF; else return Next::table_end();
-  }
-  // copies this and the following passes' tables from global memory into LDS, transposed (every thread of the workgroup; the
-  // caller's next barrier publishes them).  A table that is never read (size == R: no twiddle, mod.rs:238) is skipped.
-  static __device__ __forceinline__ void stage_tables(const cpx<T>* g, cpx<T>* l) {
-    if constexpr (SIZE != R) {
-      for (uint32_t e = threadIdx.x; e < SIZE; e += NT) l[TWOFF + (e % R) * M + e / R] = g[TWOFF + e];
-    }
-    if constexpr (PAIR && SIZE2 != R) {
-      for (uint32_t e = threadIdx.x; e < SIZE2; e += NT) l[TWOFF + SIZE + (e % R) * M2 + e / R] = g[TWOFF + SIZE + e];
-    }
-    if constexpr (!LAST) Next::stage_tables(g, l);
   }
   // gin / gout / scale: GIO only (mix_gio) -- the first pass reads the transforms from global memory (same element order as the
   // LDS buffer), the last pass scales and writes them to global memory; returns nullptr then (nothing is left to copy out)
@@ -568,15 +537,8 @@ __global__ void __launch_bounds__(mix_threads<T>(N)) mixed_radix_kernel_ct(MixAr
       if ((total % VEC) && threadIdx.x == 0) buf0[total - 1] = in[total - 1];
     }
   }
-  // twiddle tables shared by the GROUP transforms of this workgroup: staged in LDS behind the data (mix_tw_lds)
-  constexpr bool TWL = mix_tw_lds<T>(N);
-  using Passes = MixPassesCT<T, N, N, 1, 0, true, GROUP, NT, N, TWL, GIO>;
+  using Passes = MixPassesCT<T, N, N, 1, 0, true, GROUP, NT, N, GIO>;
   const cpx<T>* tw = (const cpx<T>*)a.tw;
-  if constexpr (TWL) {
-    cpx<T>* ltw = buf0 + (size_t)(mix_inplace<T>(N) ? 1 : 2) * GROUP * N;
-    Passes::stage_tables(tw, ltw);
-    tw = ltw;
-  }
   __syncthreads();
   const bool fwd = a.forward != 0;
   cpx<T> w3{(T)a.w3re, (T)a.w3im}, w8{(T)a.w8re, (T)a.w8im};

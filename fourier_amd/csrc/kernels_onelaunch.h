@@ -6,11 +6,8 @@
 FOURIER_KERNELS_BEGIN
 
 // register rows of a one-launch chirp-z kernel that carry user data: 8 of 16 (2n <= M: the upper half of the work array is padding on
-// the way in and beyond the user array on the way out; see bluestein_rows_kernel).  FOURIER_BLU_PRUNE=0 (A/B): all 16, as until round 5
-#ifndef FOURIER_BLU_PRUNE
-#define FOURIER_BLU_PRUNE 1
-#endif
-constexpr int BLU_ROWS = FOURIER_BLU_PRUNE ? 8 : 16;
+// the way in and beyond the user array on the way out; see bluestein_rows_kernel; all 16 until round 5: 7 - 19 % slower)
+constexpr int BLU_ROWS = 8;
 
 // ---- mid sizes N = L1 x L2 <= 2^15 (f32) / 2^14 (f64): BOTH Stockham passes in one launch ----
 // One workgroup owns one whole transform in registers (N/16 points per ... 16 points x VEC per thread),
@@ -60,9 +57,8 @@ template <typename T, int L1, int L2> struct TwolevelTr {
   static constexpr size_t BYTES = (size_t)(L1 / VEC) * (L2 + 1) * (SPLIT ? 8 : 16);
 };
 
-#ifndef FOURIER_TWOLEVEL_TW_BATCH
-#define FOURIER_TWOLEVEL_TW_BATCH(NT) ((NT) <= 128 ? 4 : 8)  // loads of the inter-pass twiddle table in flight per thread (2-wave workgroups live on occupancy: stay under 128 VGPRs)
-#endif
+// loads of the inter-pass twiddle table in flight per thread (2-wave workgroups live on occupancy: stay under 128 VGPRs)
+constexpr int twolevel_tw_batch(int nt) { return nt <= 128 ? 4 : 8; }
 // Both passes of an N = L1 x L2 transform on register-resident data.  In: thread (th = tid / CG1,
 // cg = tid % CG1) holds rows th + Q1*r of the L1 x L2 row-major matrix (element row*L2 + col), columns
 // cg*VEC + v.  Out: thread (th2 = tid / CG2, cg2 = tid % CG2) holds X[k1 + L1*k2] for k2 = th2 + Q2*r,
@@ -84,7 +80,7 @@ __device__ __forceinline__ void twolevel_core(cpx<T> (*x)[16], int tid, unsigned
   {
     const BufRsrc rt = make_rsrc(tw_full);
     const uint32_t voff = (uint32_t)((th * L2 + cg * VEC) * sizeof(cpx<T>));
-    units_batched<T, FOURIER_TWOLEVEL_TW_BATCH(Q1 * CG1)>(
+    units_batched<T, twolevel_tw_batch(Q1 * CG1)>(
         [&](int r) { return buf_load_unit<T>(rt, voff, (uint32_t)((Q1 * r) * L2 * sizeof(cpx<T>))); },
         [&](int r, const Unit16<T>& u) {
 #pragma unroll
@@ -286,7 +282,7 @@ __global__ void __launch_bounds__(FOURIER_TWOLEVEL_NT(T, L1, L2), FOURIER_MIN_WA
     const uint32_t voff = (uint32_t)((th * L2 + cg * VEC) * sizeof(cpx<T>));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const Unit16<T> u = buf_load_unit<T, FOURIER_NT_LOAD != 0 ? BUF_NT : BUF_PLAIN>(ri, voff, (uint32_t)((Q1 * r) * L2 * sizeof(cpx<T>)));
+      const Unit16<T> u = buf_load_unit<T, BUF_NT>(ri, voff, (uint32_t)((Q1 * r) * L2 * sizeof(cpx<T>)));
 #pragma unroll
       for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
     }
@@ -313,12 +309,7 @@ __global__ void __launch_bounds__(FOURIER_TWOLEVEL_NT(T, L1, L2), FOURIER_MIN_WA
       if (a.swap_out) y = {y.im, y.re};
       u.a[2 * v] = y.re * scale; u.a[2 * v + 1] = y.im * scale;
     }
-#ifdef FOURIER_TWOLEVEL_STORE_SOFF  // A/B only: reproduces the corruption described at buf_store_unit
-    __builtin_amdgcn_raw_buffer_store_b128(*(const decltype(__builtin_amdgcn_raw_buffer_load_b128(ro, 0, 0, 0))*)&u, ro, (int)voff,
-                                           (int)((Q2 * r) * L1 * sizeof(cpx<T>)), FOURIER_NT_STORE != 0 ? BUF_NT : BUF_PLAIN);
-#else
-    buf_store_unit<T, FOURIER_NT_STORE != 0 ? BUF_NT : BUF_PLAIN>(make_rsrc(obase + (Q2 * r) * L1), voff, u);
-#endif
+    buf_store_unit<T, BUF_NT>(make_rsrc(obase + (Q2 * r) * L1), voff, u);
   }
 }
 

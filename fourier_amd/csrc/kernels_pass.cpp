@@ -66,9 +66,6 @@ KernelInfo get_kernel(Real<TUReal>, int L, int mode, int io) {
   throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "no kernel for pass length " + std::to_string(L));
 }
 
-#ifndef FOURIER_CONV_CG_1024
-#define FOURIER_CONV_CG_1024 FOURIER_CG_1024
-#endif
 // fft_conv_kernel: forward LAST + (.) w + inverse FIRST of a Bluestein plan, same tile shapes as the passes
 template <typename T, int L, int CG> static KernelInfo make_conv_info() {
   using C = TileCfg<T, L, CG>;
@@ -85,7 +82,7 @@ KernelInfo get_conv_kernel(Real<TUReal>, int L) {
     case 128: return make_conv_info<T, 128, 16>();
     case 256: return make_conv_info<T, 256, 16>();
     case 512: return make_conv_info<T, 512, FOURIER_CG_512>();
-    case 1024: return make_conv_info<T, 1024, FOURIER_CONV_CG_1024>();
+    case 1024: return make_conv_info<T, 1024, FOURIER_CG_1024>();
     case 2048: return make_conv_info<T, 2048, FOURIER_CG_2048>();
     default: break;
   }

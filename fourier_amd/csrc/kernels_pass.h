@@ -18,7 +18,7 @@ template <typename T, int L, int CG> struct TileCfg {
   // cg (the row-contiguous mapping) hit distinct banks.
   static constexpr int PADU = (Q == 1) ? 0 : ((CG >= 32) ? L : (L * CG) / 32);
   static constexpr int UNITS = (Q == 1) ? 0 : L * CG + PADU;
-  static constexpr bool SPLIT = (size_t)UNITS * 16 > FOURIER_SPLIT_THRESHOLD;  // exchange re and im planes separately
+  static constexpr bool SPLIT = (size_t)UNITS * 16 > SPLIT_THRESHOLD;  // exchange re and im planes separately
   static constexpr size_t EXCH_BYTES = SPLIT ? (size_t)UNITS * 8 : (size_t)UNITS * 16;
   static constexpr size_t TABU_OFF = (EXCH_BYTES + 15) & ~(size_t)15;
   static constexpr size_t TABU_BYTES = (size_t)COLS * 16 * sizeof(cpx<T>);
@@ -30,7 +30,7 @@ template <typename T, int L, int CG> struct TileCfg {
   // c * STAGE_LP + p (pass_tile).  The pad keeps the gather of a half-wave (th + Q*r at fixed r) on distinct banks.
   // Measured (r03_s28_rows_staged_io_ab.jsonl): f32 64 51 -> 62 % of the HBM peak, f64 32 58 -> 64 %; with 64-byte pieces
   // and wider the element form is as good or better (f32 128 64 / 63 %, f64 64 64 / 59 %, f64 128 72 / 59 %).
-  static constexpr bool ROWS_STAGED = (FOURIER_ROWS_STAGED != 0) && Q >= 2 && Q * 2 * (int)sizeof(T) <= 32;
+  static constexpr bool ROWS_STAGED = Q >= 2 && Q * 2 * (int)sizeof(T) <= 32;
   static constexpr int STAGE_LP = L + 4;
   static constexpr size_t STAGE_BYTES = ROWS_STAGED ? (size_t)(COLS / 2) * STAGE_LP * 2 * sizeof(T) : 0;
   static constexpr size_t SMEM_PLAIN = EXCH_BYTES > STAGE_BYTES ? EXCH_BYTES : STAGE_BYTES;
@@ -41,8 +41,24 @@ template <typename T, int L, int CG> struct TileCfg {
   // LAYOUT 1 ("xor"):  for the stage-1 exchange of the split-plane tiles, where a 16-lane ds_write_b64
   //   group holds 16/CG threads whose positions differ by 16: flip the unit index by the 16-block
   //   parity so those threads land in different bank quarters; reads (cg-fastest) stay contiguous.
+  // LAYOUT 2 ("rows"): the whole-transform kernels (MODE_ROWS), whose lanes walk th = tid % Q -- a write instruction touches positions
+  //   16*th + r, a read instruction positions th + Q*r, a wave spans 64 / Q column groups.  Under the skew layout that is 2.3x (L = 512, 1024)
+  //   to 6.7x (L = 128) the conflict-free LDS cycles: SQ_LDS_BANK_CONFLICT = 57 % of the LDS cycles of the chirp-z kernel of M = 512, and the
+  //   emulator's bank model agrees to three digits (round 6, profiles/r06_s3_sq_chirpz.json).  An XOR swizzle per (L, CG), found by
+  //   tools/lds_rows_swizzle_search.py by exhaustive search over this family under the bank model of MI355X_MICROARCH.md: every row-mode
+  //   exchange conflict-free, no padding units.
+  struct RowSwz { int a, ma, b1, s1, b2, s2; };
+  static constexpr bool HAS_ROW_SWZ = (L == 32 && CG == 32) || (L == 64 && CG == 16) || (L == 128 && (CG == 16 || CG == 32)) || (L == 256 && CG == 16) ||
+                                      ((L == 512 || L == 1024) && CG == 8);
+  static constexpr RowSwz row_swz() {
+    return L == 32 ? RowSwz{0, 0, 0, 4, 1, 0} : L == 64 ? RowSwz{0, 0, 0, 2, 2, 0} : (L == 128 && CG == 16) ? RowSwz{0, 0, 0, 1, 3, 0}
+           : L == 128 ? RowSwz{0, 0, 0, 2, 3, 0} : L == 256 ? RowSwz{0, 0, 0, 0, 4, 0} : RowSwz{7, 1, 1, 0, 4, 0};
+  }
   template <int LAYOUT> static __device__ __forceinline__ int unit_index(int pos, int cg) {
-    if constexpr (LAYOUT == 1 && CG <= 8) return (pos * CG + cg) ^ (((pos >> 4) & (16 / CG - 1)) * CG);
+    if constexpr (LAYOUT == 2 && HAS_ROW_SWZ) {
+      constexpr RowSwz z = row_swz();
+      return (pos ^ ((pos >> z.a) & z.ma)) * CG + (cg ^ (((pos >> z.b1) << z.s1) & (CG - 1)) ^ (((pos >> z.b2) << z.s2) & (CG - 1)));
+    } else if constexpr (LAYOUT == 1 && CG <= 8) return (pos * CG + cg) ^ (((pos >> 4) & (16 / CG - 1)) * CG);
     else return pos * CG + cg + ((CG >= 32) ? pos : ((pos * CG) >> 5));
   }
 };
@@ -136,14 +152,10 @@ template <typename T, int B, typename Ld, typename Use>
 __device__ __forceinline__ void units_batched(const Ld& ld, const Use& use) { units_batched_rows<T, B, 16>(ld, use); }
 
 // x[v][k] *= t[k], k = 1..15 (t[0] = 1): the stage twiddles of one thread, sixteen consecutive table entries.  All of
-// them (f64: half of them) are loaded in one batch -- under FOURIER_STAGE_TW_BATCHED; otherwise hipcc picks the grouping
-#ifndef FOURIER_STAGE_TW_BATCH
-#define FOURIER_STAGE_TW_BATCH 8
-#endif
+// them (f64: half of them) are loaded in one batch; left alone hipcc picks a grouping that waits per load (r03; 0 and 4 per batch: slower)
 template <typename T, int VEC>
 __device__ __forceinline__ void stage_twiddle(cpx<T> (&x)[VEC][16], const cpx<T>* t) {
-#if FOURIER_STAGE_TW_BATCH > 0
-  constexpr int PER = 16 / (int)sizeof(cpx<T>), NU = 16 / PER, B = FOURIER_STAGE_TW_BATCH < NU ? FOURIER_STAGE_TW_BATCH : NU;
+  constexpr int PER = 16 / (int)sizeof(cpx<T>), NU = 16 / PER, B = 8 < NU ? 8 : NU;
 #pragma unroll
   for (int u0 = 0; u0 < NU; u0 += B) {
     Unit16<T> u[B];
@@ -165,14 +177,6 @@ __device__ __forceinline__ void stage_twiddle(cpx<T> (&x)[VEC][16], const cpx<T>
       }
     FOURIER_SCHED_FENCE();
   }
-#else
-#pragma unroll
-  for (int k = 1; k < 16; ++k) {
-    const cpx<T> w = t[k];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) x[v][k] = cmul(x[v][k], w);
-  }
-#endif
 }
 
 template <typename T>
@@ -207,8 +211,17 @@ __device__ __forceinline__ uint32_t xcd_remap_base(const PassArgs& a, uint64_t b
 // the same DRAM bank set at the same moment (round 6, profiles/r06_s2_placement2_*.jsonl: the slow mode of the last passes belongs
 // to exactly those allocations).  The rotation makes the streams differ in the tile-column bits; still a bijection.
 __device__ __forceinline__ uint32_t xcd_remap(const PassArgs& a, uint64_t blk64, uint64_t nwg64) {
-  const uint32_t idx = xcd_remap_base(a, blk64, nwg64);
+  uint32_t idx = xcd_remap_base(a, blk64, nwg64);
   const uint32_t tiles = (uint32_t)a.tiles;
+  if (a.xcd_phase != 0 && a.nxcd > 1 && tiles >= 1) {
+    // ... and a per-XCD PHASE in the walk through its own range of whole transforms (A/B, round 6): XCD x is x * xcd_phase transforms ahead
+    // inside its range (wrapping around), so the eight streams are (range + phase) apart instead of exactly one range
+    const uint32_t nb = (uint32_t)nwg64 / tiles;
+    if (nb % a.nxcd == 0) {
+      const uint32_t tpx = nb / a.nxcd, b = idx / tiles, g = b / tpx, off = b - g * tpx;
+      idx = (g * tpx + (off + g * a.xcd_phase) % tpx) * tiles + (idx - b * tiles);
+    }
+  }
   if (a.xcd_rot == 0 || a.nxcd <= 1 || tiles <= 1) return idx;
   // keyed by the transform, not by the block: g = the XCD that owns transform b when the ranges are whole transforms (batch a multiple of
   // the XCD count) -- a permutation of each transform's own tiles for ANY batch
@@ -282,7 +295,7 @@ __device__ __forceinline__ void tile_core(RegTile<T, L, CG>& x, int& th, int& cg
       const int th_r = remap ? tb % Q : th, cg_r = remap ? tb / Q : cg;
       const int th_w = th;
       // both sides cg-fastest and split planes -> xor layout; anything row-contiguous -> skew layout
-      constexpr int LAY1 = (C::SPLIT && !IN_ROWS && !(MODE == MODE_FIRST && R3 == 1)) ? 1 : 0;
+      constexpr int LAY1 = IN_ROWS ? 2 : ((C::SPLIT && !(MODE == MODE_FIRST && R3 == 1)) ? 1 : 0);
       if constexpr (DO_EXCH)
         lds_exchange<T, L, CG, LAY1>(x, smem, cg, [=](int r) { return 16 * th_w + r; }, th_r, cg_r, 0);
       th = th_r; cg = cg_r;
@@ -316,7 +329,7 @@ __device__ __forceinline__ void tile_core(RegTile<T, L, CG>& x, int& th, int& cg
         const int jw = th & 15, iw = th >> 4;
         __syncthreads();  // all reads of exchange 1 are done before the buffer is rewritten
         if constexpr (DO_EXCH)
-        lds_exchange<T, L, CG, 0>(x, smem, cg, [=](int r) { return jw + 16 * (16 * iw + r); }, th_r, cg_r, 4);
+        lds_exchange<T, L, CG, IN_ROWS ? 2 : 0>(x, smem, cg, [=](int r) { return jw + 16 * (16 * iw + r); }, th_r, cg_r, 4);
         th = th_r; cg = cg_r;
       }
       // ---- stage 3: radix R3 on register sets {u + NB3*k'}
@@ -337,45 +350,6 @@ __device__ __forceinline__ void tile_core(RegTile<T, L, CG>& x, int& th, int& cg
   }
 }
 
-// Row-contiguous stores of an f32 register tile, 16 bytes per lane.  In the th-fastest mapping a thread holds outputs k = th + Q*r
-// of TWO columns (v = 0, 1), so its natural store is one 8-byte element per column -- 32 global_store_dwordx2 per thread, half
-// the bytes per instruction of everything else in these kernels.  Lanes l and l ^ 1 hold k and k + 1 of the same two columns:
-// one DPP exchange per value (the even lane sends its column-1 value and receives the odd lane's column-0 value) leaves the
-// even lane with (k, k + 1) of column 0 and the odd lane with (k, k + 1) of column 1 -- 16 global_store_dwordx4 per thread, a
-// wave's instruction covering 512 contiguous bytes of each column.  Same values, same addresses.
-// MEASURED, NO GAIN (round 4, profiles/r04_s10_paired_16_byte_row_stores_ab.jsonl, shared buffers, seven alternating repetitions):
-// C2's first pass 12.03 against 12.08 ms, C5's 12.34 against 12.20, C4's chirp-in pass 2.75 against 2.64, the conv kernel 3.82 / 3.81,
-// whole rows N = 128 ... 1024 within +-1.5 % -- the 8-byte stores were not what holds these kernels.  Off; the knob stays for A/B.
-#ifndef FOURIER_PAIRED_ROW_STORES
-#define FOURIER_PAIRED_ROW_STORES 0
-#endif
-__device__ __forceinline__ float shfl_xor1(float v) {
-  int i;
-  __builtin_memcpy(&i, &v, 4);
-  i = __shfl_xor(i, 1);
-  __builtin_memcpy(&v, &i, 4);
-  return v;
-}
-// base0 / base1: where column 0 / column 1 of this thread starts (element k = 0); ok0 / ok1: the column exists (ragged ROWS tile)
-template <int Q, bool NT, typename Fin>
-__device__ __forceinline__ void store_rows_paired(cpx<float> (&x)[2][16], cpx<float>* base0, cpx<float>* base1, bool ok0, bool ok1, int th,
-                                                  const Fin& fin) {
-  static_assert(Q % 2 == 0, "pairs of adjacent lanes share two columns");
-  const bool odd = (th & 1) != 0;
-  cpx<float>* p = (odd ? base1 : base0) + (th & ~1);
-  const bool ok = odd ? ok1 : ok0;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const cpx<float> y0 = fin(x[0][r]), y1 = fin(x[1][r]);
-    const cpx<float> send = odd ? y0 : y1;
-    const cpx<float> recv{shfl_xor1(send.re), shfl_xor1(send.im)};
-    Unit16<float> u;
-    u.a[0] = odd ? recv.re : y0.re; u.a[1] = odd ? recv.im : y0.im;  // element k
-    u.a[2] = odd ? y1.re : recv.re; u.a[3] = odd ? y1.im : recv.im;  // element k + 1
-    if (ok) store_unit<float, NT>(p + Q * r, u);
-  }
-}
-
 // The body of a pass: one tile (block index `blk0` of `nblk`) of one big-radix Stockham pass.  LDPOL / STPOL = cache
 // policy of the data loads / stores (POL_*): the stand-alone pass kernels stream (non-temporal), the XCD-fused kernel
 // parks its intermediate in the L2 (plain stores, sc1 loads).
@@ -387,12 +361,6 @@ __device__ __forceinline__ void store_rows_paired(cpx<float> (&x)[2][16], cpx<fl
 // tile each (two per CU, load and compute phases overlap) instead of one 1024-thread workgroup whose 256 KiB tile
 // fills the CU's registers; the tile is read twice, the second time from the XCD's L2 (the two workgroups are adjacent
 // blocks of one XCD), written once.
-#ifdef FOURIER_AB_NO_CHIRP  // timing experiment only (wrong results): the chirp is not read
-template <typename T> __device__ __forceinline__ Unit16<T> ab_ones() { Unit16<T> u; for (int i = 0; i < (int)(16 / sizeof(T)); ++i) u.a[i] = (i & 1) ? (T)0 : (T)1; return u; }
-#define FOURIER_AB_CHIRP_LOAD(rc, off) ab_ones<T>()
-#else
-#define FOURIER_AB_CHIRP_LOAD(rc, off) buf_load_unit<T>(rc, off)
-#endif
 // (x * y) mod n for x, y with x*y < 2^53, exactly: the f64 product and the fused remainder are exact, the quotient estimate
 // is off by at most one
 __device__ __forceinline__ uint32_t mulmod_n(uint32_t x, uint32_t y, double n, double inv_n) {
@@ -409,15 +377,6 @@ template <typename T> __device__ __forceinline__ cpx<T> root_n(const PassArgs& a
   return cmul(lo[e & ((1u << a.tn_bits) - 1u)], hi[e >> a.tn_bits]);
 }
 
-#ifndef FOURIER_ROWS_STAGED_LOADS_FIRST
-#define FOURIER_ROWS_STAGED_LOADS_FIRST 1
-#endif
-#ifndef FOURIER_TABS_AFTER_LOADS
-#define FOURIER_TABS_AFTER_LOADS 1
-#endif
-#ifndef FOURIER_BLU_OUT_ST_NT
-#define FOURIER_BLU_OUT_ST_NT 0
-#endif
 struct NoHook {
   __device__ __forceinline__ void operator()() const {}
 };
@@ -468,8 +427,8 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
   constexpr int LDAUX = LDPOL == POL_NT ? BUF_NT : (LDPOL == POL_SC1 ? BUF_SC1 : BUF_PLAIN);
   constexpr int STAUX = STPOL == POL_NT ? BUF_NT : BUF_PLAIN;
 
-  // ---- inter-pass twiddle table for this tile: tabU[col][r] = W_size^{i_col * Q * r}.  Filled BEHIND the tile's own loads
-  // (FOURIER_TABS_AFTER_LOADS): its table loads feed LDS writes, and ahead of the tile's loads -- where it used to sit -- their L2
+  // ---- inter-pass twiddle table for this tile: tabU[col][r] = W_size^{i_col * Q * r}.  Filled BEHIND the tile's own loads:
+  // its table loads feed LDS writes, and ahead of the tile's loads -- where it used to sit -- their L2
   // latency was served before the first HBM load of the tile was issued, once per tile
   auto fill_tabs = [&]() {
   if constexpr (TWIDDLED) {
@@ -495,8 +454,6 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
     }
   }
   };
-  if constexpr (FOURIER_TABS_AFTER_LOADS == 0) fill_tabs();
-
   // ---- load: register r <- row th + Q*r
   cpx<T> x[VEC][16];
   constexpr bool STAGED = IN_ROWS && C::ROWS_STAGED;
@@ -509,38 +466,27 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
     stage_valid = (uint32_t)(left < (uint64_t)COLS ? left : (uint64_t)COLS) * (uint32_t)L;
     cpx<T>* stage = (cpx<T>*)smem;
     const cpx<T>* src = in + g0 * L;
-    // every unit of BOTH halves is loaded before the first LDS write (FOURIER_ROWS_STAGED_LOADS_FIRST): one memory latency per tile
-    // instead of one per half (the registers are free: x is filled from LDS afterwards)
+    // every unit of BOTH halves is loaded before the first LDS write: one memory latency per tile instead of one per half (the
+    // registers are free: x is filled from LDS afterwards)
     constexpr int SITER = (HALF * L / VEC + C::NT - 1) / C::NT;
-    Unit16<T> sw[FOURIER_ROWS_STAGED_LOADS_FIRST ? 2 : 1][SITER];
-    if constexpr (FOURIER_ROWS_STAGED_LOADS_FIRST != 0) {
+    Unit16<T> sw[2][SITER];
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int it = 0; it < SITER; ++it) {
-          const int u = tid + it * C::NT;
-          const uint32_t eh = (uint32_t)u * VEC, e = (uint32_t)(h * HALF * L) + eh;
-          Unit16<T> w{};
-          if (u < HALF * L / VEC && e < stage_valid) w = load_unit_a8<T>(src + e);
-          sw[h][it] = w;
-        }
-    }
+      for (int it = 0; it < SITER; ++it) {
+        const int u = tid + it * C::NT;
+        const uint32_t eh = (uint32_t)u * VEC, e = (uint32_t)(h * HALF * L) + eh;
+        Unit16<T> w{};
+        if (u < HALF * L / VEC && e < stage_valid) w = load_unit_a8<T>(src + e);
+        sw[h][it] = w;
+      }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      if constexpr (FOURIER_ROWS_STAGED_LOADS_FIRST != 0) {
 #pragma unroll
-        for (int it = 0; it < SITER; ++it) {
-          const int u = tid + it * C::NT;
-          const uint32_t eh = (uint32_t)u * VEC;
-          if (u < HALF * L / VEC) *(Unit16<T>*)(stage + (eh / L) * LP + (eh % L)) = sw[h][it];
-        }
-      } else {
-        for (int u = tid; u < HALF * L / VEC; u += C::NT) {
-          const uint32_t eh = (uint32_t)u * VEC, e = (uint32_t)(h * HALF * L) + eh;
-          Unit16<T> w{};
-          if (e < stage_valid) w = load_unit_a8<T>(src + e);
-          *(Unit16<T>*)(stage + (eh / L) * LP + (eh % L)) = w;
-        }
+      for (int it = 0; it < SITER; ++it) {
+        const int u = tid + it * C::NT;
+        const uint32_t eh = (uint32_t)u * VEC;
+        if (u < HALF * L / VEC) *(Unit16<T>*)(stage + (eh / L) * LP + (eh % L)) = sw[h][it];
       }
       __syncthreads();
 #pragma unroll
@@ -575,7 +521,7 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
     Unit16<T> d[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) d[r] = buf_load_unit<T, LDAUX>(rd, voff + (uint32_t)r * rowb);
-    if constexpr (FOURIER_TABS_AFTER_LOADS != 0) fill_tabs();
+    fill_tabs();
     if (a.blu_p) {
       // chirp computed, not read: x[k] = P[row] * (U[b] * W_n^{cn*b*th}) * tabV[col][r]   (see PassArgs)
       const cpx<T>* pt = (const cpx<T>*)a.blu_p + th;
@@ -605,7 +551,7 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
     } else {
       Unit16<T> c[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) c[r] = FOURIER_AB_CHIRP_LOAD(rc, voff + (uint32_t)r * rowb);
+      for (int r = 0; r < 8; ++r) c[r] = buf_load_unit<T>(rc, voff + (uint32_t)r * rowb);
 #pragma unroll
       for (int r = 0; r < 8; ++r)
 #pragma unroll
@@ -649,7 +595,7 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
 #pragma unroll
       for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
     }
-    if constexpr (FOURIER_TABS_AFTER_LOADS != 0) fill_tabs();
+    fill_tabs();
   }
   if (a.swap_in) {
 #pragma unroll
@@ -698,7 +644,7 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
         }
       }
       __syncthreads();
-      if constexpr (FOURIER_ROWS_STAGED_LOADS_FIRST != 0) {  // (the LDS reads of a half ahead of its first store, as on the way in)
+      {  // (the LDS reads of a half ahead of its first store, as on the way in)
         constexpr int SITER = (HALF * L / VEC + C::NT - 1) / C::NT;
         Unit16<T> sw[SITER];
 #pragma unroll
@@ -713,26 +659,8 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
           const uint32_t eh = (uint32_t)u * VEC, e = (uint32_t)(h * HALF * L) + eh;
           if (u < HALF * L / VEC && e < stage_valid) store_unit_a8<T>(dst + e, sw[it]);
         }
-      } else {
-        for (int u = tid; u < HALF * L / VEC; u += C::NT) {
-          const uint32_t eh = (uint32_t)u * VEC, e = (uint32_t)(h * HALF * L) + eh;
-          if (e < stage_valid) store_unit_a8<T>(dst + e, *(const Unit16<T>*)(stage + (eh / L) * LP + (eh % L)));
-        }
       }
       __syncthreads();
-    }
-  } else if constexpr (OUT_ROWS && VEC == 2 && Q % 2 == 0 && FOURIER_PAIRED_ROW_STORES != 0) {
-    if constexpr (sizeof(T) == 4) {  // (VEC == 2 is f32)
-      const uint64_t gc = g0 + (uint64_t)(cg * VEC);
-      const bool swap_out = FINAL && a.swap_out;
-      store_rows_paired<Q, STPOL == POL_NT>(x, out + gc * L, out + (gc + 1) * L, MODE != MODE_ROWS || gc < a.total_cols,
-                                             MODE != MODE_ROWS || gc + 1 < a.total_cols, th, [&](cpx<T> y) {
-                                               if constexpr (FINAL) {
-                                                 if (swap_out) y = {y.im, y.re};
-                                                 y = {y.re * scale, y.im * scale};
-                                               }
-                                               return y;
-                                             });
     }
   } else if constexpr (OUT_ROWS) {
 #pragma unroll
@@ -760,7 +688,7 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
     const uint32_t rowb = (uint32_t)(a.s * (uint64_t)(KM * Q) * sizeof(cpx<T>));
     Unit16<T> c[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) c[r] = FOURIER_AB_CHIRP_LOAD(rc, voff + (uint32_t)r * rowb);
+    for (int r = 0; r < 8; ++r) c[r] = buf_load_unit<T>(rc, voff + (uint32_t)r * rowb);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       Unit16<T> u;
@@ -774,7 +702,7 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
       }
       // no streaming hint: the user rows of an odd-length f32 batch are only 8-byte aligned, a wave's 128-byte row segment
       // then straddles two lines, and the L2 must be allowed to merge the halves (NT: +29 % bytes written, PMC, round 3)
-      buf_store_unit<T, FOURIER_BLU_OUT_ST_NT ? STAUX : BUF_PLAIN>(ro, voff + (uint32_t)r * rowb, u);
+      buf_store_unit<T, BUF_PLAIN>(ro, voff + (uint32_t)r * rowb, u);
     }
   } else {
     // output row of register r: j0 + s * (KM*L*i + KM*(th + Q*r) + par); uniform part in the descriptor base
@@ -799,21 +727,15 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
   }
 }
 
-#ifndef FOURIER_NT_STORE_NARROW_2048
-#define FOURIER_NT_STORE_NARROW_2048 1  // streaming intermediate stores also for the narrow-tile (two workgroups per CU) first passes of length 2048 / 4096: -3..-6 % on that pass (profiles/r03_s8_*.jsonl); 0 = plain
-#endif
-// default cache policy of the stand-alone pass kernels (see the FOURIER_NT_* notes at the top of this file)
+// cache policy of the stand-alone pass kernels (kernels_common.h has the measurements)
 template <int L, int MODE, int CG = 8> struct PassPolicy {
   static constexpr bool FINAL = (MODE == MODE_LAST || MODE == MODE_ROWS);
   // 64-byte-wide tiles (CG = 4): two workgroups share every 128-byte line, the second one must find it in the L2, so
   // no streaming hint (L = 2048 first pass: 6.5 vs 7.6 ms per 1024 transforms of 2^21, r01 session 11)
-  static constexpr int LD = (MODE != MODE_ROWS && CG < 8) ? POL_PLAIN
-                            : (FOURIER_NT_LOAD == 3 && MODE == MODE_LAST) ? POL_SC1  // A/B (round 6): last-pass loads that bypass the L1 only
-                            : ((MODE == MODE_FIRST && FOURIER_NT_LOAD != 0) || FOURIER_NT_LOAD == 2) ? POL_NT : POL_PLAIN;
+  static constexpr int LD = (MODE != MODE_ROWS && CG < 8) ? POL_PLAIN : POL_NT;
   // MODE_ROWS: a wave's element stores only form whole lines for L >= 256; below that they rely on L2
   // write-combining and a non-temporal hint is a 2-6x loss (N = 16..64, r01 session 9)
-  static constexpr int ST = (MODE == MODE_ROWS ? (FOURIER_NT_STORE != 0 && L >= 256)
-                             : (FINAL ? FOURIER_NT_STORE != 0 : (FOURIER_NT_STORE == 2 && (L <= 1024 || (FOURIER_NT_STORE_NARROW_2048 && CG < 8))))) ? POL_NT : POL_PLAIN;
+  static constexpr int ST = (MODE == MODE_ROWS ? L >= 256 : (FINAL || L <= 1024 || CG < 8)) ? POL_NT : POL_PLAIN;
 };
 
 template <typename T, int L, int CG, int MODE, int IO = IO_PLAIN>
@@ -822,19 +744,6 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
   pass_tile<T, L, CG, MODE, IO, PassPolicy<L, MODE, CG>::LD, PassPolicy<L, MODE, CG>::ST>(a, blockIdx.x, gridDim.x, smem, (int)threadIdx.x);
 }
 
-#ifndef FOURIER_CONV_MIN_WAVES
-#define FOURIER_CONV_MIN_WAVES(NT) FOURIER_MIN_WAVES(NT)
-#endif
-// A/B knobs of the conv kernel (tools/build_variants.py): non-temporal stores / non-temporal loads of the w table
-#ifndef FOURIER_CONV_ST_NT
-#define FOURIER_CONV_ST_NT 1  // with the XCD-sliced tile order of launch_conv: 4.5 vs 4.75 ms (C4), 7.8 vs 8.3 ms (N = 65537), r02 session 3
-#endif
-#ifndef FOURIER_CONV_W_NT
-#define FOURIER_CONV_W_NT 0
-#endif
-#ifndef FOURIER_CONV_W_BATCH
-#define FOURIER_CONV_W_BATCH 8  // loads of the w table in flight per thread
-#endif
 // ---- Bluestein middle (bluesteins.rs:236-239): LAST pass of the forward inner FFT, (.) w, and FIRST pass of
 // the inverse inner FFT in ONE launch.  The last forward pass (R = L, s = M/L) leaves X[j + (M/L)*k] of its
 // column tile in registers; an inverse FFT whose first pass has the same length (R = L, s = 1, m = M/L) reads
@@ -842,7 +751,7 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
 // one write of the work array instead of two of each.  The inverse is swap . DFT . swap (mod.rs:366-387):
 // the leading swap happens here, the trailing one in the inverse plan's last pass.
 template <typename T, int L, int CG>
-__global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16) * CG)) fft_conv_kernel(PassArgs a) {
+__global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG)) fft_conv_kernel(PassArgs a) {
   using C = TileCfg<T, L, CG>;
   constexpr int VEC = C::VEC, Q = C::Q, COLS = C::COLS;
   static_assert(Q > 1, "conv kernel: L >= 32");
@@ -866,8 +775,6 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16)
       tabU[idx] = two_level_twiddle<T>(a, i * (uint64_t)(Q * (idx & 15)));
     }
   };
-  if constexpr (FOURIER_TABS_AFTER_LOADS == 0) fill_tabs();
-
   // forward LAST pass: rows th + Q*r (stride cn) of columns c0 + cg*VEC + v
   cpx<T> x[VEC][16];
   int th = tid / CG, cg = tid % CG;
@@ -877,12 +784,12 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       // tiles narrower than a 128-byte line share every line with a sibling workgroup: no streaming hint then
-      const Unit16<T> u = buf_load_unit<T, (FOURIER_NT_LOAD == 2 && CG >= 8) ? BUF_NT : BUF_PLAIN>(rs, voff, (uint32_t)r * rowb);
+      const Unit16<T> u = buf_load_unit<T, CG >= 8 ? BUF_NT : BUF_PLAIN>(rs, voff, (uint32_t)r * rowb);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
     }
   }
-  if constexpr (FOURIER_TABS_AFTER_LOADS != 0) fill_tabs();
+  fill_tabs();
   tile_core<T, L, CG, MODE_LAST>(x, th, cg, tid, smem, (const cpx<T>*)a.tw1, (const cpx<T>*)a.tw2);
   // register r holds X[c + cn*(th + Q*r)]: (.) w (FFT'd chirp, 1/M folded in), then the inverse's leading swap
   {
@@ -890,14 +797,9 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16)
     FOURIER_LAUNDER(t);
     const BufRsrc rw = make_rsrc(a.mul);
     const uint32_t voff = (uint32_t)(((uint64_t)(t / CG) * a.cn + c0 + (uint64_t)((t % CG) * VEC)) * sizeof(cpx<T>));
-    units_batched<T, FOURIER_CONV_W_BATCH>(
-        [&](int r) {
-#ifdef FOURIER_AB_NO_W
-          Unit16<T> u1; for (int i = 0; i < (int)(16 / sizeof(T)); ++i) u1.a[i] = (i & 1) ? (T)0 : (T)1; return u1;
-#else
-          return buf_load_unit<T, FOURIER_CONV_W_NT != 0 ? BUF_NT : BUF_PLAIN>(rw, voff, (uint32_t)r * rowb);
-#endif
-        },
+    // (eight loads of the w table in flight per thread: 4 and 16 measured slower, as did a streaming hint on them -- the XCD's slice of
+    // the table is meant to stay in its L2)
+    units_batched<T, 8>([&](int r) { return buf_load_unit<T, BUF_PLAIN>(rw, voff, (uint32_t)r * rowb); },
         [&](int r, const Unit16<T>& u) {
 #pragma unroll
           for (int v = 0; v < VEC; ++v) {
@@ -922,19 +824,13 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_CONV_MIN_WAVES((L / 16)
 #pragma unroll
     for (int r = 0; r < 16; ++r) x[v][r] = cmul(x[v][r], cmul(base, tu[r]));
   }
-  // transposed store: column i's L outputs are contiguous
-  if constexpr (VEC == 2 && Q % 2 == 0 && FOURIER_PAIRED_ROW_STORES != 0) {
-    if constexpr (sizeof(T) == 4) {
-      cpx<T>* p0 = out + (c0 + (uint64_t)(cg * VEC)) * L;
-      store_rows_paired<Q, FOURIER_CONV_ST_NT != 0>(x, p0, p0 + L, true, true, th, [](cpx<T> y) { return y; });
-    }
-  } else {
+  // transposed store: column i's L outputs are contiguous; streaming (with the XCD-sliced tile order of launch_conv: 4.5 vs 4.75 ms at
+  // C4, 7.8 vs 8.3 ms at N = 65537, r02 session 3)
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      cpx<T>* p = out + (c0 + (uint64_t)(cg * VEC + v)) * L + th;
+  for (int v = 0; v < VEC; ++v) {
+    cpx<T>* p = out + (c0 + (uint64_t)(cg * VEC + v)) * L + th;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) store_elem<T, FOURIER_CONV_ST_NT != 0>(p + Q * r, x[v][r]);
-    }
+    for (int r = 0; r < 16; ++r) store_elem<T, true>(p + Q * r, x[v][r]);
   }
 }
 

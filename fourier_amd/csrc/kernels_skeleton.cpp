@@ -4,6 +4,7 @@
 // shape streams when nothing else happens.  bench.py times these kernels (plan option "skeleton", experiments library only)
 // on the workload's own buffers as `roofline.stream_ceiling_gbps`.  Results are meaningless.
 // Compiled once per precision: -DFOURIER_TU_REAL=float / double (fourier_amd/build.py); experiments library only.
+#define FOURIER_EXPERIMENTS_TU 1  // an ablation: its templates live in the inline namespace `ablated` (kernels_common.h)
 #define FOURIER_ABLATE 2
 #include "engine_common.h"
 #include "kernels_pass.h"

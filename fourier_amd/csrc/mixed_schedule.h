@@ -14,9 +14,7 @@ namespace fourier_hip {
 // 5, 7, 11 or 13 are not the reference's to schedule (it sends them to Bluestein): odd radices first, largest first -- a
 // stride-1 pass writes with a lane stride of R elements, which only an odd R spreads over all LDS banks -- then greedily
 // 8, 4, 2, which never takes more passes than the reference's rule and one fewer when 2^a is a power of 8.
-#ifndef FOURIER_MIX_PRIMES_FIRST
 #define FOURIER_MIX_PRIMES_FIRST 1
-#endif
 constexpr bool mix_extended(uint32_t n) { return n % 5 == 0 || n % 7 == 0 || n % 11 == 0 || n % 13 == 0; }
 constexpr uint32_t mix_next_radix(uint32_t n, uint32_t cur, bool first) {
   if (FOURIER_MIX_PRIMES_FIRST && mix_extended(n))
@@ -28,18 +26,12 @@ constexpr uint32_t mix_next_radix(uint32_t n, uint32_t cur, bool first) {
 
 // fused (3,3) pass pairs: for lengths with a factor 9; in f64 only from 1024 points on (below, the 18 extra VGPRs and
 // the idle threads cost more than the saved LDS round trip: 729 f64 53 % without, 42 % with; 2187 30 % / 33 %)
-#ifndef FOURIER_MIX_PAIR_MIN_N_F64
 #define FOURIER_MIX_PAIR_MIN_N_F64 1024u
-#endif
 // fused (5,5) pairs (lengths beyond the reference's), 25 points per work item: built and measured, off -- too few work
 // items per pass and 50+ live registers (f32 5000: 53 % of the HBM peak without, 33 % with; 10000: 48 / 33 %; f64 5000:
 // 55 / 31 %; only 12500 / 15625 gain, 33 -> 35-36 %; r03_s22)
-#ifndef FOURIER_MIX_PAIR5_MIN_N_F32
 #define FOURIER_MIX_PAIR5_MIN_N_F32 0xffffffffu
-#endif
-#ifndef FOURIER_MIX_PAIR5_MIN_N_F64
 #define FOURIER_MIX_PAIR5_MIN_N_F64 0xffffffffu
-#endif
 template <typename T> constexpr bool mix_pairs(uint32_t n, uint32_t r) {
   return r == 3 ? (n % 9 == 0 && (sizeof(T) == 4 || n >= FOURIER_MIX_PAIR_MIN_N_F64))
                 : (r == 5 && n % 25 == 0 && n >= (sizeof(T) == 4 ? FOURIER_MIX_PAIR5_MIN_N_F32 : FOURIER_MIX_PAIR5_MIN_N_F64));
@@ -53,12 +45,8 @@ template <typename T> constexpr uint32_t mix_group(uint32_t n) { return 1024 / n
 // arithmetic, same bits.  2^a*3^b: above 4096 points (f32 9216: 29 -> 44 % of the HBM peak, 18432: 18 -> 34 %, f64 9216:
 // 22 -> 35 %; below, f64 2187 loses 45 -> 34 %).  Lengths with factors 5..13: above 32 KiB per transform (f32 10000: 28 -> 48 %;
 // f64 3125: 43 -> 57 %, 2500: 49 -> 57 %, but 2401: 45 -> 38 %; f32 from 16 KiB loses, 3125: 46 -> 28 %).  r03_s22.
-#ifndef FOURIER_MIX_WIDE_MIN_BYTES
 #define FOURIER_MIX_WIDE_MIN_BYTES 32768u
-#endif
-#ifndef FOURIER_MIX_WIDE_MIN_N
 #define FOURIER_MIX_WIDE_MIN_N 4096u
-#endif
 // ... and 128 threads in f32 where a pass has, on average, no more than FOURIER_MIX_HALF_MAX_ITEMS work items (butterflies or
 // butterfly pairs) per workgroup: these kernels are latency-bound chains of barrier-separated passes, most of 256 threads
 // would idle, and half-size workgroups put twice as many chains on a CU (243: 50 -> 61 % of the HBM peak, 625: 43 -> 59 %,
@@ -66,13 +54,9 @@ template <typename T> constexpr uint32_t mix_group(uint32_t n) { return 1024 / n
 // never beat 128; r03_s24_mixed_radix_threads_per_workgroup_ab.jsonl)
 // (512 threads for the transforms between 16 KiB and the 1024-thread threshold: measured, no -- 2187 f32 56 -> 46 %, f64
 // 1152 / 2000 53 / 55 -> 45 / 46 %, 4000 f32 46 -> 51 % the only gain; r03_s26_mixed_radix_mid_sizes_512_threads_ab.jsonl)
-#ifndef FOURIER_MIX_MID_THREADS
 #define FOURIER_MIX_MID_THREADS 256u
 #define FOURIER_MIX_MID_MIN_BYTES 16384u
-#endif
-#ifndef FOURIER_MIX_HALF_MAX_ITEMS
 #define FOURIER_MIX_HALF_MAX_ITEMS 190u
-#endif
 template <typename T> constexpr uint32_t mix_mean_items(uint32_t n) {
   uint32_t cur = n, passes = 0, items = 0;
   const uint32_t pts_total = mix_group<T>(n) * n;
@@ -97,16 +81,7 @@ template <typename T> constexpr uint32_t mix_threads(uint32_t n) {
 // form; half the LDS, so twice the resident workgroups where LDS was the limit (N=6561 f32 16 -> 32 % of the HBM
 // peak, 2304 37 -> 51 %, f64 1152 46 -> 61 %) and no loss elsewhere (A/B over the threshold,
 // profiles/r01_s15_mixed_inplace_ab.txt).  FOURIER_MIX_INPLACE_BYTES > 0 restores ping-pong below that footprint.
-#ifndef FOURIER_MIX_INPLACE_BYTES
 #define FOURIER_MIX_INPLACE_BYTES 0u
-#endif
-// Per-pass twiddle tables of the per-length kernels staged in LDS (transposed: entry (i, k) at k * m + i, so that the lanes of a
-// wave -- consecutive butterflies i -- read consecutive words) where a workgroup's transforms share them: two or more
-// transforms per workgroup.  A/B knob; DESIGN.md section 7 has the measurement.
-#ifndef FOURIER_MIX_TW_LDS
-#define FOURIER_MIX_TW_LDS 0
-#endif
-template <typename T> constexpr bool mix_tw_lds(uint32_t n) { return FOURIER_MIX_TW_LDS != 0 && mix_group<T>(n) >= 2; }
 // First pass straight from global memory, last pass straight to global memory (mix_gio): the per-length kernels otherwise copy the
 // transforms into LDS, run every pass there and copy the result out -- 2 * passes + 2 LDS accesses per point and 2 * passes + 1
 // barriers.  A work item of the first pass reads its points in[i + m * k] itself (for a fixed k the lanes of a wave -- consecutive
@@ -118,18 +93,10 @@ template <typename T> constexpr bool mix_tw_lds(uint32_t n) { return FOURIER_MIX
 // 2^a*3^b from 10 KiB per transform on -- f32 1536 +7 %, 3072 +14 %, 9216 +8 %, 18432 +16 %, 19683 +10 %, 6561 +6 %; f64 729 +11 %,
 // 2187 +27 %, 4374 +15 %, 9216 +22 % -- while 768 / 729 f32 lose 2-3 %; of the lengths with factors 5..13 only 5^5 and 5^6 gain
 // (+11 % / +8 %; 1000 -6 %, 2401 -4 %, 5000 / 10000 +-1 %).
-#ifndef FOURIER_MIX_GIO_MIN_RUN
 #define FOURIER_MIX_GIO_MIN_RUN 64u
-#endif
-#ifndef FOURIER_MIX_GIO_MIN_BYTES
 #define FOURIER_MIX_GIO_MIN_BYTES 10240u
-#endif
-#ifndef FOURIER_MIX_GIO_MIN_BYTES_F32
 #define FOURIER_MIX_GIO_MIN_BYTES_F32 98304u
-#endif
-#ifndef FOURIER_MIX_GIO_ALL
 #define FOURIER_MIX_GIO_ALL 0  // 1: every length that satisfies the run-length condition (A/B)
-#endif
 template <typename T> constexpr bool mix_gio(uint32_t n) {
   if (FOURIER_MIX_GIO_MIN_RUN == 0u) return false;
   uint32_t cur = n, first_run = 0, last_run = 0, stride = 1;
@@ -162,9 +129,7 @@ template <typename T> constexpr bool mix_gio(uint32_t n) {
 // them; the next pass reads through the same map.  The map permutes the elements of an aligned block of 16 (f64: 8), so contiguous
 // accesses (every read, every later write) stay conflict-free and no LDS is added.  Encoded src << 8 | nbits << 4 | dst; 0 = the
 // plain layout.  Only where the transform is a whole number of such blocks.
-#ifndef FOURIER_MIX_SWIZZLE
 #define FOURIER_MIX_SWIZZLE 1
-#endif
 constexpr bool mix_is_pow2(uint32_t v) { return v != 0 && (v & (v - 1)) == 0; }
 constexpr uint32_t mix_log2(uint32_t v) { return v <= 1 ? 0 : 1 + mix_log2(v >> 1); }
 // group_bits: log2 of the lanes in a ds_write lane group = log2 of the bank slots an element can fall on -- 4 for 8-byte elements
@@ -189,9 +154,7 @@ constexpr uint32_t mix_sw_span(uint32_t layout) { return layout == 0 ? 1u : 1u <
 // 9216 +8 %; f32 3072 +3 %, 6144 +5 %, 2304 / 13824 +2 % -- but not the f32 lengths that fill a CU's LDS (18432 -2 %); shorter
 // transforms lose 1 - 2 %; of the lengths with factors 5..13 only 5^5 gains (+3 %; 5000 -3 %, 10000 f64 -2 %).  The pass's twiddles
 // loaded with them as well: measured, no (r04_s21: 9216 f32 / f64 -22 % / -8 %, the others +-2 %).
-#ifndef FOURIER_MIX_LOADS_FIRST
 #define FOURIER_MIX_LOADS_FIRST 1  // 0: never, 2: every length (A/B)
-#endif
 template <typename T> constexpr bool mix_loads_first(uint32_t n) {
   if (FOURIER_MIX_LOADS_FIRST != 1) return FOURIER_MIX_LOADS_FIRST != 0;
   if (mix_extended(n)) return false;  // (5^5 f32 gained 3 % while its first pass read global memory; through the batched copy: -1 %, r04_s49)

@@ -204,6 +204,7 @@ template <typename T> class Plan {
     if (key == "host_chunk_bytes" && v > 0) { host_chunk_bytes_ = (size_t)v; return 0; }
     // per-XCD rotation of the tile index inside a transform (xcd_remap): v = tiles per XCD for the last pass | for the first pass << 12 |
     // odd XCDs backwards (last pass) << 24 | (first pass) << 25; 0 = none
+    if (key == "xcd_phase" && v >= 0 && v < (1 << 20) && eng_ && !blu_) { eng_->set_xcd_phase((unsigned)v); return 0; }
     if (key == "xcd_rotate" && v >= 0 && v < (1 << 26) && eng_ && !blu_) {
       const unsigned last = (unsigned)v & 0xfff, first = ((unsigned)v >> 12) & 0xfff;
       eng_->set_xcd_rot(first | (((unsigned)v >> 25) & 1u) << 31, last | (((unsigned)v >> 24) & 1u) << 31);

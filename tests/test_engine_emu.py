@@ -453,6 +453,8 @@ def test_chunking_and_scratch_options_do_not_change_results(fa):
             assert np.array_equal(run_batch(plan, x2, 0), base2), (n2, batch2, rot)
             plan.set_option("tile_walk", 4)
             assert np.array_equal(run_batch(plan, x2, 0), base2), (n2, batch2, rot, "band walk")
+            plan.set_option("xcd_phase", 1 + rot % 5)  # a per-XCD phase inside its own range of transforms (batch a multiple of 8)
+            assert np.array_equal(run_batch(plan, x2, 0), base2), (n2, batch2, rot, "phase")
     with pytest.raises(fa.FourierError):
         make(fa, n, np.complex64).set_option("xcd_swizzle", 5)
     with pytest.raises(fa.FourierError):

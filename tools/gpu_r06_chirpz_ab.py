@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 import torch
 from fourier_amd import fft as F, _lib
 
-SIZES = [191, 222, 439, 722, 1013, 1418, 37, 97, 331, 2039, 4097, 5003, 10007, 16381, 2048, 4096, 8192, 16384, 32768]
+SIZES = [int(v) for v in os.environ.get("CHIRPZ_SIZES", "").split(",") if v] or [191, 222, 439, 722, 1013, 1418, 37, 97, 331, 2039, 4097, 5003, 10007, 16381, 2048, 4096, 8192, 16384, 32768]
 REPS = 7
 
 

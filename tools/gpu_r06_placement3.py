@@ -23,11 +23,15 @@ ARMS = [("default", 0), ("last1", 1), ("last2", 2), ("last3", 3), ("last4", 4), 
         ("last0_back", 1 << BL), ("last1_back", 1 | 1 << BL), ("last8_back", 8 | 1 << BL),
         ("first1", 1 << F1), ("first4", 4 << F1), ("first8", 8 << F1), ("first16", 16 << F1), ("first3", 3 << F1), ("first0_back", 1 << BF),
         ("both8", 8 | 8 << F1), ("both1", 1 | 1 << F1), ("both3", 3 | 3 << F1)]
+if os.environ.get("PLACEMENT3_PHASE"):  # session 4: a per-XCD phase inside its own range of transforms instead (both passes)
+    ARMS = [("default", 0)] + [(f"lastphase{v}", ("xcd_phase", v)) for v in (1, 3, 8, 21, 37, 64, 101)]
 
 
 def make(rot):
     p = (F.create_fft_f32 if REAL == "f32" else F.create_fft_f64)(N, 0)
-    if rot:
+    if isinstance(rot, tuple):  # ("xcd_phase", transforms)
+        p.set_option(rot[0], rot[1])
+    elif rot:
         p.set_option("xcd_rotate", rot)
     return p
 
