@@ -158,6 +158,7 @@ template <typename T> class TiledMixedEngine {
     if (specialised_) d += " specialised";
     return d;
   }
+  bool specialised() const { return specialised_; }
   // scratch: batch * n elements; needed by in-place calls and by three-pass plans
   bool needs_scratch(bool in_place) const { return in_place || passes_.size() >= 3; }
   void run(const cpx<T>* in, cpx<T>* out, cpx<T>* scratch, size_t batch, bool inverse, double scale, hipStream_t stream, Profiler* prof) const {
@@ -214,7 +215,7 @@ template <typename T> class TiledMixedEngine {
     std::unique_ptr<DevBuf> tw_lo, tw_hi;
   };
   size_t n_;
-  bool specialised_ = false;
+  bool specialised_ = false;  // at least one pass runs a kernel compiled at run time
   std::vector<Pass> passes_;
   std::map<uint32_t, std::unique_ptr<DevBuf>> tables_;
 };

@@ -69,8 +69,10 @@ template <typename T> class Plan {
       tiled_.reset(new TiledMixedEngine<T>(n));  // two or three HBM round trips on column tiles of mixed length
     } else if (GenericEngine<T>::handles(n)) {
       gen_.reset(new GenericEngine<T>(n));       // what is left of 2^a*3^b, a < 12: one round trip per radix
-    } else if (TiledMixedEngine<T>::handles_smooth(n)) {
-      tiled_.reset(new TiledMixedEngine<T>(n));  // factors 5 / 7 beyond the LDS kernels: tile passes instead of Bluestein (round 5)
+    } else if (TiledMixedEngine<T>::handles_smooth(n) && !(n <= MixedEngine<T>::MAX_N && specialise_policy() >= 1 && specialised_route(n, specialise_policy() >= 2, nullptr))) {
+      // factors 5 / 7 beyond the ahead-of-time LDS kernels: tile passes instead of Bluestein (round 5) -- unless the length fits a compute
+      // unit's LDS and its own one-launch kernel is in the code-object cache (one HBM round trip instead of two)
+      tiled_.reset(new TiledMixedEngine<T>(n));
     } else if (specialise_policy() >= 1 && specialised_route(n, specialise_policy() >= 2, nullptr)) {
       // prime factors up to 13 without an ahead-of-time route: the kernels of an earlier "specialise" from the on-disk cache
     } else {
@@ -90,7 +92,11 @@ template <typename T> class Plan {
       if (!MixedEngine<T>::factor(n, radices)) { w = "a prime factor above 13"; return false; }
       if (!allow_compile && !MixedEngine<T>::specialised_kernel_cached(n)) { w = "not in the code-object cache"; return false; }
       std::unique_ptr<MixedEngine<T>> m;
-      try { m.reset(new MixedEngine<T>(n, true)); } catch (const EngineError& e) { (void)hipGetLastError(); w = e.what(); return false; }
+      try { m.reset(new MixedEngine<T>(n, true)); }
+      catch (const EngineError& e) {
+        if (e.status == ::fourier::c::FOURIER_HIP_OUT_OF_MEMORY) throw;  // as try_mixed: out of memory is not "take the next route"
+        (void)hipGetLastError(); w = e.what(); return false;
+      }
       if (m->specialise(&w, allow_compile) != ::fourier::c::FOURIER_HIP_OK) return false;
       mix_ = std::move(m);
       return true;
@@ -98,7 +104,11 @@ template <typename T> class Plan {
     if (n <= TiledMixedEngine<T>::MAX_N && !TiledMixedEngine<T>::factorise(n, true).empty()) {
       if (!allow_compile && !TiledMixedEngine<T>::specialised_kernels_cached(n)) { w = "not in the code-object cache"; return false; }
       try { tiled_.reset(new TiledMixedEngine<T>(n, true, allow_compile)); }
-      catch (const EngineError& e) { (void)hipGetLastError(); tiled_.reset(); w = e.what(); return false; }
+      catch (const EngineError& e) {
+        tiled_.reset();
+        if (e.status == ::fourier::c::FOURIER_HIP_OUT_OF_MEMORY) throw;
+        (void)hipGetLastError(); w = e.what(); return false;
+      }
       return true;
     }
     w = "not a length whose prime factors stop at 13 with a kernel to specialise";
@@ -200,7 +210,13 @@ template <typename T> class Plan {
       return 0;
     }
     if (key == "bluestein_conv" && (v == 0 || v == 1)) { conv_ = (v == 1) && conv_ok_; return 0; }
-    if (key == "bluestein_chirp_compute" && (v == 0 || v == 1)) { chirp_compute_ = (v == 1) && chirp_p_.p != nullptr; return 0; }
+    if (key == "bluestein_chirp_compute" && (v == 0 || v == 1)) {
+      // (the computed chirp is built on exact exponents: under "bluestein_reference_chirp" it would disagree with the chirp-out table and w by the
+      // reference's own angle error -- the request is remembered for when that option is switched off again, the pass keeps reading the table)
+      if (reference_chirp_) { chirp_compute_saved_ = (v == 1) && chirp_p_.p != nullptr; return 0; }
+      chirp_compute_ = (v == 1) && chirp_p_.p != nullptr;
+      return 0;
+    }
     if (key == "host_chunk_bytes" && v > 0) { host_chunk_bytes_ = (size_t)v; return 0; }
     // per-XCD rotation of the tile index inside a transform (xcd_remap): v = tiles per XCD for the last pass | for the first pass << 12 |
     // odd XCDs backwards (last pass) << 24 | (first pass) << 25; 0 = none
@@ -247,7 +263,18 @@ template <typename T> class Plan {
         if (specialised_route(n_, true, &why)) { refresh_desc(); return ::fourier::c::FOURIER_HIP_OK; }
         return report(::fourier::c::FOURIER_HIP_UNSUPPORTED);
       }
-      if (tiled_) return ::fourier::c::FOURIER_HIP_OK;  // ahead-of-time tile passes already: nothing to specialise
+      if (tiled_) {
+        // ahead-of-time tile passes: where the length fits a compute unit's LDS its own one-launch kernel replaces them (one HBM round trip
+        // instead of two); otherwise there is nothing to specialise and the plan stays as it is (OK)
+        if (n_ <= MixedEngine<T>::MAX_N && !tiled_->specialised()) {
+          std::unique_ptr<TiledMixedEngine<T>> keep = std::move(tiled_);
+          if (specialised_route(n_, true, &why) && mix_) { refresh_desc(); return ::fourier::c::FOURIER_HIP_OK; }
+          tiled_ = std::move(keep);
+          mix_.reset();
+          return report(::fourier::c::FOURIER_HIP_UNSUPPORTED);
+        }
+        return ::fourier::c::FOURIER_HIP_OK;
+      }
       why = "not a length whose prime factors stop at 13 with a kernel to specialise";
       return report(::fourier::c::FOURIER_HIP_UNSUPPORTED);
     }

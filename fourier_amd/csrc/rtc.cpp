@@ -9,7 +9,7 @@
 // kernel, the code object is loaded as a module and cached per (precision, length) for the life of the process -- and, round 5,
 // ON DISK: $FOURIER_HIP_CACHE_DIR, else $XDG_CACHE_HOME/fourier-hip, else $HOME/.cache/fourier-hip (an empty FOURIER_HIP_CACHE_DIR
 // switches the disk cache off), one file per (device architecture, precision, kind, length, LDS bytes, hash of the embedded headers
-// and compile options), written through a temporary file and rename().  About one second per length the first time on a machine,
+// and compile options), written through a temporary file and rename(), read back only from a directory and a file that belong to this user and that nobody else may write (no symbolic links followed; the entry names its own key and payload length).  About one second per length the first time on a machine,
 // a few milliseconds from the disk cache (no libhiprtc needed for that), nothing from the process cache.  libhiprtc is loaded
 // lazily (dlopen): the library keeps libamdhip64 as its only link-time dependency, and where hipRTC is missing and the cache has no
 // entry the caller gets FOURIER_HIP_UNSUPPORTED and the plan keeps its kernel.
@@ -85,13 +85,17 @@ std::string cache_dir() {
   if ((e = getenv("HOME")) && *e) return std::string(e) + "/.cache/fourier-hip";
   return std::string();
 }
-// FNV-1a over everything a code object depends on besides its key: the embedded headers and the compile options
+// FNV-1a over everything a code object depends on besides its key: the embedded headers, the compile options and the HIP runtime's
+// version (the compiler comes with it; hipRTC's own version is only known once libhiprtc is loaded, which a cache hit never does)
 uint64_t sources_hash() {
   static const uint64_t h = [] {
     uint64_t x = 1469598103934665603ull;
     auto eat = [&](const char* p) { for (; *p; ++p) { x ^= (unsigned char)*p; x *= 1099511628211ull; } x ^= 0xff; x *= 1099511628211ull; };
     for (int i = 0; i < RTC_NUM_HEADERS; ++i) { eat(RTC_HEADER_NAMES[i]); eat(RTC_HEADER_SOURCES[i]); }
     for (int i = 0; i < RTC_NUM_OPTIONS; ++i) eat(RTC_OPTIONS[i]);
+    int ver = 0;
+    if (hipRuntimeGetVersion(&ver) != hipSuccess) { (void)hipGetLastError(); ver = 0; }
+    eat(("hip-runtime-" + std::to_string(ver)).c_str());
     return x;
   }();
   return h;
@@ -122,36 +126,71 @@ void make_dirs(const std::string& dir) {
   for (size_t i = 1; i <= dir.size(); ++i)
     if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), i == dir.size() ? 0700 : 0755);
 }
-const char CACHE_MAGIC[] = "FOURIER-HIP-CO-1\n";
-// file: magic line, the kernel's lowered name, a newline, the code object
-bool read_cache(const std::string& path, std::string& lowered, std::vector<char>& code) {
-  FILE* f = path.empty() ? nullptr : fopen(path.c_str(), "rb");
-  if (!f) return false;
-  // a code object is executed on the device: only a regular file that belongs to this user and that nobody else may write is trusted
+const char CACHE_MAGIC[] = "FOURIER-HIP-CO-2\n";
+// A code object is executed on the device, so a cache entry is trusted only when nobody else could have put it there: the directory
+// belongs to this user and is not writable by group or others, the entry is opened without following a symbolic link, is a regular file
+// of this user that nobody else may write, and says of itself what the caller asked for.
+// file: magic line; "<tag> <payload bytes>\n" with tag = what the file name says (precision, kind, length, LDS bytes); the kernel's lowered
+// name and a newline; the code object, exactly <payload bytes> long
+std::string entry_tag(bool f64, uint32_t n, size_t lds_bytes, bool tile_pass) {
+  return std::string(f64 ? "f64" : "f32") + "-" + (tile_pass ? "tile" : "whole") + "-n" + std::to_string(n) + "-lds" + std::to_string(lds_bytes);
+}
+bool trusted_dir(const std::string& dir) {
   struct stat st;
-  if (fstat(fileno(f), &st) != 0 || !S_ISREG(st.st_mode) || st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) { fclose(f); return false; }
+  return stat(dir.c_str(), &st) == 0 && S_ISDIR(st.st_mode) && st.st_uid == geteuid() && !(st.st_mode & (S_IWGRP | S_IWOTH));
+}
+// damaged (out): a file of THIS user in a trusted directory whose content is not a cache entry of this key (an older format, a truncated
+// write, a renamed entry): the caller discards it
+bool read_cache(const std::string& path, const std::string& tag, std::string& lowered, std::vector<char>& code, bool& damaged) {
+  damaged = false;
+  if (path.empty() || !trusted_dir(path.substr(0, path.rfind('/')))) return false;
+  const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+  if (fd < 0) return false;
+  struct stat st;
+  if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) { close(fd); return false; }
+  FILE* f = fdopen(fd, "rb");
+  if (!f) { close(fd); return false; }
   std::vector<char> all;
   char buf[65536];
   size_t got;
   while ((got = fread(buf, 1, sizeof buf, f)) > 0) all.insert(all.end(), buf, buf + got);
   fclose(f);
+  damaged = true;  // from here on the file is ours; anything but a well-formed entry of this key is discarded
   const size_t ml = sizeof(CACHE_MAGIC) - 1;
   if (all.size() <= ml || memcmp(all.data(), CACHE_MAGIC, ml) != 0) return false;
-  const char* nl = (const char*)memchr(all.data() + ml, '\n', all.size() - ml);
-  if (!nl) return false;
-  lowered.assign((const char*)all.data() + ml, nl);
-  code.assign(nl + 1, (const char*)all.data() + all.size());
-  return !lowered.empty() && !code.empty();
+  const char* end = all.data() + all.size();
+  const char* nl1 = (const char*)memchr(all.data() + ml, '\n', all.size() - ml);
+  if (!nl1) return false;
+  const std::string head((const char*)all.data() + ml, nl1);  // "<tag> <payload bytes>"
+  const size_t sp = head.rfind(' ');
+  if (sp == std::string::npos || head.substr(0, sp) != tag) return false;
+  char* num_end = nullptr;
+  const unsigned long long payload = strtoull(head.c_str() + sp + 1, &num_end, 10);
+  if (!num_end || *num_end) return false;
+  const char* nl2 = (const char*)memchr(nl1 + 1, '\n', (size_t)(end - (nl1 + 1)));
+  if (!nl2 || (unsigned long long)(end - (nl2 + 1)) != payload || payload < 64) return false;  // truncated or padded
+  lowered.assign(nl1 + 1, nl2);
+  code.assign(nl2 + 1, end);
+  // the code object must be an ELF image that ends inside the buffer (hipModuleLoadData takes no size)
+  if (memcmp(code.data(), "\177ELF", 4) != 0) return false;
+  uint64_t shoff = 0; uint16_t shentsize = 0, shnum = 0;
+  memcpy(&shoff, code.data() + 0x28, 8); memcpy(&shentsize, code.data() + 0x3a, 2); memcpy(&shnum, code.data() + 0x3c, 2);
+  if (shoff > code.size() || (uint64_t)shentsize * shnum > code.size() - shoff) return false;
+  damaged = lowered.empty();
+  return !damaged;
 }
-void write_cache(const std::string& path, const std::string& lowered, const std::vector<char>& code) {
+void write_cache(const std::string& path, const std::string& tag, const std::string& lowered, const std::vector<char>& code) {
   if (path.empty()) return;
-  make_dirs(path.substr(0, path.rfind('/')));
+  const std::string dir = path.substr(0, path.rfind('/'));
+  make_dirs(dir);
+  if (!trusted_dir(dir)) return;  // somebody else's (or a shared) directory: this process neither reads nor feeds it
   const std::string tmp = path + ".tmp" + std::to_string((long long)getpid());
-  const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL, 0600);
+  const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
   FILE* f = fd >= 0 ? fdopen(fd, "wb") : nullptr;
   if (!f) { if (fd >= 0) close(fd); return; }
-  bool ok = fwrite(CACHE_MAGIC, 1, sizeof(CACHE_MAGIC) - 1, f) == sizeof(CACHE_MAGIC) - 1 && fwrite(lowered.data(), 1, lowered.size(), f) == lowered.size() &&
-            fputc('\n', f) != EOF && fwrite(code.data(), 1, code.size(), f) == code.size();
+  const std::string head = tag + " " + std::to_string(code.size()) + "\n" + lowered + "\n";
+  bool ok = fwrite(CACHE_MAGIC, 1, sizeof(CACHE_MAGIC) - 1, f) == sizeof(CACHE_MAGIC) - 1 && fwrite(head.data(), 1, head.size(), f) == head.size() &&
+            fwrite(code.data(), 1, code.size(), f) == code.size();
   ok = (fclose(f) == 0) && ok;
   if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)unlink(tmp.c_str());
 }
@@ -174,27 +213,41 @@ bool rtc_cached(bool f64, uint32_t n, size_t lds_bytes, bool tile_pass) {
     if (g_cache.count(std::make_pair(cache_key(dev, f64, tile_pass), n))) return true;
   }
   const std::string path = cache_file(dev, f64, n, lds_bytes, tile_pass);
-  return !path.empty() && access(path.c_str(), R_OK) == 0;
+  return !path.empty() && trusted_dir(path.substr(0, path.rfind('/'))) && access(path.c_str(), R_OK) == 0;
 }
 
 bool rtc_mixed_kernel(bool f64, uint32_t n, size_t lds_bytes, RtcKernel& out, std::string& why, bool tile_pass, bool allow_compile) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { why = "no device"; return false; }
-  std::lock_guard<std::mutex> lock(g_mu);
   const auto key = std::make_pair(cache_key(dev, f64, tile_pass), n);
-  auto it = g_cache.find(key);
-  if (it != g_cache.end()) { out = it->second; return true; }
-  const std::string path = cache_file(dev, f64, n, lds_bytes, tile_pass);
+  // the process cache under the lock; file I/O and the one-second compilation outside it (creates on other threads do not queue up behind a
+  // compilation), the map re-checked before the insertion: two threads that compile the same kernel at once both succeed, one module stays unused
+  auto cached = [&]() {
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_cache.find(key);
+    if (it == g_cache.end()) return false;
+    out = it->second;
+    return true;
+  };
+  auto publish = [&]() {
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto ins = g_cache.emplace(key, out);
+    if (!ins.second) out = ins.first->second;
+  };
+  if (cached()) return true;
+  const std::string path = cache_file(dev, f64, n, lds_bytes, tile_pass), tag = entry_tag(f64, n, lds_bytes, tile_pass);
   {  // the disk cache: no compiler needed
     std::string lowered, err;
     std::vector<char> code;
-    if (read_cache(path, lowered, code)) {
-      if (load_module(code, lowered, out, err)) { g_cache.emplace(key, out); return true; }
-      (void)unlink(path.c_str());  // a file this runtime cannot load: compile again
+    bool damaged = false;
+    if (read_cache(path, tag, lowered, code, damaged)) {
+      if (load_module(code, lowered, out, err)) { publish(); return true; }
+      damaged = true;  // a file this runtime cannot load
     }
+    if (damaged) (void)unlink(path.c_str());  // compile again (where asked to)
   }
   if (!allow_compile) { why = "not in the code-object cache (compilation not asked for)"; return false; }
-  static Rtc rtc;
+  static Rtc rtc;  // (initialised once, thread-safe)
   if (!rtc.ok) { why = "libhiprtc not available"; return false; }
   const std::string real = f64 ? "double" : "float";
   // the whole-transform kernel of length n, or the column-tile pass of length n (kernels_tiled.h)
@@ -228,8 +281,8 @@ bool rtc_mixed_kernel(bool f64, uint32_t n, size_t lds_bytes, RtcKernel& out, st
     std::vector<char> code(cs);
     if (rtc.code(prog, code.data()) != 0) { why = "hiprtcGetCode failed"; break; }
     if (!load_module(code, low, out, why)) break;
-    write_cache(path, low, code);
-    g_cache.emplace(key, out);
+    write_cache(path, tag, low, code);
+    publish();
     ok = true;
   } while (false);
   rtc.destroy(&prog);

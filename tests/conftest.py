@@ -16,7 +16,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import tempfile  # noqa: E402
 
 os.environ.setdefault("FOURIER_HIP_SPECIALISE", "0")
-os.environ.setdefault("FOURIER_HIP_CACHE_DIR", tempfile.mkdtemp(prefix="fourier-hip-test-cache-"))
+if "FOURIER_HIP_CACHE_DIR" not in os.environ:
+    import atexit
+    import shutil
+
+    _cache_dir = tempfile.mkdtemp(prefix="fourier-hip-test-cache-")  # one per pytest process (and per xdist worker); removed at exit
+    os.environ["FOURIER_HIP_CACHE_DIR"] = _cache_dir
+    atexit.register(shutil.rmtree, _cache_dir, ignore_errors=True)
 
 
 def pytest_configure(config):

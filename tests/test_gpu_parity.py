@@ -1267,7 +1267,7 @@ def test_code_object_cache_and_the_library_wide_specialise_policy(torch, fa, ora
         return json.loads(out.stdout.strip().splitlines()[-1])
     r = child(None)
     assert r["policy"] == 1 and "specialised" in r["d5005"] and "specialised" not in r["d3003"], r
-    assert r["create_s"] < 0.25, r  # a cache hit: read 1 file, load 1 module (a compilation takes about a second)
+    assert r["create_s"] < 0.6, r  # a cache hit: read 1 file, load 1 module (a compilation takes a second or more; loose: a loaded box)
     r = child("0")
     assert r["policy"] == 0 and "specialised" not in r["d5005"], r
     r = child("2")
@@ -1286,8 +1286,31 @@ def test_code_object_cache_and_the_library_wide_specialise_policy(torch, fa, ora
     assert "specialised" not in r["d5005"] and victim.exists(), r
     victim.chmod(0o600)
     assert "specialised" in child(None)["d5005"]
-    # a damaged cache file is discarded, not trusted
+    # ... nor is an entry in a directory somebody else may write, nor one behind a symbolic link (another user of a shared
+    # cache directory could link one of the victim's own entries under another length's name -- a wrong-length kernel would then run out
+    # of bounds on the device); an entry also names its own key, so a renamed copy is refused (and discarded: the file is ours)
+    cache.chmod(0o777)
+    assert "specialised" not in child(None)["d5005"]
+    cache.chmod(0o700)
+    assert "specialised" in child(None)["d5005"]
+    other = next(p for p in cache.iterdir() if "-n9009-" in p.name)
+    good = victim.read_bytes()
+    victim.unlink()
+    victim.symlink_to(other)
+    r = child(None)
+    assert "specialised" not in r["d5005"] and victim.is_symlink(), r
+    victim.unlink()
+    victim.write_bytes(other.read_bytes())  # a well-formed entry of ANOTHER length under this name
+    victim.chmod(0o600)
+    r = child(None)
+    assert "specialised" not in r["d5005"] and not victim.exists(), r
+    victim.write_bytes(good[:-7])  # truncated
+    victim.chmod(0o600)
+    r = child(None)
+    assert "specialised" not in r["d5005"] and not victim.exists(), r
+    # a damaged cache file (here: the format of round 5) is discarded, not trusted
     victim.write_bytes(b"FOURIER-HIP-CO-1\nnot_a_kernel\n" + b"\x00" * 100)
+    victim.chmod(0o600)
     fa.set_default_option("specialise_at_create", 1)
     try:
         # the process cache still holds the kernel of this process; a fresh process must fall back to its default route, silently
@@ -1295,6 +1318,20 @@ def test_code_object_cache_and_the_library_wide_specialise_policy(torch, fa, ora
         assert "specialised" not in r["d5005"] and not victim.exists(), r
     finally:
         fa.set_default_option("specialise_at_create", prev)
+    # the install step (packaging/warm_cache.c, python -m fourier_amd.warm_cache): after it, a plain create of a length with factors
+    # 7 / 11 / 13 runs on its own kernel -- f64 5005 leaves Bluestein -- in a process that never heard of any option
+    env = {k: v for k, v in os.environ.items() if k != "FOURIER_HIP_SPECIALISE"}
+    env["FOURIER_HIP_CACHE_DIR"] = str(tmp_path / "warm")
+    out = subprocess.run([sys.executable, "-m", "fourier_amd.warm_cache", "5005", "1001", "3003"], env=env, capture_output=True, text=True, timeout=600,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and "6 plans run on kernels of their own" in out.stdout, (out.stdout, out.stderr[-1500:])
+    prog2 = ("import sys, json; sys.path.insert(0, %r); import fourier_amd as fa\n"
+             "print(json.dumps([fa.create_fft_f32(5005).describe(), fa.create_fft_f64(5005).describe(), fa.create_fft_f64(1001).describe()]))\n"
+             % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", prog2], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    ds = json.loads(out.stdout.strip().splitlines()[-1])
+    assert all("specialised" in d and not d.startswith("bluestein") for d in ds), ds
 
 
 def test_plan_option_specialise_compiles_the_lengths_own_kernel_with_hiprtc(torch, fa, oracle):
