@@ -65,11 +65,15 @@ bool get_blu_small_kernel(Real<TUReal>, int k, KernelInfo& info) {
   switch (k) {
     case 4: info = make_blu_rows_info<T, 16, 64>(); return true;   // same tile shapes as the row kernels
     case 5: info = make_blu_rows_info<T, 32, 32>(); return true;
+    // M = 64 ... 1024: ONE WAVE per workgroup (64 / Q column groups) -- every barrier of the chain chirp -> FFT -> (.)w -> FFT -> chirp is then
+    // inside a wave and the sixteen waves of a CU run sixteen independent chains instead of four lock-stepped groups of four: +8 ... 20 % over
+    // the 256-thread workgroups of rounds 3 - 5 (f32 N = 439: 27.1 -> 32.5 % of the HBM peak, 331: 22.2 -> 27.0 %; f64 M = 1024 is best at four
+    // column groups; profiles/r06_s5_chirpz_rows_tuning_ab.jsonl, r06_s6_chirpz_one_wave_ab.jsonl)
     case 6: info = make_blu_rows_info<T, 64, 16>(); return true;
-    case 7: info = make_blu_rows_info<T, 128, 16>(); return true;
-    case 8: info = make_blu_rows_info<T, 256, 16>(); return true;
-    case 9: info = make_blu_rows_info<T, 512, FOURIER_CG_512>(); return true;
-    case 10: info = make_blu_rows_info<T, 1024, FOURIER_CG_1024>(); return true;
+    case 7: info = make_blu_rows_info<T, 128, 8>(); return true;
+    case 8: info = make_blu_rows_info<T, 256, 4>(); return true;
+    case 9: info = make_blu_rows_info<T, 512, 2>(); return true;
+    case 10: info = make_blu_rows_info<T, 1024, (sizeof(T) == 4 ? 1 : 4)>(); return true;
     case 11: info = make_blu_small_info<T, 64, 32>(); return true;
     case 12: info = make_blu_small_info<T, 64, 64>(); return true;
     case 13: info = make_blu_small_info<T, 128, 64>(); return true;

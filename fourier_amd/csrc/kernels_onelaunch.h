@@ -164,7 +164,9 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
   const uint32_t nbytes = ncols * n * (uint32_t)sizeof(cpx<T>);
   const BufRsrc ri = make_rsrc((const cpx<T>*)a.in + g0 * a.blu_n, nbytes), ro = make_rsrc((cpx<T>*)a.out + g0 * a.blu_n, nbytes);
   const BufRsrc rc = make_rsrc(a.blu_x, n * (uint32_t)sizeof(cpx<T>));
-  constexpr int RB = 4;  // rows per batch: RB chirp values and RB * VEC data elements in flight per thread
+  // rows per batch: RB chirp values and RB * VEC data elements in flight per thread (f32: every load of a phase in one batch; +2 ... 4 %,
+  // profiles/r06_s5_chirpz_rows_tuning_ab.jsonl)
+  constexpr int RB = (sizeof(T) == 8 && L < 1024) ? 4 : 8;
   constexpr uint32_t ES = (uint32_t)sizeof(cpx<T>);
   // M = L >= 2n - 1 and L even give n <= L/2 (bluesteins.rs:110; the engine checks it): positions th + Q*r with r >= 8 are padding on
   // the way in and beyond the user array on the way out.  Registers 8 .. 15 are therefore CONSTANT zeros here -- the first radix-16

@@ -56,7 +56,9 @@ KernelInfo get_kernel(Real<TUReal>, int L, int mode, int io) {
     FK2(128, 16, FOURIER_CG_128_ROWS)
     FK(256, 16)
     FK(512, FOURIER_CG_512)
-    FK(1024, FOURIER_CG_1024)
+    // whole rows of 1024 points, f32: 8 transforms per 256-thread workgroup instead of 16 per 512 -- 61.4 -> 67.1 % of the HBM peak; N = 256 / 512
+    // lose 2 - 6 % on narrower workgroups and stay (profiles/r06_s6_rows_width_ab.jsonl; f64 1024 is a 32 x 32 one-launch plan)
+    FK2(1024, FOURIER_CG_1024, (sizeof(T) == 4 ? 4 : FOURIER_CG_1024))
     FK(2048, FOURIER_CG_2048)
     default: break;
   }

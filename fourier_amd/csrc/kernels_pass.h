@@ -48,11 +48,14 @@ template <typename T, int L, int CG> struct TileCfg {
   //   tools/lds_rows_swizzle_search.py by exhaustive search over this family under the bank model of MI355X_MICROARCH.md: every row-mode
   //   exchange conflict-free, no padding units.
   struct RowSwz { int a, ma, b1, s1, b2, s2; };
-  static constexpr bool HAS_ROW_SWZ = (L == 32 && CG == 32) || (L == 64 && CG == 16) || (L == 128 && (CG == 16 || CG == 32)) || (L == 256 && CG == 16) ||
-                                      ((L == 512 || L == 1024) && CG == 8);
+  static constexpr bool HAS_ROW_SWZ = (L == 32 && CG == 32) || (L == 64 && CG == 16) || (L == 128 && (CG == 8 || CG == 16 || CG == 32)) ||
+                                      (L == 256 && (CG == 4 || CG == 8 || CG == 16)) || (L == 512 && (CG == 2 || CG == 4 || CG == 8)) ||
+                                      (L == 1024 && (CG == 1 || CG == 4 || CG == 8));
   static constexpr RowSwz row_swz() {
-    return L == 32 ? RowSwz{0, 0, 0, 4, 1, 0} : L == 64 ? RowSwz{0, 0, 0, 2, 2, 0} : (L == 128 && CG == 16) ? RowSwz{0, 0, 0, 1, 3, 0}
-           : L == 128 ? RowSwz{0, 0, 0, 2, 3, 0} : L == 256 ? RowSwz{0, 0, 0, 0, 4, 0} : RowSwz{7, 1, 1, 0, 4, 0};
+    return L == 32 ? RowSwz{0, 0, 0, 4, 1, 0} : L == 64 ? RowSwz{0, 0, 0, 2, 2, 0}
+           : L == 128 ? (CG == 8 ? RowSwz{4, 1, 0, 0, 4, 0} : CG == 16 ? RowSwz{0, 0, 0, 1, 3, 0} : RowSwz{0, 0, 0, 2, 3, 0})
+           : L == 256 ? (CG == 4 ? RowSwz{4, 3, 2, 0, 6, 0} : CG == 8 ? RowSwz{4, 1, 1, 0, 5, 0} : RowSwz{0, 0, 0, 0, 4, 0})
+           : CG == 1 ? RowSwz{4, 15, 0, 0, 0, 0} : CG == 2 ? RowSwz{5, 7, 3, 0, 4, 0} : CG == 4 ? RowSwz{6, 3, 2, 0, 4, 0} : RowSwz{7, 1, 1, 0, 4, 0};  // 512, 1024
   }
   template <int LAYOUT> static __device__ __forceinline__ int unit_index(int pos, int cg) {
     if constexpr (LAYOUT == 2 && HAS_ROW_SWZ) {

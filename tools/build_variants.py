@@ -21,7 +21,7 @@ VARIANTS = {
     "abl3": ["-DFOURIER_EXPERIMENTS_TU=1", "-DFOURIER_ABLATE=3"],
     "abl4": ["-DFOURIER_EXPERIMENTS_TU=1", "-DFOURIER_ABLATE=4"],  # stage twiddles from a constant (no table loads inside the in-tile transform)
     "abl5": ["-DFOURIER_EXPERIMENTS_TU=1", "-DFOURIER_ABLATE=5"],  # per-thread inter-pass twiddle factor from a constant (no two-level look-up)
-    "onelaunch_scalar": ["-DFOURIER_ONELAUNCH_PK=0"],  # round 6: the one-launch kernels (2^11..2^15, chirp-z M <= 2^15) without packed f32 arithmetic
+    "onelaunch_scalar": ["-DFOURIER_ONELAUNCH_PK=0"],
 }
 
 
