@@ -554,8 +554,6 @@ template <typename T> class Pow2Engine {
       a.nxcd = nxcd & 0xff;
       a.xcd_interleave = (nxcd >> 8) & 7;
       a.walk_band = (nxcd >> 12) & 0xff; a.walk_group = (nxcd >> 20) & 0x3ff; a.walk_tf = nxcd >> 30;
-      a.xcd_rot = (ps.mode == MODE_LAST) ? xcd_rot_last_ : (ps.mode == MODE_FIRST ? xcd_rot_first_ : 0u);
-      a.xcd_phase = xcd_phase_;
       const bool blu_here = ps.has_blu && ((blu.io == IO_BLU_IN && p == 0) || (blu.io == IO_BLU_OUT && p + 1 == np));
       if (blu_here) {
         a.blu_x = blu.xtab; a.blu_n = blu.n; a.blu_swap = blu.swap;
@@ -607,9 +605,6 @@ template <typename T> class Pow2Engine {
     return !passes_.empty();
   }
   void set_skeleton(bool on) { skeleton_ = on; }
-  // per-XCD rotation of the tile index inside a transform (xcd_remap), first / last pass of a plain plan
-  void set_xcd_rot(unsigned first, unsigned last) { xcd_rot_first_ = first; xcd_rot_last_ = last; }
-  void set_xcd_phase(unsigned p) { xcd_phase_ = p; }
   // "last_pass_prefetch" (experiments library): 1 = wherever the kernel exists; off by default -- measured slower
   void set_prefetch_last(bool on) { prefetch_last_ = on; }
   bool has_prefetch_last() const { return !passes_.empty() && passes_.back()->k_pf.fn != nullptr; }
@@ -673,7 +668,6 @@ template <typename T> class Pow2Engine {
   bool fused_on_ = false;
   bool prefetch_last_ = false;
   bool skeleton_ = false;
-  unsigned xcd_rot_first_ = 0, xcd_rot_last_ = 0, xcd_phase_ = 0;
   unsigned fused_grid_ = 0, fused_depth_ = 2;
   mutable DevBuf fused_window_, fused_ctrl_;
   mutable PinnedBuf fused_flag_;  // ctrl[1] (abort flag) of the last fused launch, read back before the call returns

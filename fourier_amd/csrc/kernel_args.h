@@ -38,8 +38,6 @@ struct PassArgs {
   uint32_t nxcd;      // >1: remap blockIdx so that each XCD (blockIdx % nxcd) walks a contiguous tile range
   uint32_t xcd_interleave;  // block -> tile mapping mode, see xcd_remap()
   uint32_t walk_band, walk_group, walk_tf;  // mode 4: tiles per band, transforms per group (0 = the XCD's whole range), transform-fastest
-  uint32_t xcd_phase; // transforms by which XCD x is ahead inside its own range of whole transforms (x * xcd_phase, wrapping), any mode
-  uint32_t xcd_rot;   // tiles by which XCD x rotates the tile index inside a transform (x * xcd_rot; bit 31: odd XCDs backwards), any mode
   const void* blu_x;  // Bluestein chirp table x[0..blu_n) (IO_BLU_IN / IO_BLU_OUT)
   // chirp-in pass WITHOUT the n-entry chirp table (a quarter of that pass's HBM-side traffic when read, PMC round 3):
   // index k = row*cn + b, so x[k] = W_2n^{k^2} = blu_p[row] * blu_u[b] * W_n^{cn*row*b}; the cross term splits like the

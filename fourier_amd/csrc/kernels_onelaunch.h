@@ -320,8 +320,11 @@ __global__ void __launch_bounds__(FOURIER_TWOLEVEL_NT(T, L1, L2), FOURIER_MIN_WA
 // register-resident M-point array of one workgroup: the forward two-level core, then the same core with the
 // roles of L1 and L2 exchanged (its input layout is the other's output layout).  HBM sees the N-point user
 // array once in and once out; the tables (x: N, w: M, twiddles) stay L2-resident.
+#ifndef FOURIER_BLU_SMALL_MIN_WAVES  // (A/B, round 6 session 7)
+#define FOURIER_BLU_SMALL_MIN_WAVES(NT) FOURIER_MIN_WAVES(NT)
+#endif
 template <typename T, int L1, int L2>
-__global__ void __launch_bounds__(FOURIER_TWOLEVEL_NT(T, L1, L2), FOURIER_MIN_WAVES(FOURIER_TWOLEVEL_NT(T, L1, L2)))
+__global__ void __launch_bounds__(FOURIER_TWOLEVEL_NT(T, L1, L2), FOURIER_BLU_SMALL_MIN_WAVES(FOURIER_TWOLEVEL_NT(T, L1, L2)))
     bluestein_small_kernel(PassArgs a) {
   constexpr int VEC = 16 / (2 * (int)sizeof(T));
   constexpr int CG1 = L2 / VEC, CG2 = L1 / VEC, Q1 = L1 / 16, Q2 = L2 / 16;

@@ -207,34 +207,7 @@ __device__ __forceinline__ cpx<T> two_level_twiddle(const PassArgs& a, uint64_t 
 //           the L2 by transform after transform while no transform or page is shared between XCDs
 // 32-bit arithmetic throughout (a grid has fewer than 2^31 blocks): the 64-bit form costs a few hundred scalar
 // instructions per tile, which a persistent workgroup pays once per tile.
-__device__ __forceinline__ uint32_t xcd_remap_base(const PassArgs& a, uint64_t blk64, uint64_t nwg64);
-// ... and, on top of any of these modes, a per-XCD ROTATION of the tile index inside its transform (xcd_rot tiles per XCD;
-// bit 31: odd XCDs walk the tiles of a transform backwards): the eight XCDs run through their ranges in step, and with ranges that
-// start a power of two apart their address streams agree in every bit below the distance -- on physically contiguous buffers that is
-// the same DRAM bank set at the same moment (round 6, profiles/r06_s2_placement2_*.jsonl: the slow mode of the last passes belongs
-// to exactly those allocations).  The rotation makes the streams differ in the tile-column bits; still a bijection.
 __device__ __forceinline__ uint32_t xcd_remap(const PassArgs& a, uint64_t blk64, uint64_t nwg64) {
-  uint32_t idx = xcd_remap_base(a, blk64, nwg64);
-  const uint32_t tiles = (uint32_t)a.tiles;
-  if (a.xcd_phase != 0 && a.nxcd > 1 && tiles >= 1) {
-    // ... and a per-XCD PHASE in the walk through its own range of whole transforms (A/B, round 6): XCD x is x * xcd_phase transforms ahead
-    // inside its range (wrapping around), so the eight streams are (range + phase) apart instead of exactly one range
-    const uint32_t nb = (uint32_t)nwg64 / tiles;
-    if (nb % a.nxcd == 0) {
-      const uint32_t tpx = nb / a.nxcd, b = idx / tiles, g = b / tpx, off = b - g * tpx;
-      idx = (g * tpx + (off + g * a.xcd_phase) % tpx) * tiles + (idx - b * tiles);
-    }
-  }
-  if (a.xcd_rot == 0 || a.nxcd <= 1 || tiles <= 1) return idx;
-  // keyed by the transform, not by the block: g = the XCD that owns transform b when the ranges are whole transforms (batch a multiple of
-  // the XCD count) -- a permutation of each transform's own tiles for ANY batch
-  const uint32_t b = idx / tiles, nb = (uint32_t)nwg64 / tiles, g = nb ? (uint32_t)(((uint64_t)b * a.nxcd) / nb) : 0u;
-  uint32_t t = idx - b * tiles;
-  if ((a.xcd_rot >> 31) && (g & 1)) t = tiles - 1 - t;
-  t = (t + g * (a.xcd_rot & 0x7fffffffu)) % tiles;
-  return b * tiles + t;
-}
-__device__ __forceinline__ uint32_t xcd_remap_base(const PassArgs& a, uint64_t blk64, uint64_t nwg64) {
   const uint32_t blk = (uint32_t)blk64, nwg = (uint32_t)nwg64, tiles = (uint32_t)a.tiles;
   if (a.nxcd <= 1) return blk;
   const uint32_t nx = a.nxcd, xcd = blk % nx, slot = blk / nx;

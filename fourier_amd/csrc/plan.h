@@ -218,14 +218,6 @@ template <typename T> class Plan {
       return 0;
     }
     if (key == "host_chunk_bytes" && v > 0) { host_chunk_bytes_ = (size_t)v; return 0; }
-    // per-XCD rotation of the tile index inside a transform (xcd_remap): v = tiles per XCD for the last pass | for the first pass << 12 |
-    // odd XCDs backwards (last pass) << 24 | (first pass) << 25; 0 = none
-    if (key == "xcd_phase" && v >= 0 && v < (1 << 20) && eng_ && !blu_) { eng_->set_xcd_phase((unsigned)v); return 0; }
-    if (key == "xcd_rotate" && v >= 0 && v < (1 << 26) && eng_ && !blu_) {
-      const unsigned last = (unsigned)v & 0xfff, first = ((unsigned)v >> 12) & 0xfff;
-      eng_->set_xcd_rot(first | (((unsigned)v >> 25) & 1u) << 31, last | (((unsigned)v >> 24) & 1u) << 31);
-      return 0;
-    }
     // the two passes of a two-pass power-of-two plan software-pipelined over two internal streams with the intermediate in a small
     // ring (Pow2Engine::run_pipelined): v = transforms per chunk | ring slots << 16 | one-stream control << 24; 0 = off
     if (key == "stream_pipeline" && v >= 0 && v < (1 << 25)) {

@@ -442,19 +442,6 @@ def test_chunking_and_scratch_options_do_not_change_results(fa):
             plan = make(fa, n2, np.complex64)
             plan.set_option("tile_walk", walk)
             assert np.array_equal(run_batch(plan, x2, 0), base2), (n2, batch2, walk)
-        # per-XCD rotation of the tile index inside a transform (round 6): last pass | first pass << 12 | backwards flags << 24
-        for rot in (1, 3, 8, 5 << 12, 2 | 7 << 12, 4 | 1 << 24, 1 << 12 | 1 << 25, 63 | 63 << 12 | 3 << 24):
-            plan = make(fa, n2, np.complex64)
-            try:
-                plan.set_option("xcd_rotate", rot)
-            except fa.FourierError:
-                assert n2 == 40001  # (a Bluestein plan has no such option)
-                continue
-            assert np.array_equal(run_batch(plan, x2, 0), base2), (n2, batch2, rot)
-            plan.set_option("tile_walk", 4)
-            assert np.array_equal(run_batch(plan, x2, 0), base2), (n2, batch2, rot, "band walk")
-            plan.set_option("xcd_phase", 1 + rot % 5)  # a per-XCD phase inside its own range of transforms (batch a multiple of 8)
-            assert np.array_equal(run_batch(plan, x2, 0), base2), (n2, batch2, rot, "phase")
     with pytest.raises(fa.FourierError):
         make(fa, n, np.complex64).set_option("xcd_swizzle", 5)
     with pytest.raises(fa.FourierError):
