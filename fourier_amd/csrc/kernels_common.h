@@ -85,21 +85,15 @@ static __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) { retur
 #undef FOURIER_ABLATE
 #define FOURIER_ABLATE 0
 #endif
-// A translation unit that compiles these templates DIFFERENTLY -- packed f32 arithmetic (FOURIER_PK_F32, below), an ablation -- gets them
-// in an inline namespace of its own: the same template names then are different entities from those of the other translation units (no
-// two definitions of one entity in a library that links both), while every unqualified use stays as it is.
-#if defined(FOURIER_PK_F32)
-#define FOURIER_KERNELS_BEGIN namespace fourier_hip { inline namespace pk_f32 {
-#define FOURIER_KERNELS_END } }
-#define FOURIER_SPLIT_BY_COLUMN 1  // split LDS exchanges of f32 tiles by column instead of by re / im plane (kernels_pass.h lds_exchange)
-#elif FOURIER_ABLATE != 0
+// A translation unit that compiles these templates DIFFERENTLY -- an ablation -- gets them in an inline namespace of its own: the same
+// template names then are different entities from those of the other translation units (no two definitions of one entity in a library
+// that links both), while every unqualified use stays as it is.
+#if FOURIER_ABLATE != 0
 #define FOURIER_KERNELS_BEGIN namespace fourier_hip { inline namespace ablated {
 #define FOURIER_KERNELS_END } }
-#define FOURIER_SPLIT_BY_COLUMN 0
 #else
 #define FOURIER_KERNELS_BEGIN namespace fourier_hip {
 #define FOURIER_KERNELS_END }
-#define FOURIER_SPLIT_BY_COLUMN 0
 #endif
 
 FOURIER_KERNELS_BEGIN
@@ -249,112 +243,6 @@ template <typename T> __device__ __forceinline__ void bf2(cpx<T>& a, cpx<T>& b) 
   b = {t.re - b.re, t.im - b.im};
 }
 template <typename T> __device__ __forceinline__ cpx<T> mul_neg_i(cpx<T> z) { return {z.im, -z.re}; }
-
-#if defined(FOURIER_PK_F32) && !defined(FOURIER_EMU)
-// ---- packed f32 arithmetic (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32), for the kernels whose pace is set by their VALU
-// instructions: the one-launch chirp-z kernels (two M-point transforms and three pointwise products per N <= M/2 user points;
-// round 6: 83 % of their wave cycles issue VALU work).  A complex number IS the packed pair (re, im) -- the register pair a
-// 16-byte load delivers, no re-layout --, so a complex add / subtract is ONE instruction instead of two and a complex multiply
-// TWO instead of four:   t = (-a.im * w.im, a.re * w.im)      v_pk_mul_f32  op_sel swaps a, broadcasts w.im, neg_lo
-//                        a * w = (a.re * w.re + t.lo, a.im * w.re + t.hi)      v_pk_fma_f32  op_sel_hi broadcasts w.re
-// -- the same products and the same two roundings per component as the scalar mul + fma the compiler contracts cmul to.  Multiplying
-// by -i never costs an instruction of its own: it is the operand swap + half negation of the add that consumes it.  hipcc folds
-// whole-operand negations and swaps into these modifiers by itself but not a negation of ONE half (it emits v_xor + v_mov for
-// that, and its SLP vectoriser pairs unrelated values at the price of 700 v_mov per kernel and twice the registers), hence
-// inline assembly for the forms with a half negation; plain vector arithmetic elsewhere.
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f pkv(const cpx<float>& a) { return (v2f){a.re, a.im}; }
-__device__ __forceinline__ cpx<float> pkc(v2f v) { return {v.x, v.y}; }
-// a + (-i) * b = (a.re + b.im, a.im - b.re)
-__device__ __forceinline__ v2f pk_add_negi(v2f a, v2f b) {
-  v2f r;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-// a - (-i) * b = (a.re - b.im, a.im + b.re)
-__device__ __forceinline__ v2f pk_sub_negi(v2f a, v2f b) {
-  v2f r;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ v2f pk_cmul(v2f a, v2f w) {
-  v2f t, r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[1,0]" : "=v"(t) : "v"(a), "v"(w));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
-  return r;
-}
-__device__ __forceinline__ cpx<float> cmul(cpx<float> a, cpx<float> b) { return pkc(pk_cmul(pkv(a), pkv(b))); }
-// the same with a compile-time constant w: from a scalar register pair (one per wave instead of a v_mov pair per use)
-__device__ __forceinline__ cpx<float> pk_cmul_const(cpx<float> a, float wre, float wim) {
-  const v2f av = pkv(a), w = (v2f){wre, wim};
-  v2f t, r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[1,0]" : "=v"(t) : "v"(av), "s"(w));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(av), "s"(w), "v"(t));
-  return pkc(r);
-}
-__device__ __forceinline__ void bf2(cpx<float>& a, cpx<float>& b) {
-  const v2f s = pkv(a) + pkv(b), d = pkv(a) - pkv(b);
-  a = pkc(s); b = pkc(d);
-}
-// butterfly of a and (-i) * b
-__device__ __forceinline__ void bf2_negi(cpx<float>& a, cpx<float>& b) {
-  const v2f s = pk_add_negi(pkv(a), pkv(b)), d = pk_sub_negi(pkv(a), pkv(b));
-  a = pkc(s); b = pkc(d);
-}
-// z * W8^1 = c * (z + (-i) z),  z * W8^3 = -c * (z - (-i) z)    (c = cos(pi/4))
-__device__ __forceinline__ cpx<float> pk_mul_w8_1(const cpx<float>& z) { return pkc(pk_add_negi(pkv(z), pkv(z)) * 0.70710678118654752440f); }
-__device__ __forceinline__ cpx<float> pk_mul_w8_3(const cpx<float>& z) { return pkc(pk_sub_negi(pkv(z), pkv(z)) * -0.70710678118654752440f); }
-__device__ __forceinline__ void dft2(cpx<float>* x) { bf2(x[0], x[1]); }
-__device__ __forceinline__ void dft4(cpx<float>& x0, cpx<float>& x1, cpx<float>& x2, cpx<float>& x3) {
-  bf2(x0, x2);
-  bf2(x1, x3);
-  bf2(x0, x1);       // X0, X2
-  bf2_negi(x2, x3);  // X1, X3
-  const cpx<float> t = x1; x1 = x2; x2 = t;
-}
-__device__ __forceinline__ void dft4(cpx<float>* x) { dft4(x[0], x[1], x[2], x[3]); }
-__device__ __forceinline__ void dft8(cpx<float>* x) {
-  dft4(x[0], x[2], x[4], x[6]);
-  dft4(x[1], x[3], x[5], x[7]);
-  x[3] = pk_mul_w8_1(x[3]);
-  x[7] = pk_mul_w8_3(x[7]);
-  bf2(x[0], x[1]);       // X0, X4
-  bf2(x[2], x[3]);       // X1, X5
-  bf2_negi(x[4], x[5]);  // X2, X6 (W8^2 = -i)
-  bf2(x[6], x[7]);       // X3, X7
-  const cpx<float> y1 = x[2], y2 = x[4], y3 = x[6], y4 = x[1], y5 = x[3], y6 = x[5];
-  x[1] = y1; x[2] = y2; x[3] = y3; x[4] = y4; x[5] = y5; x[6] = y6;
-}
-__device__ __forceinline__ void dft16(cpx<float>* x) {
-  const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;
-#pragma unroll
-  for (int a = 0; a < 4; ++a) dft4(x[a], x[a + 4], x[a + 8], x[a + 12]);
-  x[5] = pk_cmul_const(x[5], c1, -s1);    // W^1
-  x[9] = pk_mul_w8_1(x[9]);               // W^2
-  x[13] = pk_cmul_const(x[13], s1, -c1);  // W^3
-  x[6] = pk_mul_w8_1(x[6]);               // W^2
-  x[14] = pk_mul_w8_3(x[14]);             // W^6
-  x[7] = pk_cmul_const(x[7], s1, -c1);    // W^3
-  x[11] = pk_mul_w8_3(x[11]);             // W^6
-  x[15] = pk_cmul_const(x[15], -c1, s1);  // W^9
-  // second round; x[10] carries W^4 = -i into its butterfly: DFT4 of (x8, x9, -i x10, x11)
-#pragma unroll
-  for (int kb = 0; kb < 4; ++kb) {
-    cpx<float>&x0 = x[4 * kb], &x1 = x[4 * kb + 1], &x2 = x[4 * kb + 2], &x3 = x[4 * kb + 3];
-    if (kb == 2) bf2_negi(x0, x2); else bf2(x0, x2);
-    bf2(x1, x3);
-    bf2(x0, x1);
-    bf2_negi(x2, x3);
-    const cpx<float> t = x1; x1 = x2; x2 = t;
-  }
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = a + 1; b < 4; ++b) {
-      const cpx<float> t = x[a + 4 * b]; x[a + 4 * b] = x[b + 4 * a]; x[b + 4 * a] = t;
-    }
-}
-#endif
 
 // ---- small forward DFTs, natural order in and out (W = exp(-2*pi*i/R)) ----
 template <typename T> __device__ __forceinline__ void dft2(cpx<T>* x) { bf2(x[0], x[1]); }

@@ -1,12 +1,5 @@
 // kernels_onelaunch.cpp -- instantiates the one-launch plans (kernels_onelaunch.h): both passes of 2^11..2^15 and the whole chirp-z for M <= 2^15.
 // Compiled once per precision: -DFOURIER_TU_REAL=float / double (fourier_amd/build.py).
-// Packed f32 arithmetic (kernels_common.h, FOURIER_PK_F32) for the kernels of this translation unit; 0 = the scalar forms (A/B)
-#ifndef FOURIER_ONELAUNCH_PK
-#define FOURIER_ONELAUNCH_PK 1
-#endif
-#if FOURIER_ONELAUNCH_PK
-#define FOURIER_PK_F32 1
-#endif
 #include "engine_common.h"
 #include "kernels_onelaunch.h"
 #include "tile_shapes.h"

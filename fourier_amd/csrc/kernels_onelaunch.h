@@ -91,8 +91,6 @@ __device__ __forceinline__ void twolevel_core(cpx<T> (*x)[16], int tid, unsigned
   int tb = tid;
   FOURIER_LAUNDER(tb);  // phase B's mapping is derived here, not at the top of the kernel (see tile_core)
   const int th2 = tb / CG2, cg2 = tb % CG2;
-  // (the planes stay under packed arithmetic too: a transpose changes which elements share a unit, so whole complex numbers cannot go through
-  // the half-size buffer in two rounds without a second register tile; the packed kernels pay two v_mov per 8-byte read here)
   {
     constexpr bool SPLIT = CB::SPLIT;
     __syncthreads();  // the reads of phase A's exchange are done
@@ -320,9 +318,9 @@ __global__ void __launch_bounds__(FOURIER_TWOLEVEL_NT(T, L1, L2), FOURIER_MIN_WA
 // register-resident M-point array of one workgroup: the forward two-level core, then the same core with the
 // roles of L1 and L2 exchanged (its input layout is the other's output layout).  HBM sees the N-point user
 // array once in and once out; the tables (x: N, w: M, twiddles) stay L2-resident.
-#ifndef FOURIER_BLU_SMALL_MIN_WAVES  // (A/B, round 6 session 7)
-#define FOURIER_BLU_SMALL_MIN_WAVES(NT) FOURIER_MIN_WAVES(NT)
-#endif
+// (workgroups of up to 256 threads -- M = 2048 ... 8192 -- under a 128-register cap: four waves per SIMD instead of three at 130 registers, a few
+// dwords of scratch: f32 +6 ... 12 %, f64 level; profiles/r06_s7_chirpz_small_occupancy_ab.jsonl)
+#define FOURIER_BLU_SMALL_MIN_WAVES(NT) ((NT) <= 256 ? 4 : FOURIER_MIN_WAVES(NT))
 template <typename T, int L1, int L2>
 __global__ void __launch_bounds__(FOURIER_TWOLEVEL_NT(T, L1, L2), FOURIER_BLU_SMALL_MIN_WAVES(FOURIER_TWOLEVEL_NT(T, L1, L2)))
     bluestein_small_kernel(PassArgs a) {

@@ -76,10 +76,7 @@ __device__ __forceinline__ void lds_exchange(RegTile<T, L, CG>& x, unsigned char
   using C = TileCfg<T, L, CG>;
   constexpr int VEC = C::VEC, Q = C::Q;
   if constexpr (C::SPLIT) {
-    // two rounds of 8-byte units through a buffer of half the tile: the re plane, then the im plane, of the VEC columns of a unit -- or,
-    // for f32 under FOURIER_SPLIT_BY_COLUMN, column 0 then column 1 as whole complex numbers: the same slots, sizes and bank pattern,
-    // but a unit then IS the packed (re, im) register pair of the packed-arithmetic kernels (no v_mov to gather / scatter halves)
-    constexpr bool BY_COLUMN = FOURIER_SPLIT_BY_COLUMN != 0 && VEC == 2;
+    // two rounds of 8-byte units through a buffer of half the tile: the re plane, then the im plane, of the VEC columns of a unit
     Unit8<T>* lds = (Unit8<T>*)smem;
 #pragma unroll
     for (int plane = 0; plane < 2; ++plane) {
@@ -87,11 +84,8 @@ __device__ __forceinline__ void lds_exchange(RegTile<T, L, CG>& x, unsigned char
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         Unit8<T> u;
-        if constexpr (BY_COLUMN) { u.a[0] = x[plane][r].re; u.a[1] = x[plane][r].im; }
-        else {
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) u.a[v] = plane ? x[v][r].im : x[v][r].re;
-        }
+        for (int v = 0; v < VEC; ++v) u.a[v] = plane ? x[v][r].im : x[v][r].re;
         Unit8<T>* p = lds + C::template unit_index<LAYOUT>(wpos(r), cg_w);
         LDS_NOTE(p, 8, true, site + plane);
         *p = u;
@@ -102,12 +96,9 @@ __device__ __forceinline__ void lds_exchange(RegTile<T, L, CG>& x, unsigned char
         const Unit8<T>* p = lds + C::template unit_index<LAYOUT>(th_r + Q * r, cg_r);
         LDS_NOTE(p, 8, false, site + 2 + plane);
         const Unit8<T> u = *p;
-        if constexpr (BY_COLUMN) { x[plane][r].re = u.a[0]; x[plane][r].im = u.a[1]; }
-        else {
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) {
-            if (plane) x[v][r].im = u.a[v]; else x[v][r].re = u.a[v];
-          }
+        for (int v = 0; v < VEC; ++v) {
+          if (plane) x[v][r].im = u.a[v]; else x[v][r].re = u.a[v];
         }
       }
     }

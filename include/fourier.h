@@ -213,6 +213,13 @@ const char *fourier_hip_status_string(int status);
  *                  for transform-fastest | 1 << 20 for strided bands (every (tiles / band)-th tile instead of adjacent ones; measured slower);
  *                  0 = tile-major (the default except f32 N = 2^20, which walks bands of eight tiles).  "tile_walk_last": the same encoding
  *                  for the LAST pass of a plain multi-pass plan alone (0 = as the other passes)
+ *   "stream_pipeline" chunk | slots << 16 (| 1 << 24: both passes on ONE internal stream, a control): the two passes of a two-pass
+ *                  power-of-two plan chunk by chunk over two internal streams, ordered by events only -- pass 0 of chunk k+1 beside pass 1 of
+ *                  chunk k -- with the intermediate in a plan-owned ring of `slots` (>= 2) chunks of `chunk` transforms.  The same kernels on the same
+ *                  data: the same bits.  Measured on MI355X: level with the two whole-batch launches for chunks of 128+ transforms, slower
+ *                  below (launch and event latency); what it buys is MEMORY -- an in-place call then needs the ring (two chunks) instead of a
+ *                  scratch of the whole batch.  The call stays stream-ordered on the caller's stream (forked into and joined from the internal
+ *                  streams; capturable after fourier_hip_reserve_*).  0 = off (default).  INVALID_ARGUMENT on any other plan.
  *   "l2_fused"     (lib/libfourier_experiments.so only; INVALID_ARGUMENT in the product library; so is
  *                  "last_pass_prefetch", the persistent prefetching last pass of DESIGN.md section 4) 1 = run both
  *                  passes of a two-pass plan in ONE launch with the intermediate parked in the XCD's L2 (persistent
@@ -237,8 +244,12 @@ int fourier_hip_set_option_double(FOURIER_STRUCT fourier_fft_double *, const cha
  * Environment the library reads, all of it: FOURIER_HIP_VERBOSE (error text on stderr), FOURIER_HIP_SPECIALISE (above) and the
  * location of the code-object cache: $FOURIER_HIP_CACHE_DIR, else $XDG_CACHE_HOME/fourier-hip, else $HOME/.cache/fourier-hip (an EMPTY
  * FOURIER_HIP_CACHE_DIR switches the disk cache off).  Cache files are keyed by device architecture, precision, kernel kind, length
- * and a hash of the embedded kernel sources and compile options: a library update never loads a stale kernel.  A cache file is trusted only if
- * it is a regular file owned by the calling user that no one else may write (files are created 0600 in a 0700 directory).
+ * and a hash of the embedded kernel sources, the compile options and the HIP runtime's version: a library or ROCm update never loads a stale
+ * kernel.  A cache entry is executed on the device, so it is trusted only if its directory belongs to the calling user and nobody else may write it,
+ * the entry itself is a regular file of that user that nobody else may write, opened without following a symbolic link, and it names the very
+ * key (precision, kind, length, LDS bytes) and payload length it is read for; anything else of the user's under that name is discarded, anything of
+ * another user's is ignored (files are created 0600, the directory 0700).  `fourier_warm_cache` (packaging/warm_cache.c, CMake target `warm_cache`)
+ * and `python -m fourier_amd.warm_cache` fill the cache at install time: see INTEGRATION.md section 1.
  * Returns FOURIER_HIP_OK or FOURIER_HIP_INVALID_ARGUMENT (unknown key / value); _get_ returns the value or -1. */
 int fourier_hip_set_default_option(const char *key, long long value);
 long long fourier_hip_get_default_option(const char *key);

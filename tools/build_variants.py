@@ -21,9 +21,6 @@ VARIANTS = {
     "abl3": ["-DFOURIER_EXPERIMENTS_TU=1", "-DFOURIER_ABLATE=3"],
     "abl4": ["-DFOURIER_EXPERIMENTS_TU=1", "-DFOURIER_ABLATE=4"],  # stage twiddles from a constant (no table loads inside the in-tile transform)
     "abl5": ["-DFOURIER_EXPERIMENTS_TU=1", "-DFOURIER_ABLATE=5"],  # per-thread inter-pass twiddle factor from a constant (no two-level look-up)
-    "onelaunch_scalar": ["-DFOURIER_ONELAUNCH_PK=0"],
-    "blu_small_mw4": ["-DFOURIER_BLU_SMALL_MIN_WAVES(NT)=((NT)<=256?4:FOURIER_MIN_WAVES(NT))"],
-    "blu_small_mw4_scalar": ["-DFOURIER_ONELAUNCH_PK=0", "-DFOURIER_BLU_SMALL_MIN_WAVES(NT)=((NT)<=256?4:FOURIER_MIN_WAVES(NT))"],
 }
 
 
