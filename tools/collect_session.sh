@@ -1,5 +1,5 @@
 #!/bin/bash
-# Copies what tools/gpu_r05_final.sh left in gpurun_out/ (scratch) into profiles/ (tracked) under <tag>_*, and folds the PMC
+# Copies what tools/gpu_r06_final.sh left in gpurun_out/ (scratch) into profiles/ (tracked) under <tag>_*, and folds the PMC
 # summaries into profiles/traffic_latest.json.  usage: bash tools/collect_session.sh r05_s9
 set -u
 T=${1:?tag}; G=gpurun_out; P=profiles
