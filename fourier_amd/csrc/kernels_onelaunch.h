@@ -282,6 +282,8 @@ __global__ void __launch_bounds__(FOURIER_TWOLEVEL_NT(T, L1, L2), FOURIER_MIN_WA
     const uint32_t voff = (uint32_t)((th * L2 + cg * VEC) * sizeof(cpx<T>));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
+      // (streaming hints on both sides also where one 1024-thread workgroup has a CU to itself: without them 2^15 f32 / 2^14 f64 lose 7 - 8 %,
+      // the shorter plans 2 - 4 % -- unlike the 16-column last pass of length 2048; profiles/r06_s13_one_launch_policy_ab.jsonl)
       const Unit16<T> u = buf_load_unit<T, BUF_NT>(ri, voff, (uint32_t)((Q1 * r) * L2 * sizeof(cpx<T>)));
 #pragma unroll
       for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};

@@ -697,12 +697,17 @@ __device__ __forceinline__ void pass_tile(const PassArgs& a, uint64_t blk0, uint
 // cache policy of the stand-alone pass kernels (kernels_common.h has the measurements)
 template <int L, int MODE, int CG = 8> struct PassPolicy {
   static constexpr bool FINAL = (MODE == MODE_LAST || MODE == MODE_ROWS);
+  // the 16-column last passes of length 2048 (one 1024-thread workgroup per CU): NO streaming hint on either side.  Round 6, 18 fresh
+  // allocations of the C5 chunk: 13.5 -> 12.1 - 12.25 ms on eleven of them, level on the other seven, never slower; 2^22 on shared buffers
+  // 25.70 -> 24.51 ms (f64 25.71 -> 25.17), C4's chirp-out pass 3.00 -> 2.94, bit-identical (profiles/r06_s12_*).  The two-workgroups-per-CU
+  // passes of length <= 1024 lose 0.2 - 1 ms per 4096 transforms without the hints (r06_s11_last_pass_store_policy.jsonl).
+  static constexpr bool WIDE_LAST = (MODE == MODE_LAST && L >= 2048);
   // 64-byte-wide tiles (CG = 4): two workgroups share every 128-byte line, the second one must find it in the L2, so
   // no streaming hint (L = 2048 first pass: 6.5 vs 7.6 ms per 1024 transforms of 2^21, r01 session 11)
-  static constexpr int LD = (MODE != MODE_ROWS && CG < 8) ? POL_PLAIN : POL_NT;
+  static constexpr int LD = ((MODE != MODE_ROWS && CG < 8) || WIDE_LAST) ? POL_PLAIN : POL_NT;
   // MODE_ROWS: a wave's element stores only form whole lines for L >= 256; below that they rely on L2
   // write-combining and a non-temporal hint is a 2-6x loss (N = 16..64, r01 session 9)
-  static constexpr int ST = (MODE == MODE_ROWS ? L >= 256 : (FINAL || L <= 1024 || CG < 8)) ? POL_NT : POL_PLAIN;
+  static constexpr int ST = WIDE_LAST ? POL_PLAIN : ((MODE == MODE_ROWS ? L >= 256 : (FINAL || L <= 1024 || CG < 8)) ? POL_NT : POL_PLAIN);
 };
 
 template <typename T, int L, int CG, int MODE, int IO = IO_PLAIN>
