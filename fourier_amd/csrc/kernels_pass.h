@@ -756,6 +756,7 @@ __global__ void __launch_bounds__((L / 16) * CG, FOURIER_MIN_WAVES((L / 16) * CG
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       // tiles narrower than a 128-byte line share every line with a sibling workgroup: no streaming hint then
+      // (round 6: without the hint on these loads the kernel loses 3 - 7 %, without it on its stores 4 - 10 %; profiles/r06_s16_conv_policy_ab.jsonl)
       const Unit16<T> u = buf_load_unit<T, CG >= 8 ? BUF_NT : BUF_PLAIN>(rs, voff, (uint32_t)r * rowb);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
