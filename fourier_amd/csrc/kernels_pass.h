@@ -707,6 +707,8 @@ template <int L, int MODE, int CG = 8> struct PassPolicy {
   static constexpr int LD = ((MODE != MODE_ROWS && CG < 8) || WIDE_LAST) ? POL_PLAIN : POL_NT;
   // MODE_ROWS: a wave's element stores only form whole lines for L >= 256; below that they rely on L2
   // write-combining and a non-temporal hint is a 2-6x loss (N = 16..64, r01 session 9)
+  // (the 8-column first pass of length 2048 keeps its streaming stores: plain 2 - 4 % slower; its 16-column form on one workgroup per CU stays 8 - 25 %
+  // slower with or without the hint on its loads; profiles/r06_s17_first_pass_2048_ab.jsonl)
   static constexpr int ST = WIDE_LAST ? POL_PLAIN : ((MODE == MODE_ROWS ? L >= 256 : (FINAL || L <= 1024 || CG < 8)) ? POL_NT : POL_PLAIN);
 };
 
