@@ -210,25 +210,38 @@ template <typename T, bool NT> __device__ __forceinline__ void store_elem(cpx<T>
 
 // 16-byte accesses to arrays that are only 8-byte aligned (f32 user arrays of odd length inside a batch):
 // global_load/store_dwordx4 need dword alignment only.
-template <typename T> __device__ __forceinline__ Unit16<T> load_unit_a8(const void* p) {
+template <typename T, bool STREAM = false> __device__ __forceinline__ Unit16<T> load_unit_a8(const void* p) {  // STREAM: read-once data
   Unit16<T> u;
 #ifndef FOURIER_EMU
   typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-  struct __attribute__((packed, aligned(8))) V { v4u v; };
-  const v4u v = ((const V*)p)->v;
+  v4u v;
+  if constexpr (STREAM) {
+    typedef v4u v4u_a8 __attribute__((aligned(8)));
+    v = __builtin_nontemporal_load((const v4u_a8*)p);
+  } else {
+    struct __attribute__((packed, aligned(8))) V { v4u v; };
+    v = ((const V*)p)->v;
+  }
   __builtin_memcpy(&u, &v, 16);
 #else
   __builtin_memcpy(&u, p, 16);
 #endif
   return u;
 }
-template <typename T> __device__ __forceinline__ void store_unit_a8(void* p, const Unit16<T>& u) {
+template <typename T, bool STREAM = false> __device__ __forceinline__ void store_unit_a8(void* p, const Unit16<T>& u) {
 #ifndef FOURIER_EMU
   typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-  struct __attribute__((packed, aligned(8))) V { v4u v; };
-  V w;
-  __builtin_memcpy(&w.v, &u, 16);
-  *(V*)p = w;
+  if constexpr (STREAM) {
+    typedef v4u v4u_a8 __attribute__((aligned(8)));
+    v4u v;
+    __builtin_memcpy(&v, &u, 16);
+    __builtin_nontemporal_store(v, (v4u_a8*)p);
+  } else {
+    struct __attribute__((packed, aligned(8))) V { v4u v; };
+    V w;
+    __builtin_memcpy(&w.v, &u, 16);
+    *(V*)p = w;
+  }
 #else
   __builtin_memcpy(p, &u, 16);
 #endif

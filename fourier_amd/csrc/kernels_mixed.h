@@ -132,7 +132,8 @@ template <typename T, int R> __device__ __forceinline__ void ref_butterfly(cpx<T
 // batch are only 8-byte aligned, which global_load/store_dwordx4 tolerate).  MAXU: compile-time bound of the units of a workgroup.
 // Up to eight units per thread are LOADED before the first of them is written: as a plain loop (`for u: lds[u] = g[u]`) hipcc
 // emits load, s_waitcnt vmcnt(0), ds_write per iteration -- one exposed HBM latency per 16 bytes of a thread's share (three per
-// workgroup at 768 points: +4 ... 22 % once batched, round 4).
+// workgroup at 768 points: +4 ... 22 % once batched, round 4).  Plain loads and stores: with streaming hints the lengths move by -7 ... +4 % (f64 96 / 100
+// alone gain 4 - 14 %) with no rule to them, and the mixed-length tile passes lose up to 40 % (profiles/r06_s18_*, r06_s19_mixed_lds_*).
 template <typename T, uint32_t NT, uint32_t MAXU, uint32_t CH = 8>  // CH: units of a thread in flight together
 __device__ __forceinline__ void copy_in_units(cpx<T>* lds, const cpx<T>* g, uint32_t units) {
   constexpr uint32_t VEC = 16 / (uint32_t)sizeof(cpx<T>);
