@@ -74,6 +74,7 @@ def translation_units():
         tus.append((f"kernels_misc_{tag}", "kernels_misc.cpp", d, "misc"))
         for i in range(4):
             tus.append((f"kernels_tiled_{tag}_{i}", "kernels_tiled.cpp", d + [f"-DFOURIER_TILED_SHARD={i}"], "mixed"))
+            tus.append((f"kernels_regtile_{tag}_{i}", "kernels_regtile.cpp", d + [f"-DFOURIER_TILED_SHARD={i}"], "mixed"))
         tus.append((f"kernels_experiments_{tag}", "kernels_experiments.cpp", d, "experiments"))
         tus.append((f"kernels_skeleton_{tag}", "kernels_skeleton.cpp", d, "experiments"))
     return tus

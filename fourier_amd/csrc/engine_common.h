@@ -171,7 +171,8 @@ typedef void (*BluKernel)(BluArgs);
 typedef void (*MixKernelFn)(MixArgs);
 typedef void (*TiledKernelFn)(TiledArgs);
 // a tile pass of mixed length L: columns per tile, threads, LDS bytes
-struct TiledKernel { TiledKernelFn fn = nullptr; uint32_t L = 0, cols = 0, threads = 0; size_t smem = 0; };
+// r1 != 0: the register-resident kernel of kernels_regtile.h (L = r1 x r2; its `tw` table is W_L^{j2 * k1}, [r1][r2])
+struct TiledKernel { TiledKernelFn fn = nullptr; uint32_t L = 0, cols = 0, threads = 0; size_t smem = 0; uint32_t r1 = 0, r2 = 0; };
 // a mixed-radix LDS kernel with its launch shape: transforms per workgroup, LDS buffers of `group` transforms, threads
 struct MixKernel { MixKernelFn fn; uint32_t group; size_t nbuf; uint32_t threads; };
 
@@ -237,6 +238,10 @@ template <typename T> struct Real {};
   TiledKernel get_tiled_kernel(Real<T>, uint32_t L);                                                                   \
   TiledKernel get_tiled_kernel_s0(Real<T>, uint32_t L); TiledKernel get_tiled_kernel_s1(Real<T>, uint32_t L);         \
   TiledKernel get_tiled_kernel_s2(Real<T>, uint32_t L); TiledKernel get_tiled_kernel_s3(Real<T>, uint32_t L);         \
+  /* kernels_regtile.cpp (4 shards): the same pass with the transform in registers, L = R1 x R2, R1, R2 <= 32; fn == nullptr: none */ \
+  TiledKernel get_regtile_kernel(Real<T>, uint32_t L);                                                                 \
+  TiledKernel get_regtile_kernel_s0(Real<T>, uint32_t L); TiledKernel get_regtile_kernel_s1(Real<T>, uint32_t L);     \
+  TiledKernel get_regtile_kernel_s2(Real<T>, uint32_t L); TiledKernel get_regtile_kernel_s3(Real<T>, uint32_t L);     \
   /* kernels_experiments.cpp (experiments library) or env_product.cpp (product: nothing available) */                  \
   bool get_fused_kernel(Real<T>, int k, FusedInfo& info);                                                              \
   KernelInfo get_split_kernel(Real<T>, int L, int io);                                                                 \

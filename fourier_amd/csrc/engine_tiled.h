@@ -7,6 +7,13 @@
 
 namespace fourier_hip {
 
+#ifndef FOURIER_TILE_CHUNK  // (A/B, round 6 session 24)
+#define FOURIER_TILE_CHUNK 4
+#endif
+#ifndef FOURIER_TILE_CHUNK_ALIGNED
+#define FOURIER_TILE_CHUNK_ALIGNED 0
+#endif
+
 template <typename T> class TiledMixedEngine {
  public:
   static constexpr size_t MAX_N = (size_t)1 << 26;
@@ -84,6 +91,17 @@ template <typename T> class TiledMixedEngine {
     return !factorise(n).empty();
   }
 
+  // the ahead-of-time kernel of a tile pass of length L: the register-resident one (kernels_regtile.h) where the length splits into two
+  // factors of at most 32, else the LDS one (kernels_tiled.h); FOURIER_NO_REGTILE (experiments library, emulator): always the latter
+  static TiledKernel pass_kernel(uint32_t L) {
+#ifndef FOURIER_AB_NO_REGTILE
+    if (!dev_env("FOURIER_NO_REGTILE")) {
+      const TiledKernel k = get_regtile_kernel(Real<T>{}, L);
+      if (k.fn) return k;
+    }
+#endif
+    return get_tiled_kernel(Real<T>{}, L);
+  }
   // launch shape of a tile pass of length L for a kernel compiled at run time: tiled_shape (mixed_schedule.h), the function the
   // kernel's own TiledCfg is built from
   static TiledKernel shape_of(uint32_t L) {
@@ -107,7 +125,7 @@ template <typename T> class TiledMixedEngine {
     uint64_t s = 1, size = n;
     for (uint32_t L : lens) {
       Pass ps;
-      ps.k = get_tiled_kernel(Real<T>{}, L);
+      ps.k = pass_kernel(L);
       if (!ps.k.fn) {
         if (!rtc) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "no tile kernel of this length");
         ps.k = shape_of(L);
@@ -118,12 +136,27 @@ template <typename T> class TiledMixedEngine {
         specialised_ = true;
       }
       ps.s = s; ps.m = size / L;
+      {  // row segments that straddle 128-byte lines (a transform, an input row or an output row that does not start on one): neighbouring
+         // tiles in one L2 (xcd_chunked)
+        const uint64_t e = sizeof(cpx<T>);
+        const bool straddle = (n * e) % 128 != 0 || (ps.s * ps.m * e) % 128 != 0 || (ps.s > 1 && (ps.s * e) % 128 != 0);
+        ps.xcd_chunk = straddle ? FOURIER_TILE_CHUNK : FOURIER_TILE_CHUNK_ALIGNED;
+      }
       if (ps.k.fn) raise_smem_limit((const void*)ps.k.fn, ps.k.smem);
       // tables of the in-tile transform: the reference's layout for a plan of length L (mod.rs:24-46), f64 trig then cast
       auto it = tables_.find(L);
       if (it == tables_.end()) {
         std::vector<cpx<T>> tw;
         size_t cur = L;
+        if (ps.k.r1) {  // register-resident kernel: the twiddle between its two stages, W_L^{j2 * k1} as [k1 < r1][j2 < r2]
+          for (size_t k1 = 0; k1 < ps.k.r1; ++k1)
+            for (size_t j2 = 0; j2 < ps.k.r2; ++j2) {
+              double re, im;
+              unit_root(j2 * k1, L, re, im);
+              tw.push_back({(T)re, (T)im});
+            }
+          cur = 1;
+        }
         while (cur > 1) {
           const size_t R = mix_next_radix(L, (uint32_t)cur, cur == L);
           const size_t mm = cur / R;
@@ -181,6 +214,7 @@ template <typename T> class TiledMixedEngine {
       a.tiles_per_row = (columns + ps.k.cols - 1) / ps.k.cols;
       a.swap_in = (p == 0) && inverse; a.swap_out = (p + 1 == np) && inverse;
       a.scale = (p + 1 == np) ? scale : 1.0;
+      a.xcd_chunk = ps.xcd_chunk;
       const cpx<T> w3 = ref_twiddle(1, 3), w8 = ref_twiddle(1, 8);
       a.w3re = w3.re; a.w3im = w3.im; a.w8re = w8.re; a.w8im = w8.im;
       const uint64_t grid = (uint64_t)batch * a.tiles_per_row * (ps.s == 1 ? 1 : ps.m);
@@ -210,7 +244,7 @@ template <typename T> class TiledMixedEngine {
     TiledKernel k;
     RtcKernel rtc;  // set instead of k.fn for a length compiled at run time
     uint64_t s = 1, m = 1;
-    uint32_t lo_bits = 0;
+    uint32_t lo_bits = 0, xcd_chunk = 0;
     DevBuf* tw = nullptr;
     std::unique_ptr<DevBuf> tw_lo, tw_hi;
   };

@@ -117,6 +117,7 @@ struct TiledArgs {
   uint64_t n, s, m;           // transform length (batch stride); Stockham stride; size / L (1 in the last pass)
   uint64_t tiles_per_row;     // ceil(columns / COLS): columns = m in the first pass (s == 1), s afterwards
   int swap_in, swap_out;
+  uint32_t xcd_chunk;         // workgroup -> tile order (xcd_chunked, kernels_common.h): 0 = identity
   double scale;               // applied by the last pass
   double w3re, w3im, w8re, w8im;  // compute_twiddle(1, 3, true), compute_twiddle(1, 8, true) as T values (butterfly.rs:12,50)
 };

@@ -247,6 +247,16 @@ template <typename T, bool STREAM = false> __device__ __forceinline__ void store
 #endif
 }
 
+// Tile index of workgroup blk of a grid (mixed-length tile passes).  Consecutive workgroups go to different XCDs (blockIdx % 8); with
+// chunk = G > 0 every run of 8 * G workgroups is dealt out so that XCD x takes G NEIGHBOURING tiles: tiles next to each other in a row share
+// the 128-byte lines their row segments straddle whenever a row stride is not a multiple of 128 bytes (44100 = 210 x 210: 1680 bytes) and
+// then meet in one L2, close in time.  The last grid % (8 * G) workgroups keep their index.
+__device__ __forceinline__ uint32_t xcd_chunked(uint32_t blk, uint32_t grid, uint32_t chunk) {
+  const uint32_t span = 8u * chunk;
+  if (chunk == 0u || blk >= grid - grid % span) return blk;
+  const uint32_t r = blk % span;
+  return blk - r + (r & 7u) * chunk + (r >> 3);
+}
 template <typename T> __device__ __forceinline__ cpx<T> cmul(cpx<T> a, cpx<T> b) {
   return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
 }

@@ -1,0 +1,304 @@
+// kernels_regtile.h -- column-tile passes of MIXED length with the transform in REGISTERS (round 6).
+//
+// Same pass as kernels_tiled.h -- N = L1 x L2 (x L3), one launch per factor computes
+//     out[j + L*s*i + s*k] = W_size^{i*k} * DFT_L(in[j + s*i + s*m*k'])_k          (autosort/mod.rs:203-284 with R = L)
+// on tiles of COLS adjacent columns (128-byte row segments) -- but the L-point transform of a column is ONE Cooley-Tukey step
+// L = R1 x R2 between two register-resident transforms (what kernels_pass.h does for the powers of two with 16 x 16 x R3):
+//   stage A  thread (column c, j2 < R2) loads rows j2 + R2*j1 (j1 < R1) straight from global memory, transforms them (DFT_R1 in
+//            registers, any R1 <= 32 whose prime factors stop at 13), multiplies by W_L^{j2*k1} and writes LDS;
+//   stage B  thread (column c, k1 < R1) reads its R2 values, transforms them (DFT_R2), multiplies by the inter-pass twiddle
+//            W_size^{i*(k1 + R1*k2)} and stores -- 128-byte row segments straight from registers in the later passes, through LDS
+//            (every column's L outputs contiguous: mod.rs:203-284 at s = 1) in the first.
+// kernels_tiled.h gathers the tile into LDS and runs the reference's small-radix schedule there (four or five LDS round trips with a
+// barrier each, their index arithmetic per butterfly): 3.6 - 4.2 TB/s per pass against 5.9 for the power-of-two tiles, VALU and LDS
+// instructions per byte 2.7 x / 3.2 x theirs (profiles/r06_s20_sq_tiled.json).  Here: one LDS round trip (two in the first pass), every
+// index a compile-time constant.  Tolerance-only route like every tile pass of mixed length (include/fourier.h).
+#pragma once
+#include "kernels_mixed.h"
+
+namespace fourier_hip {
+
+// ---- unit roots at compile time: exp(-2 pi i e / R) = (c[e], -s[e]) ----
+constexpr double ct_sin_poly(double x) {  // |x| <= pi / 4: Taylor to x^19, below 1e-17 there
+  const double x2 = x * x;
+  double r = -1.0 / 121645100408832000.0;  // -1 / 19!
+  r = r * x2 + 1.0 / 355687428096000.0;
+  r = r * x2 - 1.0 / 1307674368000.0;
+  r = r * x2 + 1.0 / 6227020800.0;
+  r = r * x2 - 1.0 / 39916800.0;
+  r = r * x2 + 1.0 / 362880.0;
+  r = r * x2 - 1.0 / 5040.0;
+  r = r * x2 + 1.0 / 120.0;
+  r = r * x2 - 1.0 / 6.0;
+  return x + x * x2 * r;
+}
+constexpr double ct_cos_poly(double x) {
+  const double x2 = x * x;
+  double r = 1.0 / 6402373705728000.0;  // 1 / 18!
+  r = r * x2 - 1.0 / 20922789888000.0;
+  r = r * x2 + 1.0 / 87178291200.0;
+  r = r * x2 - 1.0 / 479001600.0;
+  r = r * x2 + 1.0 / 3628800.0;
+  r = r * x2 - 1.0 / 40320.0;
+  r = r * x2 + 1.0 / 720.0;
+  r = r * x2 - 1.0 / 24.0;
+  r = r * x2 + 0.5;
+  return 1.0 - x2 * r;
+}
+template <int R> struct RootTab { double c[R], s[R]; };
+template <int R> constexpr RootTab<R> root_tab() {
+  RootTab<R> t{};
+  for (int e = 0; e < R; ++e) {
+    // angle = 2 pi e / R = quarter * pi/2 + (pi/2) * rem / R, the last term folded into [0, pi/4] by cos <-> sin
+    const int quarter = (4 * e) / R, rem = 4 * e - quarter * R;
+    const bool fold = 2 * rem > R;
+    const double x = 1.5707963267948966192 * (double)(fold ? R - rem : rem) / (double)R;
+    const double cx = fold ? ct_sin_poly(x) : ct_cos_poly(x), sx = fold ? ct_cos_poly(x) : ct_sin_poly(x);
+    t.c[e] = quarter == 0 ? cx : quarter == 1 ? -sx : quarter == 2 ? -cx : sx;
+    t.s[e] = quarter == 0 ? sx : quarter == 1 ? cx : quarter == 2 ? -sx : -cx;
+  }
+  return t;
+}
+// z * exp(-2 pi i e / R); e is a constant wherever this is called (fully unrolled loops): the branches fold
+template <typename T, int R> __device__ __forceinline__ cpx<T> mul_root(cpx<T> z, int e) {
+  constexpr RootTab<R> tab = root_tab<R>();
+  e %= R;
+  if (e == 0) return z;
+  if (4 * e == R) return {z.im, -z.re};
+  if (2 * e == R) return {-z.re, -z.im};
+  if (4 * e == 3 * R) return {-z.im, z.re};
+  const T c = (T)tab.c[e], s = (T)tab.s[e];
+  return {z.re * c + z.im * s, z.im * c - z.re * s};
+}
+
+template <typename T> __device__ __forceinline__ void dft3(cpx<T>* x) {
+  const T h = (T)0.86602540378443864676;  // sin(pi / 3)
+  const cpx<T> t = {x[1].re + x[2].re, x[1].im + x[2].im}, d = {x[1].re - x[2].re, x[1].im - x[2].im};
+  const cpx<T> m = {x[0].re - (T)0.5 * t.re, x[0].im - (T)0.5 * t.im};
+  x[0] = {x[0].re + t.re, x[0].im + t.im};
+  x[1] = {m.re + h * d.im, m.im - h * d.re};  // m - i h d
+  x[2] = {m.re - h * d.im, m.im + h * d.re};  // m + i h d
+}
+
+// the leaf a composite length is split by first: the largest register butterfly that divides it
+constexpr int reg_leaf(int r) {
+  for (int p : {16, 8, 7, 5, 4, 3, 2, 13, 11})
+    if (r % p == 0) return p;
+  return r;
+}
+constexpr bool reg_is_leaf(int r) { return r == 1 || r == 2 || r == 3 || r == 4 || r == 5 || r == 7 || r == 8 || r == 11 || r == 13 || r == 16 || r == 32; }
+// forward DFT of R points in registers, natural order in and out: leaves, or one Cooley-Tukey step R = P x Q around them --
+// n = Q*n1 + n2, k = k1 + P*k2: X[k1 + P*k2] = sum_n2 W_Q^{n2*k2} W_R^{n2*k1} sum_n1 x[Q*n1 + n2] W_P^{n1*k1}
+template <typename T, int R> __device__ __forceinline__ void dft_any(cpx<T>* x) {
+  if constexpr (R == 1) {
+  } else if constexpr (R == 2 || R == 4 || R == 8 || R == 16 || R == 32) {
+    dft_r<T, R>(x);
+  } else if constexpr (R == 3) {
+    dft3(x);
+  } else if constexpr (R == 5 || R == 7 || R == 11 || R == 13) {
+    dft_prime<T, R>(x, true);
+  } else {
+    constexpr int P = reg_leaf(R), Q = R / P;
+    static_assert(P < R, "dft_any: a prime factor above 13");
+    cpx<T> a[Q][P];
+#pragma unroll
+    for (int n2 = 0; n2 < Q; ++n2) {
+      cpx<T> t[P];
+#pragma unroll
+      for (int n1 = 0; n1 < P; ++n1) t[n1] = x[Q * n1 + n2];
+      dft_any<T, P>(t);
+#pragma unroll
+      for (int k1 = 0; k1 < P; ++k1) a[n2][k1] = mul_root<T, R>(t[k1], n2 * k1);
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < P; ++k1) {
+      cpx<T> t[Q];
+#pragma unroll
+      for (int n2 = 0; n2 < Q; ++n2) t[n2] = a[n2][k1];
+      dft_any<T, Q>(t);
+#pragma unroll
+      for (int k2 = 0; k2 < Q; ++k2) x[k1 + P * k2] = t[k2];
+    }
+  }
+}
+
+// one complex number (8 / 16 bytes, 8-byte aligned: an f64 transform of odd length inside a batch) as ONE global access
+template <typename T> __device__ __forceinline__ cpx<T> load_cpx(const cpx<T>* p) {
+  if constexpr (sizeof(T) == 8) {
+    const Unit16<T> u = load_unit_a8<T>(p);
+    return {u.a[0], u.a[1]};
+  } else {
+    return *p;
+  }
+}
+template <typename T> __device__ __forceinline__ void store_cpx(cpx<T>* p, cpx<T> z) {
+  if constexpr (sizeof(T) == 8) {
+    Unit16<T> u;
+    u.a[0] = z.re; u.a[1] = z.im;
+    store_unit_a8<T>(p, u);
+  } else {
+    *p = z;
+  }
+}
+
+template <typename T, uint32_t L> struct RegTileCfg {  // the rules: reg_tile_shape (mixed_schedule.h), shared with the host
+  static constexpr RegTileShape S = reg_tile_shape(L, (uint32_t)sizeof(cpx<T>));
+  static constexpr uint32_t R1 = S.r1, R2 = S.r2, COLS = S.cols, NT = S.threads, XS = S.xstride, LDO = S.ldo;
+  static constexpr size_t TAB_OFF = S.tab_off, SMEM = S.smem;
+};
+
+template <typename T, uint32_t L>
+__global__ void __launch_bounds__((RegTileCfg<T, L>::NT)) tiled_reg_kernel(TiledArgs a) {
+  using C = RegTileCfg<T, L>;
+  constexpr uint32_t R1 = C::R1, R2 = C::R2, COLS = C::COLS, NT = C::NT, XS = C::XS, LDO = C::LDO;
+  static_assert(R1 * R2 == L && R1 >= R2, "tiled_reg_kernel: split");
+  FOURIER_DYN_SMEM(smem);
+  cpx<T>* buf = (cpx<T>*)smem;                // exchange: [k1][j2][c] at k1 * XS + j2 * COLS + c; first pass, then: [c][k] at c * LDO + k
+  cpx<T>* tu = (cpx<T>*)(smem + C::TAB_OFF);  // [COLS][R1]: W_size^{i * k1}
+  cpx<T>* tv = tu + COLS * R1;                // [COLS][R2]: W_size^{i * R1 * k2}
+  const uint32_t tid = threadIdx.x;
+  const uint32_t c = tid % COLS, q = tid / COLS;  // stage A: q = j2 (< R2); stage B: q = k1 (< R1)
+  const bool first = (a.s == 1);
+  // tile coordinates: block -> (transform b, i, first column c0), as in tiled_mixed_kernel_ct
+  const uint32_t tiles_per_row = (uint32_t)a.tiles_per_row;
+  const uint32_t rows = first ? 1u : (uint32_t)a.m;
+  const uint32_t blk = xcd_chunked(blockIdx.x, gridDim.x, a.xcd_chunk);
+  const uint32_t b = blk / (tiles_per_row * rows), rem = blk - b * (tiles_per_row * rows);
+  const uint32_t i_row = rem / tiles_per_row, c0 = (rem - i_row * tiles_per_row) * COLS;
+  const uint32_t ncols_total = first ? (uint32_t)a.m : (uint32_t)a.s;
+  const uint32_t ncols = ncols_total - c0 < COLS ? ncols_total - c0 : COLS;
+  const cpx<T>* __restrict__ in = (const cpx<T>*)a.in + (uint64_t)b * a.n;
+  cpx<T>* __restrict__ out = (cpx<T>*)a.out + (uint64_t)b * a.n;
+  const uint64_t row_stride = a.s * a.m;
+  const uint64_t col0 = first ? (uint64_t)c0 : (uint64_t)c0 + a.s * (uint64_t)i_row;
+  const bool twiddled = a.m > 1;
+  const bool live = c < ncols;  // a ragged last tile of a row: the columns past it load nothing and store nothing
+
+  // ---- stage A: rows j2 + R2*j1 of column c, their stage twiddles, and the entries of the inter-pass tables -- every global load
+  // of the thread ahead of its first use
+  cpx<T> x[R1];
+  if (q < R2) {
+    const cpx<T>* p = in + col0 + (live ? c : 0u) + row_stride * (uint64_t)q;  // (a column past a ragged tile reads column 0: never stored)
+#pragma unroll
+    for (uint32_t j1 = 0; j1 < R1; ++j1) x[j1] = load_cpx(p + row_stride * (uint64_t)(R2 * j1));
+  }
+  // the twiddle between the stages, W_L^{j2 * k1}, applied on the side with fewer values per thread (stage B: R2 <= R1), loaded with the
+  // data (issued before the barrier instead, its latency is exposed in every tile: f64 -25 %, profiles/r06_s23_regtile_remap_ab.jsonl)
+  cpx<T> w[R2];
+  if (q < R1) {
+    const cpx<T>* tw = (const cpx<T>*)a.tw + q * R2;  // [k1][j2]
+#pragma unroll
+    for (uint32_t j2 = 1; j2 < R2; ++j2) w[j2] = tw[j2];
+  }
+  constexpr uint32_t TENT = COLS * (R1 + R2), TITER = (TENT + NT - 1) / NT;
+  cpx<T> tlo[TITER], thi[TITER];
+  const uint32_t tcols = first ? COLS : 1u;  // the later passes have one i for the whole tile: table column 0
+  if (twiddled) {
+    const cpx<T>* lo = (const cpx<T>*)a.tw_lo;
+    const cpx<T>* hi = (const cpx<T>*)a.tw_hi;
+    const uint32_t mask = (1u << a.lo_bits) - 1u;
+#pragma unroll
+    for (uint32_t it = 0; it < TITER; ++it) {
+      const uint32_t e = tid + it * NT;
+      if (e < tcols * (R1 + R2)) {
+        const uint32_t tc = e / (R1 + R2), r = e - tc * (R1 + R2);
+        // (a masked column of a ragged last tile takes the last valid column's entries: its own index would reach past the tables)
+        const uint64_t i = first ? (uint64_t)(c0 + tc < ncols_total ? c0 + tc : ncols_total - 1u) : (uint64_t)i_row;
+        const uint64_t ex = i * (uint64_t)(r < R1 ? r : R1 * (r - R1));  // i * k < size
+        tlo[it] = lo[ex & mask];
+        thi[it] = hi[ex >> a.lo_bits];
+      }
+    }
+  }
+  if (q < R2) {
+    if (a.swap_in) {
+#pragma unroll
+      for (uint32_t j1 = 0; j1 < R1; ++j1) x[j1] = {x[j1].im, x[j1].re};
+    }
+    dft_any<T, (int)R1>(x);
+#pragma unroll
+    for (uint32_t k1 = 0; k1 < R1; ++k1) {
+      cpx<T>* d = buf + k1 * XS + q * COLS + c;
+      LDS_NOTE(d, sizeof(cpx<T>), true, 300);
+      *d = x[k1];
+    }
+  }
+  if (twiddled) {
+#pragma unroll
+    for (uint32_t it = 0; it < TITER; ++it) {
+      const uint32_t e = tid + it * NT;
+      if (e < tcols * (R1 + R2)) {
+        const uint32_t tc = e / (R1 + R2), r = e - tc * (R1 + R2);
+        const cpx<T> v = cmul(tlo[it], thi[it]);
+        if (r < R1) tu[tc * R1 + r] = v; else tv[tc * R2 + (r - R1)] = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- stage B: the R2 values of (column c, k1 = q); output k = k1 + R1*k2
+  cpx<T> y[R2];
+  if (q < R1) {
+#pragma unroll
+    for (uint32_t j2 = 0; j2 < R2; ++j2) {
+      const cpx<T>* s = buf + q * XS + j2 * COLS + c;
+      LDS_NOTE(s, sizeof(cpx<T>), false, 301);
+      y[j2] = j2 == 0 ? *s : cmul(*s, w[j2]);
+    }
+    dft_any<T, (int)R2>(y);
+    if (twiddled) {
+      const uint32_t tc = first ? c : 0u;
+      const cpx<T> u = tu[tc * R1 + q];
+#pragma unroll
+      for (uint32_t k2 = 0; k2 < R2; ++k2) y[k2] = cmul(y[k2], k2 == 0 ? u : cmul(u, tv[tc * R2 + k2]));
+    } else {  // last pass (mod.rs:238: no twiddle): the user-level scaling and the inverse's trailing swap
+      const T scale = (T)a.scale;
+#pragma unroll
+      for (uint32_t k2 = 0; k2 < R2; ++k2) {
+        if (a.swap_out) y[k2] = {y[k2].im, y[k2].re};
+        y[k2] = {y[k2].re * scale, y[k2].im * scale};
+      }
+    }
+  }
+  if (!first) {
+    // out[j + L*s*i + s*k]: 128-byte row segments, row k at stride s
+    if (q < R1 && live) {
+      cpx<T>* o = out + (uint64_t)c0 + c + (uint64_t)L * a.s * (uint64_t)i_row + a.s * (uint64_t)q;
+#pragma unroll
+      for (uint32_t k2 = 0; k2 < R2; ++k2) store_cpx(o + a.s * (uint64_t)(R1 * k2), y[k2]);
+    }
+    return;
+  }
+  // first pass: out[L*i + k] -- the tile's output is ONE contiguous run of ncols * L elements; transposed through LDS
+  __syncthreads();  // every thread has read its stage-B inputs
+  if (q < R1) {
+#pragma unroll
+    for (uint32_t k2 = 0; k2 < R2; ++k2) {
+      cpx<T>* d = buf + c * LDO + q + R1 * k2;
+      LDS_NOTE(d, sizeof(cpx<T>), true, 302);
+      *d = y[k2];
+    }
+  }
+  __syncthreads();
+  {
+    // one element per lane and instruction (f32: 8 bytes -- a wave still writes 512 contiguous bytes, and the LDS reads are at stride 1:
+    // pairs of elements per lane read two 8-byte words at a 16-byte stride, a 2-way bank conflict, SQ_LDS_BANK_CONFLICT 41 % at L = 400)
+    cpx<T>* o = out + (uint64_t)L * c0;
+    const uint32_t total = ncols * L;
+    constexpr uint32_t OITER = (L * COLS + NT - 1) / NT;
+    cpx<T> v[OITER];
+#pragma unroll
+    for (uint32_t it = 0; it < OITER; ++it) {
+      const uint32_t idx = tid + it * NT, idc = idx < total ? idx : 0u, cc = idc / L, k = idc - cc * L;  // (clamped: no branch around the read)
+      LDS_NOTE(buf + cc * LDO + k, sizeof(cpx<T>), false, 303);
+      v[it] = buf[cc * LDO + k];
+    }
+#pragma unroll
+    for (uint32_t it = 0; it < OITER; ++it) {
+      const uint32_t idx = tid + it * NT;
+      if (idx < total) store_cpx(o + idx, v[it]);
+    }
+  }
+}
+
+}  // namespace fourier_hip

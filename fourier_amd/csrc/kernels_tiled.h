@@ -41,7 +41,7 @@ __global__ void __launch_bounds__((TiledCfg<T, L>::NT)) tiled_mixed_kernel_ct(Ti
   // tile coordinates: block -> (transform b, i, first column c0)
   const uint32_t tiles_per_row = (uint32_t)a.tiles_per_row;      // ceil(columns per row / COLS)
   const uint32_t rows = first ? 1u : (uint32_t)a.m;              // values of i that have their own rows of tiles
-  const uint32_t blk = blockIdx.x;
+  const uint32_t blk = xcd_chunked(blockIdx.x, gridDim.x, a.xcd_chunk);
   const uint32_t b = blk / (tiles_per_row * rows), rem = blk - b * (tiles_per_row * rows);
   const uint32_t i_row = rem / tiles_per_row, c0 = (rem - i_row * tiles_per_row) * COLS;
   const uint32_t ncols_total = first ? (uint32_t)a.m : (uint32_t)a.s;

@@ -189,4 +189,36 @@ constexpr TileShape tiled_shape(uint32_t L, uint32_t elem) {
   return t;
 }
 
+// Launch shape of a register-resident column-tile pass of length L = R1 x R2 (kernels_regtile.h): ONE definition for the kernel
+// (RegTileCfg) and for the host.  r1 == 0: the length has no split into two factors of at most 32 (7^3, 5 * 7^2, 10 * 7^2, ...): it
+// stays on kernels_tiled.h.  The most balanced split, R1 >= R2: stage B (COLS x R1 threads, R2 stores each) keeps every thread busy.
+struct RegTileShape {
+  uint32_t r1, r2;
+  uint32_t cols;     // 128-byte row segments: 16 (f32) / 8 (f64) columns
+  uint32_t threads;  // COLS x R1, rounded up to whole waves
+  uint32_t xstride;  // elements between the k1 planes of the exchange buffer: R2 * COLS + padding
+  uint32_t ldo;      // leading dimension of a column in the first pass's output staging: odd
+  uint32_t tab_off;  // byte offset of the inter-pass twiddle tables behind the buffer
+  uint32_t smem;     // bytes of LDS
+};
+constexpr uint32_t REG_TILE_MAX_FACTOR = 32;
+constexpr RegTileShape reg_tile_shape(uint32_t L, uint32_t elem) {
+  RegTileShape t{};
+  uint32_t r2 = 0;
+  for (uint32_t b = 2; b * b <= L; ++b)
+    if (L % b == 0 && L / b <= REG_TILE_MAX_FACTOR) r2 = b;
+  if (r2 == 0) return t;
+  t.r1 = L / r2; t.r2 = r2;
+  t.cols = 128u / elem;
+  t.threads = (t.cols * t.r1 + 63u) & ~63u;
+  // stage B reads plane k1 = tid / COLS at j2 * COLS + c: the two (f64: four) planes a 32-lane group of a ds_read touches must differ by
+  // an odd multiple of 128 bytes -- one row segment of padding where R2 is even
+  t.xstride = t.r2 * t.cols + (t.r2 % 2u == 0u ? t.cols : 0u);
+  t.ldo = L | 1u;
+  const uint32_t xch = t.r1 * t.xstride, stage = t.cols * t.ldo;
+  t.tab_off = ((xch > stage ? xch : stage) * elem + 15u) & ~15u;
+  t.smem = t.tab_off + t.cols * (t.r1 + t.r2) * elem;
+  return t;
+}
+
 }  // namespace fourier_hip
