@@ -8,7 +8,7 @@
 namespace fourier_hip {
 
 #ifndef FOURIER_TILE_CHUNK  // (A/B, round 6 session 24)
-#define FOURIER_TILE_CHUNK 4
+#define FOURIER_TILE_CHUNK 8
 #endif
 #ifndef FOURIER_TILE_CHUNK_ALIGNED
 #define FOURIER_TILE_CHUNK_ALIGNED 0

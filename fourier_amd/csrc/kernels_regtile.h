@@ -153,7 +153,7 @@ __global__ void __launch_bounds__((RegTileCfg<T, L>::NT)) tiled_reg_kernel(Tiled
   constexpr uint32_t R1 = C::R1, R2 = C::R2, COLS = C::COLS, NT = C::NT, XS = C::XS, LDO = C::LDO;
   static_assert(R1 * R2 == L && R1 >= R2, "tiled_reg_kernel: split");
   FOURIER_DYN_SMEM(smem);
-  cpx<T>* buf = (cpx<T>*)smem;                // exchange: [k1][j2][c] at k1 * XS + j2 * COLS + c; first pass, then: [c][k] at c * LDO + k
+  cpx<T>* buf = (cpx<T>*)smem;                // exchange: [k1][j2][c] at k1 * XS + reg_tile_row(k1, j2) * COLS + c; first pass, then: [c][k] at c * LDO + k
   cpx<T>* tu = (cpx<T>*)(smem + C::TAB_OFF);  // [COLS][R1]: W_size^{i * k1}
   cpx<T>* tv = tu + COLS * R1;                // [COLS][R2]: W_size^{i * R1 * k2}
   const uint32_t tid = threadIdx.x;
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__((RegTileCfg<T, L>::NT)) tiled_reg_kernel(Tiled
     dft_any<T, (int)R1>(x);
 #pragma unroll
     for (uint32_t k1 = 0; k1 < R1; ++k1) {
-      cpx<T>* d = buf + k1 * XS + q * COLS + c;
+      cpx<T>* d = buf + k1 * XS + reg_tile_row(R2, k1, q) * COLS + c;
       LDS_NOTE(d, sizeof(cpx<T>), true, 300);
       *d = x[k1];
     }
@@ -241,7 +241,7 @@ __global__ void __launch_bounds__((RegTileCfg<T, L>::NT)) tiled_reg_kernel(Tiled
   if (q < R1) {
 #pragma unroll
     for (uint32_t j2 = 0; j2 < R2; ++j2) {
-      const cpx<T>* s = buf + q * XS + j2 * COLS + c;
+      const cpx<T>* s = buf + q * XS + reg_tile_row(R2, q, j2) * COLS + c;
       LDS_NOTE(s, sizeof(cpx<T>), false, 301);
       y[j2] = j2 == 0 ? *s : cmul(*s, w[j2]);
     }

@@ -196,24 +196,27 @@ struct RegTileShape {
   uint32_t r1, r2;
   uint32_t cols;     // 128-byte row segments: 16 (f32) / 8 (f64) columns
   uint32_t threads;  // COLS x R1, rounded up to whole waves
-  uint32_t xstride;  // elements between the k1 planes of the exchange buffer: R2 * COLS + padding
+  uint32_t xstride;  // elements between the k1 planes of the exchange buffer: R2 * COLS
   uint32_t ldo;      // leading dimension of a column in the first pass's output staging: odd
   uint32_t tab_off;  // byte offset of the inter-pass twiddle tables behind the buffer
   uint32_t smem;     // bytes of LDS
 };
 constexpr uint32_t REG_TILE_MAX_FACTOR = 32;
+// row of (plane k1, j2) inside its plane of the exchange buffer
+constexpr uint32_t reg_tile_row(uint32_t r2, uint32_t k1, uint32_t j2) { return (r2 % 2u == 0u) ? (j2 ^ (k1 & 1u)) : j2; }
 constexpr RegTileShape reg_tile_shape(uint32_t L, uint32_t elem) {
   RegTileShape t{};
   uint32_t r2 = 0;
   for (uint32_t b = 2; b * b <= L; ++b)
     if (L % b == 0 && L / b <= REG_TILE_MAX_FACTOR) r2 = b;
-  if (r2 == 0) return t;
+  // (125 = 25 x 5: 40 of 256 threads transform in stage A -- f64 15625 = 125 x 125 0.26 against 0.31 on the LDS kernel, r06_s25)
+  if (r2 == 0 || L / r2 > 4u * r2) return t;
   t.r1 = L / r2; t.r2 = r2;
   t.cols = 128u / elem;
   t.threads = (t.cols * t.r1 + 63u) & ~63u;
-  // stage B reads plane k1 = tid / COLS at j2 * COLS + c: the two (f64: four) planes a 32-lane group of a ds_read touches must differ by
-  // an odd multiple of 128 bytes -- one row segment of padding where R2 is even
-  t.xstride = t.r2 * t.cols + (t.r2 % 2u == 0u ? t.cols : 0u);
+  // stage B reads plane k1 = tid / COLS at j2 * COLS + c: the two (f64: four) planes a lane group of a ds_read touches must differ by an
+  // odd number of 128-byte row segments -- R2 odd, or (R2 even) rows j2 and j2 ^ 1 exchanged in the odd planes (reg_tile_row); no padding
+  t.xstride = t.r2 * t.cols;
   t.ldo = L | 1u;
   const uint32_t xch = t.r1 * t.xstride, stage = t.cols * t.ldo;
   t.tab_off = ((xch > stage ? xch : stage) * elem + 15u) & ~15u;
