@@ -239,9 +239,10 @@ template <typename T> struct Real {};
   TiledKernel get_tiled_kernel_s0(Real<T>, uint32_t L); TiledKernel get_tiled_kernel_s1(Real<T>, uint32_t L);         \
   TiledKernel get_tiled_kernel_s2(Real<T>, uint32_t L); TiledKernel get_tiled_kernel_s3(Real<T>, uint32_t L);         \
   /* kernels_regtile.cpp (4 shards): the same pass with the transform in registers, L = R1 x R2, R1, R2 <= 32; fn == nullptr: none */ \
-  TiledKernel get_regtile_kernel(Real<T>, uint32_t L);                                                                 \
-  TiledKernel get_regtile_kernel_s0(Real<T>, uint32_t L); TiledKernel get_regtile_kernel_s1(Real<T>, uint32_t L);     \
-  TiledKernel get_regtile_kernel_s2(Real<T>, uint32_t L); TiledKernel get_regtile_kernel_s3(Real<T>, uint32_t L);     \
+  /* which: 0 = the plain pass, 1 / 2 / 3 = Bluestein on a smooth M: chirp-in first pass, conv, chirp-out last pass */ \
+  TiledKernel get_regtile_kernel(Real<T>, uint32_t L, int which = 0);                                                  \
+  TiledKernel get_regtile_kernel_s0(Real<T>, uint32_t L, int which); TiledKernel get_regtile_kernel_s1(Real<T>, uint32_t L, int which); \
+  TiledKernel get_regtile_kernel_s2(Real<T>, uint32_t L, int which); TiledKernel get_regtile_kernel_s3(Real<T>, uint32_t L, int which); \
   /* kernels_experiments.cpp (experiments library) or env_product.cpp (product: nothing available) */                  \
   bool get_fused_kernel(Real<T>, int k, FusedInfo& info);                                                              \
   KernelInfo get_split_kernel(Real<T>, int L, int io);                                                                 \

@@ -254,4 +254,108 @@ template <typename T> class TiledMixedEngine {
   std::map<uint32_t, std::unique_ptr<DevBuf>> tables_;
 };
 
+// Bluestein's inner transforms on a SMOOTH M = L1 x L2 (kernels_regtile.h): the reference pads to the next power of two
+// (bluesteins.rs:110: M >= 2N - 1 is all the algorithm needs), up to 4N; here the smallest product of two register-tile lengths, three
+// sweeps -- chirp-in first pass (L1), conv (last forward + (.) w + first inverse pass, L2), chirp-out last pass (L1).
+template <typename T> class BluTiledEngine {
+ public:
+  // lengths with all three Bluestein kernels
+  static const std::vector<uint32_t>& menu() {
+    static const std::vector<uint32_t> m = [] {
+      std::vector<uint32_t> v;
+      for (uint32_t L = 64; L <= 512; ++L)
+        if (get_regtile_kernel(Real<T>{}, L, 1).fn) v.push_back(L);
+      return v;
+    }();
+    return m;
+  }
+  // the smallest M = L1 x L2 >= 2n - 1 (L1 >= L2: the conv kernel, the heavier one, at the shorter length; ties: the more balanced pair); 0: none
+  static uint64_t choose_m(size_t n, uint32_t& l1, uint32_t& l2) {
+    uint64_t best = 0;
+    const uint64_t need = 2 * (uint64_t)n - 1;
+    for (uint32_t a : menu())
+      for (uint32_t b : menu()) {
+        if (b > a) break;
+        const uint64_t m = (uint64_t)a * b;
+        if (m < need) continue;
+        if (best == 0 || m < best || (m == best && a < l1)) { best = m; l1 = a; l2 = b; }
+        break;  // larger b only grows m
+      }
+    return best;
+  }
+  BluTiledEngine(size_t n_user, uint32_t l1, uint32_t l2) : n_(n_user), m_((uint64_t)l1 * l2), l1_(l1), l2_(l2) {
+    k_in_ = get_regtile_kernel(Real<T>{}, l1, 1);
+    k_conv_ = get_regtile_kernel(Real<T>{}, l2, 2);
+    k_out_ = get_regtile_kernel(Real<T>{}, l1, 3);
+    if (!k_in_.fn || !k_conv_.fn || !k_out_.fn) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "no register-tile Bluestein kernels of these lengths");
+    for (const TiledKernel* k : {&k_in_, &k_conv_, &k_out_}) raise_smem_limit((const void*)k->fn, k->smem);
+    tw1_.upload(stage_table(k_in_));
+    tw2_.upload(stage_table(k_conv_));
+    const int lb = (ilog2(m_) + 1) / 2;  // W_M^{i * k}, two-level (first forward pass and first inverse pass)
+    lo_bits_ = (uint32_t)lb;
+    std::vector<cpx<T>> lo((size_t)1 << lb), hi((size_t)(m_ >> lb) + 1);
+    for (size_t e = 0; e < lo.size(); ++e) { double re, im; unit_root(e, m_, re, im); lo[e] = {(T)re, (T)im}; }
+    for (size_t h = 0; h < hi.size(); ++h) { double re, im; unit_root((uint64_t)h << lb, m_, re, im); hi[h] = {(T)re, (T)im}; }
+    tw_lo_.upload(lo); tw_hi_.upload(hi);
+    const uint64_t e = sizeof(cpx<T>);
+    chunk_in_ = ((n_ * e) % 128 != 0 || (l2_ * e) % 128 != 0) ? FOURIER_TILE_CHUNK : FOURIER_TILE_CHUNK_ALIGNED;
+    chunk_conv_ = ((m_ * e) % 128 != 0 || (l1_ * e) % 128 != 0) ? FOURIER_TILE_CHUNK : FOURIER_TILE_CHUNK_ALIGNED;
+    chunk_out_ = ((n_ * e) % 128 != 0 || (l2_ * e) % 128 != 0) ? FOURIER_TILE_CHUNK : FOURIER_TILE_CHUNK_ALIGNED;
+  }
+  uint64_t m() const { return m_; }
+  std::string describe() const { return "mixed tiles " + std::to_string(l1_) + "x" + std::to_string(l2_); }
+  // in: user array (n per transform), out: user array; work, scratch: m per transform each.  in == out is fine: the user array is read
+  // completely by the first launch and written by the last.
+  void run(const cpx<T>* in, cpx<T>* out, cpx<T>* work, cpx<T>* scratch, size_t batch, const void* xtab, const void* wtab, bool inverse,
+           double scale, hipStream_t stream, Profiler* prof) const {
+    if (batch == 0) return;
+    TiledArgs a;
+    auto base = [&]() {
+      std::memset(&a, 0, sizeof(a));
+      a.tw_lo = tw_lo_.p; a.tw_hi = tw_hi_.p; a.lo_bits = lo_bits_;
+      a.n = m_; a.scale = 1.0;
+      a.blu_x = xtab; a.blu_w = wtab; a.blu_n = n_; a.blu_swap = inverse ? 1 : 0;
+    };
+    auto launch = [&](const TiledKernel& k, uint64_t tiles, int slot) {
+      const uint64_t grid = (uint64_t)batch * tiles;
+      if (grid > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");
+      PROF_BEGIN(prof, slot);
+      FOURIER_LAUNCH(k.fn, grid, k.threads, k.smem, stream, a);
+      PROF_END(prof);
+    };
+    // chirp-in: first pass of the forward transform, length L1 at s = 1, m = L2 columns
+    base();
+    a.in = in; a.out = work; a.tw = tw1_.p; a.s = 1; a.m = l2_;
+    a.tiles_per_row = (l2_ + k_in_.cols - 1) / k_in_.cols; a.xcd_chunk = chunk_in_;
+    launch(k_in_, a.tiles_per_row, 0);
+    // conv: last forward pass (length L2 at s = L1), (.) w, first inverse pass (length L2, m = L1)
+    base();
+    a.in = work; a.out = scratch; a.tw = tw2_.p; a.s = l1_; a.m = 1;
+    a.tiles_per_row = (l1_ + k_conv_.cols - 1) / k_conv_.cols; a.xcd_chunk = chunk_conv_;
+    launch(k_conv_, a.tiles_per_row, 1);
+    // chirp-out: last pass of the inverse transform, length L1 at s = L2
+    base();
+    a.in = scratch; a.out = out; a.tw = tw1_.p; a.s = l2_; a.m = 1; a.swap_out = 1; a.scale = scale;
+    a.tiles_per_row = (l2_ + k_out_.cols - 1) / k_out_.cols; a.xcd_chunk = chunk_out_;
+    launch(k_out_, a.tiles_per_row, 2);
+  }
+
+ private:
+  static std::vector<cpx<T>> stage_table(const TiledKernel& k) {  // W_L^{j2 * k1} as [k1 < r1][j2 < r2]
+    std::vector<cpx<T>> tw;
+    for (size_t k1 = 0; k1 < k.r1; ++k1)
+      for (size_t j2 = 0; j2 < k.r2; ++j2) {
+        double re, im;
+        unit_root(j2 * k1, k.L, re, im);
+        tw.push_back({(T)re, (T)im});
+      }
+    return tw;
+  }
+  size_t n_;
+  uint64_t m_;
+  uint32_t l1_, l2_, lo_bits_ = 0, chunk_in_ = 0, chunk_conv_ = 0, chunk_out_ = 0;
+  TiledKernel k_in_, k_conv_, k_out_;
+  DevBuf tw1_, tw2_, tw_lo_, tw_hi_;
+};
+
 }  // namespace fourier_hip

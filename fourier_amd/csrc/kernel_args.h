@@ -120,6 +120,11 @@ struct TiledArgs {
   uint32_t xcd_chunk;         // workgroup -> tile order (xcd_chunked, kernels_common.h): 0 = identity
   double scale;               // applied by the last pass
   double w3re, w3im, w8re, w8im;  // compute_twiddle(1, 3, true), compute_twiddle(1, 8, true) as T values (butterfly.rs:12,50)
+  // Bluestein on smooth M (kernels_regtile.h): chirp table x (blu_n entries), w = FFT_M(conj chirp) / M (n entries), user length,
+  // user-level inverse (swap at the user array)
+  const void* blu_x; const void* blu_w;
+  uint64_t blu_n;
+  int blu_swap;
 };
 
 // ---- XCD-fused one-launch plan (kernels_experiments.h)

@@ -9,11 +9,13 @@ namespace fourier_hip {
 
 typedef FOURIER_TU_REAL TUReal;
 
-template <typename T, uint32_t L> static TiledKernel make_regtile() {
+// which: 0 = the plain pass, 1 / 2 / 3 = the Bluestein sweeps on a smooth M (chirp-in first pass, conv, chirp-out last pass)
+template <typename T, uint32_t L> static TiledKernel make_regtile(int which) {
   if constexpr (reg_tile_shape(L, (uint32_t)sizeof(cpx<T>)).r1 != 0) {
     using C = RegTileCfg<T, L>;
     TiledKernel k;
-    k.fn = &tiled_reg_kernel<T, L>;
+    k.fn = which == 1 ? &tiled_reg_kernel<T, L, IO_BLU_IN> : which == 2 ? &tiled_reg_conv_kernel<T, L> : which == 3 ? &tiled_reg_kernel<T, L, IO_BLU_OUT>
+                                                                                                                 : &tiled_reg_kernel<T, L, IO_PLAIN>;
     k.L = L; k.cols = C::COLS; k.threads = C::NT; k.smem = C::SMEM; k.r1 = C::R1; k.r2 = C::R2;
     return k;
   } else {
@@ -21,9 +23,9 @@ template <typename T, uint32_t L> static TiledKernel make_regtile() {
   }
 }
 
-#define FOURIER_TILED(LL) case LL: return make_regtile<T, LL>();
+#define FOURIER_TILED(LL) case LL: return make_regtile<T, LL>(which);
 #if FOURIER_TILED_SHARD == 0
-TiledKernel get_regtile_kernel_s0(Real<TUReal>, uint32_t L) {
+TiledKernel get_regtile_kernel_s0(Real<TUReal>, uint32_t L, int which) {
   typedef TUReal T;
   switch (L) {
     FOURIER_TILED(64) FOURIER_TILED(72) FOURIER_TILED(81) FOURIER_TILED(96) FOURIER_TILED(108) FOURIER_TILED(128)
@@ -32,14 +34,14 @@ TiledKernel get_regtile_kernel_s0(Real<TUReal>, uint32_t L) {
     default: return TiledKernel();
   }
 }
-TiledKernel get_regtile_kernel(Real<TUReal>, uint32_t L) {
-  for (TiledKernel k : {get_regtile_kernel_s0(Real<TUReal>{}, L), get_regtile_kernel_s1(Real<TUReal>{}, L), get_regtile_kernel_s2(Real<TUReal>{}, L),
-                        get_regtile_kernel_s3(Real<TUReal>{}, L)})
+TiledKernel get_regtile_kernel(Real<TUReal>, uint32_t L, int which) {
+  for (TiledKernel k : {get_regtile_kernel_s0(Real<TUReal>{}, L, which), get_regtile_kernel_s1(Real<TUReal>{}, L, which),
+                        get_regtile_kernel_s2(Real<TUReal>{}, L, which), get_regtile_kernel_s3(Real<TUReal>{}, L, which)})
     if (k.fn) return k;
   return TiledKernel();
 }
 #elif FOURIER_TILED_SHARD == 1
-TiledKernel get_regtile_kernel_s1(Real<TUReal>, uint32_t L) {
+TiledKernel get_regtile_kernel_s1(Real<TUReal>, uint32_t L, int which) {
   typedef TUReal T;
   switch (L) {
     FOURIER_TILED(70) FOURIER_TILED(75) FOURIER_TILED(80) FOURIER_TILED(84) FOURIER_TILED(90) FOURIER_TILED(98) FOURIER_TILED(100)
@@ -50,7 +52,7 @@ TiledKernel get_regtile_kernel_s1(Real<TUReal>, uint32_t L) {
   }
 }
 #elif FOURIER_TILED_SHARD == 2
-TiledKernel get_regtile_kernel_s2(Real<TUReal>, uint32_t L) {
+TiledKernel get_regtile_kernel_s2(Real<TUReal>, uint32_t L, int which) {
   typedef TUReal T;
   switch (L) {
     FOURIER_TILED(240) FOURIER_TILED(245) FOURIER_TILED(250) FOURIER_TILED(252) FOURIER_TILED(270) FOURIER_TILED(280) FOURIER_TILED(294)
@@ -59,7 +61,7 @@ TiledKernel get_regtile_kernel_s2(Real<TUReal>, uint32_t L) {
   }
 }
 #else
-TiledKernel get_regtile_kernel_s3(Real<TUReal>, uint32_t L) {
+TiledKernel get_regtile_kernel_s3(Real<TUReal>, uint32_t L, int which) {
   typedef TUReal T;
   switch (L) {
     FOURIER_TILED(375) FOURIER_TILED(378) FOURIER_TILED(392) FOURIER_TILED(400) FOURIER_TILED(405) FOURIER_TILED(420) FOURIER_TILED(441)

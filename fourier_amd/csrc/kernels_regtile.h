@@ -13,6 +13,12 @@
 // barrier each, their index arithmetic per butterfly): 3.6 - 4.2 TB/s per pass against 5.9 for the power-of-two tiles, VALU and LDS
 // instructions per byte 2.7 x / 3.2 x theirs (profiles/r06_s20_sq_tiled.json).  Here: one LDS round trip (two in the first pass), every
 // index a compile-time constant.  Tolerance-only route like every tile pass of mixed length (include/fourier.h).
+//
+// Bluestein with a SMOOTH M = L1 x L2 (bluesteins.rs:110 asks for M >= 2N - 1 only; the reference takes the next power of two, up to
+// 4N): the three sweeps of kernels_pass.h on these tiles -- tiled_reg_kernel<IO_BLU_IN> (first forward pass of length L1, reads the user
+// array times the chirp, zero padded: bluesteins.rs:229-234), tiled_reg_conv_kernel (last forward pass of length L2, (.) w, first inverse
+// pass of length L2 in one launch: bluesteins.rs:236-239) and tiled_reg_kernel<IO_BLU_OUT> (last inverse pass of length L1, times chirp
+// and scale, the first N points into the user array: bluesteins.rs:240-258).
 #pragma once
 #include "kernels_mixed.h"
 
@@ -147,7 +153,62 @@ template <typename T, uint32_t L> struct RegTileCfg {  // the rules: reg_tile_sh
   static constexpr size_t TAB_OFF = S.tab_off, SMEM = S.smem;
 };
 
-template <typename T, uint32_t L>
+// the two halves of an inter-pass twiddle table build (W_size^{i * k} from the two-level tables, k = r for r < RA, RA * (r - RA) beyond): the
+// global loads first, the products and LDS writes once the data loads are under way
+template <typename T, uint32_t RA, uint32_t RB, uint32_t COLS, uint32_t NT> struct RegTileTabs {
+  static constexpr uint32_t TITER = (COLS * (RA + RB) + NT - 1) / NT;
+  cpx<T> tlo[TITER], thi[TITER];
+  __device__ __forceinline__ void load(const TiledArgs& a, uint32_t tid, uint32_t tcols, bool per_column, uint32_t c0, uint32_t ncols_total, uint32_t i_row) {
+    const cpx<T>* lo = (const cpx<T>*)a.tw_lo;
+    const cpx<T>* hi = (const cpx<T>*)a.tw_hi;
+    const uint32_t mask = (1u << a.lo_bits) - 1u;
+#pragma unroll
+    for (uint32_t it = 0; it < TITER; ++it) {
+      const uint32_t e = tid + it * NT;
+      if (e < tcols * (RA + RB)) {
+        const uint32_t tc = e / (RA + RB), r = e - tc * (RA + RB);
+        // (a masked column of a ragged last tile takes the last valid column's entries: its own index would reach past the tables)
+        const uint64_t i = per_column ? (uint64_t)(c0 + tc < ncols_total ? c0 + tc : ncols_total - 1u) : (uint64_t)i_row;
+        const uint64_t ex = i * (uint64_t)(r < RA ? r : RA * (r - RA));  // i * k < size
+        tlo[it] = lo[ex & mask];
+        thi[it] = hi[ex >> a.lo_bits];
+      }
+    }
+  }
+  __device__ __forceinline__ void store(uint32_t tid, uint32_t tcols, cpx<T>* tu, cpx<T>* tv) const {
+#pragma unroll
+    for (uint32_t it = 0; it < TITER; ++it) {
+      const uint32_t e = tid + it * NT;
+      if (e < tcols * (RA + RB)) {
+        const uint32_t tc = e / (RA + RB), r = e - tc * (RA + RB);
+        const cpx<T> v = cmul(tlo[it], thi[it]);
+        if (r < RA) tu[tc * RA + r] = v; else tv[tc * RB + (r - RA)] = v;
+      }
+    }
+  }
+};
+// a first pass's output: the tile's ncols * L elements, staged as [c][k] at c * LDO + k, are ONE contiguous run of global memory
+template <typename T, uint32_t L, uint32_t COLS, uint32_t NT, uint32_t LDO>
+__device__ __forceinline__ void reg_tile_copy_out(const cpx<T>* buf, cpx<T>* o, uint32_t ncols, uint32_t tid) {
+  // one element per lane and instruction (f32: 8 bytes -- a wave still writes 512 contiguous bytes, and the LDS reads are at stride 1:
+  // pairs of elements per lane read two 8-byte words at a 16-byte stride, a 2-way bank conflict, SQ_LDS_BANK_CONFLICT 41 % at L = 400)
+  const uint32_t total = ncols * L;
+  constexpr uint32_t OITER = (L * COLS + NT - 1) / NT;
+  cpx<T> v[OITER];
+#pragma unroll
+  for (uint32_t it = 0; it < OITER; ++it) {
+    const uint32_t idx = tid + it * NT, idc = idx < total ? idx : 0u, cc = idc / L, k = idc - cc * L;  // (clamped: no branch around the read)
+    LDS_NOTE(buf + cc * LDO + k, sizeof(cpx<T>), false, 303);
+    v[it] = buf[cc * LDO + k];
+  }
+#pragma unroll
+  for (uint32_t it = 0; it < OITER; ++it) {
+    const uint32_t idx = tid + it * NT;
+    if (idx < total) store_cpx(o + idx, v[it]);
+  }
+}
+
+template <typename T, uint32_t L, int IO = IO_PLAIN>
 __global__ void __launch_bounds__((RegTileCfg<T, L>::NT)) tiled_reg_kernel(TiledArgs a) {
   using C = RegTileCfg<T, L>;
   constexpr uint32_t R1 = C::R1, R2 = C::R2, COLS = C::COLS, NT = C::NT, XS = C::XS, LDO = C::LDO;
@@ -167,8 +228,9 @@ __global__ void __launch_bounds__((RegTileCfg<T, L>::NT)) tiled_reg_kernel(Tiled
   const uint32_t i_row = rem / tiles_per_row, c0 = (rem - i_row * tiles_per_row) * COLS;
   const uint32_t ncols_total = first ? (uint32_t)a.m : (uint32_t)a.s;
   const uint32_t ncols = ncols_total - c0 < COLS ? ncols_total - c0 : COLS;
-  const cpx<T>* __restrict__ in = (const cpx<T>*)a.in + (uint64_t)b * a.n;
-  cpx<T>* __restrict__ out = (cpx<T>*)a.out + (uint64_t)b * a.n;
+  // (the Bluestein end passes: the user array holds blu_n points per transform, the work array n = M)
+  const cpx<T>* __restrict__ in = (const cpx<T>*)a.in + (uint64_t)b * (IO == IO_BLU_IN ? a.blu_n : a.n);
+  cpx<T>* __restrict__ out = (cpx<T>*)a.out + (uint64_t)b * (IO == IO_BLU_OUT ? a.blu_n : a.n);
   const uint64_t row_stride = a.s * a.m;
   const uint64_t col0 = first ? (uint64_t)c0 : (uint64_t)c0 + a.s * (uint64_t)i_row;
   const bool twiddled = a.m > 1;
@@ -178,9 +240,30 @@ __global__ void __launch_bounds__((RegTileCfg<T, L>::NT)) tiled_reg_kernel(Tiled
   // of the thread ahead of its first use
   cpx<T> x[R1];
   if (q < R2) {
-    const cpx<T>* p = in + col0 + (live ? c : 0u) + row_stride * (uint64_t)q;  // (a column past a ragged tile reads column 0: never stored)
+    if constexpr (IO == IO_BLU_IN) {
+      // work = x (.) in, zero padded (bluesteins.rs:229-234): element e = column + m * row of the user array and of the chirp table, zero
+      // from blu_n on (more than half of the rows: 2N <= M + 1) -- those loads are never issued
+      cpx<T> ch[R1];
+      const uint64_t e0 = col0 + (live ? c : 0u) + row_stride * (uint64_t)q;
 #pragma unroll
-    for (uint32_t j1 = 0; j1 < R1; ++j1) x[j1] = load_cpx(p + row_stride * (uint64_t)(R2 * j1));
+      for (uint32_t j1 = 0; j1 < R1; ++j1) {
+        const uint64_t e = e0 + row_stride * (uint64_t)(R2 * j1);
+        const bool valid = e < a.blu_n;
+        const uint64_t ec = valid ? e : 0u;
+        x[j1] = load_cpx(in + ec);
+        ch[j1] = load_cpx((const cpx<T>*)a.blu_x + ec);
+        if (!valid) x[j1] = cpx<T>{(T)0, (T)0};
+      }
+#pragma unroll
+      for (uint32_t j1 = 0; j1 < R1; ++j1) {
+        if (a.blu_swap) x[j1] = {x[j1].im, x[j1].re};
+        x[j1] = cmul(ch[j1], x[j1]);
+      }
+    } else {
+      const cpx<T>* p = in + col0 + (live ? c : 0u) + row_stride * (uint64_t)q;  // (a column past a ragged tile reads column 0: never stored)
+#pragma unroll
+      for (uint32_t j1 = 0; j1 < R1; ++j1) x[j1] = load_cpx(p + row_stride * (uint64_t)(R2 * j1));
+    }
   }
   // the twiddle between the stages, W_L^{j2 * k1}, applied on the side with fewer values per thread (stage B: R2 <= R1), loaded with the
   // data (issued before the barrier instead, its latency is exposed in every tile: f64 -25 %, profiles/r06_s23_regtile_remap_ab.jsonl)
@@ -190,26 +273,9 @@ __global__ void __launch_bounds__((RegTileCfg<T, L>::NT)) tiled_reg_kernel(Tiled
 #pragma unroll
     for (uint32_t j2 = 1; j2 < R2; ++j2) w[j2] = tw[j2];
   }
-  constexpr uint32_t TENT = COLS * (R1 + R2), TITER = (TENT + NT - 1) / NT;
-  cpx<T> tlo[TITER], thi[TITER];
+  RegTileTabs<T, R1, R2, COLS, NT> tabs;
   const uint32_t tcols = first ? COLS : 1u;  // the later passes have one i for the whole tile: table column 0
-  if (twiddled) {
-    const cpx<T>* lo = (const cpx<T>*)a.tw_lo;
-    const cpx<T>* hi = (const cpx<T>*)a.tw_hi;
-    const uint32_t mask = (1u << a.lo_bits) - 1u;
-#pragma unroll
-    for (uint32_t it = 0; it < TITER; ++it) {
-      const uint32_t e = tid + it * NT;
-      if (e < tcols * (R1 + R2)) {
-        const uint32_t tc = e / (R1 + R2), r = e - tc * (R1 + R2);
-        // (a masked column of a ragged last tile takes the last valid column's entries: its own index would reach past the tables)
-        const uint64_t i = first ? (uint64_t)(c0 + tc < ncols_total ? c0 + tc : ncols_total - 1u) : (uint64_t)i_row;
-        const uint64_t ex = i * (uint64_t)(r < R1 ? r : R1 * (r - R1));  // i * k < size
-        tlo[it] = lo[ex & mask];
-        thi[it] = hi[ex >> a.lo_bits];
-      }
-    }
-  }
+  if (twiddled) tabs.load(a, tid, tcols, first, c0, ncols_total, i_row);
   if (q < R2) {
     if (a.swap_in) {
 #pragma unroll
@@ -223,17 +289,7 @@ __global__ void __launch_bounds__((RegTileCfg<T, L>::NT)) tiled_reg_kernel(Tiled
       *d = x[k1];
     }
   }
-  if (twiddled) {
-#pragma unroll
-    for (uint32_t it = 0; it < TITER; ++it) {
-      const uint32_t e = tid + it * NT;
-      if (e < tcols * (R1 + R2)) {
-        const uint32_t tc = e / (R1 + R2), r = e - tc * (R1 + R2);
-        const cpx<T> v = cmul(tlo[it], thi[it]);
-        if (r < R1) tu[tc * R1 + r] = v; else tv[tc * R2 + (r - R1)] = v;
-      }
-    }
-  }
+  if (twiddled) tabs.store(tid, tcols, tu, tv);
   __syncthreads();
 
   // ---- stage B: the R2 values of (column c, k1 = q); output k = k1 + R1*k2
@@ -260,6 +316,27 @@ __global__ void __launch_bounds__((RegTileCfg<T, L>::NT)) tiled_reg_kernel(Tiled
       }
     }
   }
+  if constexpr (IO == IO_BLU_OUT) {
+    // out = work (.) x (.) scale, the first blu_n points only (bluesteins.rs:240-258); the last pass: i = 0, element e = j + s * k.
+    // (y was swapped and scaled above: the inverse inner transform's trailing swap; the user-level inverse swaps once more)
+    if (q < R1 && live) {
+      const uint64_t e0 = (uint64_t)c0 + c + a.s * (uint64_t)q;
+      cpx<T> ch[R2];
+#pragma unroll
+      for (uint32_t k2 = 0; k2 < R2; ++k2) {
+        const uint64_t e = e0 + a.s * (uint64_t)(R1 * k2);
+        ch[k2] = load_cpx((const cpx<T>*)a.blu_x + (e < a.blu_n ? e : 0u));
+      }
+#pragma unroll
+      for (uint32_t k2 = 0; k2 < R2; ++k2) {
+        const uint64_t e = e0 + a.s * (uint64_t)(R1 * k2);
+        cpx<T> z = cmul(y[k2], ch[k2]);
+        if (a.blu_swap) z = {z.im, z.re};
+        if (e < a.blu_n) store_cpx(out + e, z);
+      }
+    }
+    return;
+  }
   if (!first) {
     // out[j + L*s*i + s*k]: 128-byte row segments, row k at stride s
     if (q < R1 && live) {
@@ -280,25 +357,121 @@ __global__ void __launch_bounds__((RegTileCfg<T, L>::NT)) tiled_reg_kernel(Tiled
     }
   }
   __syncthreads();
-  {
-    // one element per lane and instruction (f32: 8 bytes -- a wave still writes 512 contiguous bytes, and the LDS reads are at stride 1:
-    // pairs of elements per lane read two 8-byte words at a 16-byte stride, a 2-way bank conflict, SQ_LDS_BANK_CONFLICT 41 % at L = 400)
-    cpx<T>* o = out + (uint64_t)L * c0;
-    const uint32_t total = ncols * L;
-    constexpr uint32_t OITER = (L * COLS + NT - 1) / NT;
-    cpx<T> v[OITER];
+  reg_tile_copy_out<T, L, COLS, NT, LDO>(buf, out + (uint64_t)L * c0, ncols, tid);
+}
+
+// Bluestein middle sweep on a smooth M = L1 x L: the LAST pass of the forward inner transform (length L, stride s = M / L, no twiddle:
+// mod.rs:238), the pointwise product with w (bluesteins.rs:236-238) and the FIRST pass of the inverse inner transform (length L again, m = s:
+// it reads element (column j, row k) exactly where the forward pass put it) in one launch -- the tile never leaves the CU in between.
+// The second transform runs the split the other way round (its input index k = k1 + R1 * k2 IS what stage B's threads hold): stage A' =
+// DFT_R2 on stage B's threads, exchange, stage B' = DFT_R1 on stage A's threads, output k'' = k1'' + R2 * k2''; the twiddle between its
+// stages, W_L^{k1 * k1''}, is the first transform's table again.  Inverse = swap . DFT . swap: the swap after the product here, the
+// trailing one in the chirp-out pass.
+template <typename T, uint32_t L>
+__global__ void __launch_bounds__((RegTileCfg<T, L>::NT)) tiled_reg_conv_kernel(TiledArgs a) {
+  using C = RegTileCfg<T, L>;
+  constexpr uint32_t R1 = C::R1, R2 = C::R2, COLS = C::COLS, NT = C::NT, XS = C::XS, LDO = C::LDO;
+  constexpr uint32_t XS2 = R1 * COLS;  // second exchange: [k1''][k1][c] at k1'' * XS2 + reg_tile_row(R1, k1'', k1) * COLS + c
+  FOURIER_DYN_SMEM(smem);
+  cpx<T>* buf = (cpx<T>*)smem;
+  cpx<T>* tu = (cpx<T>*)(smem + C::TAB_OFF);  // [COLS][R2]: W_M^{i * k1''}
+  cpx<T>* tv = tu + COLS * R2;                // [COLS][R1]: W_M^{i * R2 * k2''}
+  const uint32_t tid = threadIdx.x;
+  const uint32_t c = tid % COLS, q = tid / COLS;
+  const uint32_t tiles_per_row = (uint32_t)a.tiles_per_row;  // ceil(s / COLS)
+  const uint32_t blk = xcd_chunked(blockIdx.x, gridDim.x, a.xcd_chunk);
+  const uint32_t b = blk / tiles_per_row, c0 = (blk - b * tiles_per_row) * COLS;
+  const uint32_t ncols_total = (uint32_t)a.s;
+  const uint32_t ncols = ncols_total - c0 < COLS ? ncols_total - c0 : COLS;
+  const cpx<T>* __restrict__ in = (const cpx<T>*)a.in + (uint64_t)b * a.n;
+  cpx<T>* __restrict__ out = (cpx<T>*)a.out + (uint64_t)b * a.n;
+  const bool live = c < ncols;
+  const uint32_t cl = live ? c : 0u;  // (a column past a ragged tile reads column 0: never stored)
+
+  // ---- forward last pass, stage A: rows j2 + R2*j1 of column c; then every other global load of the thread
+  cpx<T> x[R1];
+  if (q < R2) {
+    const cpx<T>* p = in + c0 + cl + a.s * (uint64_t)q;
 #pragma unroll
-    for (uint32_t it = 0; it < OITER; ++it) {
-      const uint32_t idx = tid + it * NT, idc = idx < total ? idx : 0u, cc = idc / L, k = idc - cc * L;  // (clamped: no branch around the read)
-      LDS_NOTE(buf + cc * LDO + k, sizeof(cpx<T>), false, 303);
-      v[it] = buf[cc * LDO + k];
-    }
+    for (uint32_t j1 = 0; j1 < R1; ++j1) x[j1] = load_cpx(p + a.s * (uint64_t)(R2 * j1));
+  }
+  cpx<T> w[R2], ww[R2];  // W_L^{k1 * j2} (both transforms); w[j + s * k] at the thread's outputs k = q + R1 * k2
+  if (q < R1) {
+    const cpx<T>* tw = (const cpx<T>*)a.tw + q * R2;
 #pragma unroll
-    for (uint32_t it = 0; it < OITER; ++it) {
-      const uint32_t idx = tid + it * NT;
-      if (idx < total) store_cpx(o + idx, v[it]);
+    for (uint32_t j2 = 1; j2 < R2; ++j2) w[j2] = tw[j2];
+    const cpx<T>* pw = (const cpx<T>*)a.blu_w + c0 + cl + a.s * (uint64_t)q;
+#pragma unroll
+    for (uint32_t k2 = 0; k2 < R2; ++k2) ww[k2] = load_cpx(pw + a.s * (uint64_t)(R1 * k2));
+  }
+  RegTileTabs<T, R2, R1, COLS, NT> tabs;  // the inverse first pass: i = c0 + column, output k'' = k1'' + R2 * k2''
+  tabs.load(a, tid, COLS, true, c0, ncols_total, 0u);
+  if (q < R2) {
+    dft_any<T, (int)R1>(x);
+#pragma unroll
+    for (uint32_t k1 = 0; k1 < R1; ++k1) {
+      cpx<T>* d = buf + k1 * XS + reg_tile_row(R2, k1, q) * COLS + c;
+      LDS_NOTE(d, sizeof(cpx<T>), true, 310);
+      *d = x[k1];
     }
   }
+  tabs.store(tid, COLS, tu, tv);
+  __syncthreads();
+
+  // ---- stage B, (.) w, swap; stage A' of the inverse first pass on the same threads
+  cpx<T> y[R2];
+  if (q < R1) {
+#pragma unroll
+    for (uint32_t j2 = 0; j2 < R2; ++j2) {
+      const cpx<T>* s = buf + q * XS + reg_tile_row(R2, q, j2) * COLS + c;
+      LDS_NOTE(s, sizeof(cpx<T>), false, 311);
+      y[j2] = j2 == 0 ? *s : cmul(*s, w[j2]);
+    }
+    dft_any<T, (int)R2>(y);  // y[k2] = Y[q + R1 * k2]
+#pragma unroll
+    for (uint32_t k2 = 0; k2 < R2; ++k2) {
+      const cpx<T> z = cmul(y[k2], ww[k2]);
+      y[k2] = {z.im, z.re};
+    }
+    dft_any<T, (int)R2>(y);  // over k2: y[k1''], k1'' < R2
+#pragma unroll
+    for (uint32_t k = 1; k < R2; ++k) y[k] = cmul(y[k], w[k]);  // W_L^{q * k1''}
+  }
+  __syncthreads();  // every thread has read its stage-B inputs
+  if (q < R1) {
+#pragma unroll
+    for (uint32_t k = 0; k < R2; ++k) {
+      cpx<T>* d = buf + k * XS2 + reg_tile_row(R1, k, q) * COLS + c;
+      LDS_NOTE(d, sizeof(cpx<T>), true, 312);
+      *d = y[k];
+    }
+  }
+  __syncthreads();
+  // ---- stage B' (column c, k1'' = q < R2): the R1 values over k1, DFT_R1, the inter-pass twiddle W_M^{i * (k1'' + R2 * k2'')}
+  cpx<T> v[R1];
+  if (q < R2) {
+#pragma unroll
+    for (uint32_t j = 0; j < R1; ++j) {
+      const cpx<T>* s = buf + q * XS2 + reg_tile_row(R1, q, j) * COLS + c;
+      LDS_NOTE(s, sizeof(cpx<T>), false, 313);
+      v[j] = *s;
+    }
+    dft_any<T, (int)R1>(v);
+    const cpx<T> u = tu[c * R2 + q];
+#pragma unroll
+    for (uint32_t k2 = 0; k2 < R1; ++k2) v[k2] = cmul(v[k2], k2 == 0 ? u : cmul(u, tv[c * R1 + k2]));
+  }
+  __syncthreads();
+  if (q < R2) {
+#pragma unroll
+    for (uint32_t k2 = 0; k2 < R1; ++k2) {
+      cpx<T>* d = buf + c * LDO + q + R2 * k2;
+      LDS_NOTE(d, sizeof(cpx<T>), true, 314);
+      *d = v[k2];
+    }
+  }
+  __syncthreads();
+  reg_tile_copy_out<T, L, COLS, NT, LDO>(buf, out + (uint64_t)L * c0, ncols, tid);
 }
 
 }  // namespace fourier_hip

@@ -33,6 +33,40 @@ static inline void host_fft(std::vector<double>& re, std::vector<double>& im) {
   }
 }
 
+// ... and for any length whose prime factors are small (Bluestein on a smooth M): one Stockham pass per prime factor,
+// out[j + s*(p*i + k)] = W_cur^{i*k} sum_r W_p^{r*k} in[j + s*(i + (cur/p)*r)]   (mod.rs:203-284 with plain O(p^2) butterflies)
+static inline void host_fft_any(std::vector<double>& re, std::vector<double>& im) {
+  const size_t m = re.size();
+  if (is_pow2(m)) { host_fft(re, im); return; }
+  std::vector<double> ore(m), oim(m);
+  size_t cur = m, s = 1;
+  while (cur > 1) {
+    size_t p = 2;
+    while (cur % p) ++p;
+    const size_t mm = cur / p;
+    std::vector<double> wr(p * p), wi(p * p);
+    for (size_t e = 0; e < p * p; ++e) unit_root(e % p, p, wr[e], wi[e]);  // W_p^{r*k} at [r * p + k] via (r*k) % p below
+    for (size_t i = 0; i < mm; ++i) {
+      std::vector<double> tr(p), ti(p);
+      for (size_t k = 0; k < p; ++k) unit_root(i * k, cur, tr[k], ti[k]);
+      for (size_t j = 0; j < s; ++j) {
+        double xr[16], xi[16];
+        for (size_t r = 0; r < p; ++r) { xr[r] = re[j + s * (i + mm * r)]; xi[r] = im[j + s * (i + mm * r)]; }
+        for (size_t k = 0; k < p; ++k) {
+          double yr = 0, yi = 0;
+          for (size_t r = 0; r < p; ++r) {
+            const size_t e = (r * k) % p;
+            yr += xr[r] * wr[e] - xi[r] * wi[e]; yi += xr[r] * wi[e] + xi[r] * wr[e];
+          }
+          ore[j + s * (p * i + k)] = yr * tr[k] - yi * ti[k]; oim[j + s * (p * i + k)] = yr * ti[k] + yi * tr[k];
+        }
+      }
+    }
+    re.swap(ore); im.swap(oim);
+    s *= p; cur = mm;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 template <typename T> class Plan {
  public:
@@ -133,6 +167,7 @@ template <typename T> class Plan {
     if (mix_) desc_ = "stockham mixed-radix " + mix_->describe();
     else if (tiled_) desc_ = "stockham mixed tiles " + tiled_->describe();
     else if (gen_) desc_ = "stockham global-pass " + gen_->describe();
+    else if (blut_) desc_ = "bluestein M=" + std::to_string(m_) + " inner " + blut_->describe();
     else if (blu_) desc_ = "bluestein M=" + std::to_string(m_) + " inner " + eng_->describe() + (small_fused_ ? " fused" : "");
     else desc_ = "stockham " + eng_->describe();
     desc_ += sizeof(T) == 4 ? " f32" : " f64";
@@ -162,6 +197,7 @@ template <typename T> class Plan {
     auto passes = [&](const char* tag) {
       for (size_t p = 0; p < (blu_ ? eng_->num_passes() : eng_->hbm_round_trips()); ++p) d += std::string(d.empty() ? "" : ",") + tag + std::to_string(p);
     };
+    if (blut_) return "chirp_in_pass,conv_pass,chirp_out_pass";
     if (!blu_) { passes("pass"); return d; }
     if (small_fused_) return "bluestein_one_launch";
     d = "blu_pre"; passes("fwd_pass"); passes("inv_pass"); d += ",blu_post";  // blu_pre/post stay empty when fused
@@ -179,6 +215,7 @@ template <typename T> class Plan {
     if (!blu_) return 2.0 * n_ * ELEM * eng_->hbm_round_trips();
     // unfused: pre (n + table read, m write) + 2 inner FFTs + w table + post (n + table read, n write);
     // fused: the first / last inner pass read / write the n-point user array instead of an m-point sweep
+    if (blut_) return (double)ELEM * (5.0 * m_ + 4.0 * n_);  // (n + n, m) + (m + m, m) + (m + n, n)
     if (small_fused_) return (double)ELEM * 2.0 * n_;  // tables stay L2-resident
     const double chirp_reads = (chirp_compute_ ? 1.0 : 2.0) * n_;  // the n-entry chirp table: the chirp-out pass reads it, the chirp-in pass only without bluestein_chirp_compute
     if (fused_ && conv_) return (double)ELEM * (2.0 * m_ * (2.0 * eng_->num_passes() - 1.0) - 2.0 * (m_ - n_) + m_ + chirp_reads);
@@ -204,7 +241,22 @@ template <typename T> class Plan {
       nxcd_ = band == 0 ? 8u : (8u | (4u << 8) | (band << 12) | (group << 20) | (tf << 30));
       return 0;
     }
+    // Bluestein's M: 1 (default) = the smallest product of two tile lengths where that saves a quarter of the power-of-two work array,
+    // 0 = always the reference's next power of two (bluesteins.rs:110).  Rebuilds the plan's tables now; not while a transform is in flight.
+    if (key == "bluestein_smooth_m" && (v == 0 || v == 1)) {
+      if (!blu_) return ::fourier::c::FOURIER_HIP_INVALID_ARGUMENT;
+      if ((v == 1) != smooth_m_allowed_) {
+        HIP_CHECK(hipDeviceSynchronize());
+        smooth_m_allowed_ = (v == 1);
+        blut_.reset(); eng_.reset(); eng_inv_.reset();
+        init_bluestein();
+        if (reference_chirp_) { build_chirp_tables(true); chirp_compute_saved_ = chirp_compute_; chirp_compute_ = false; }
+        refresh_desc();
+      }
+      return 0;
+    }
     if (key == "bluestein_fusion" && (v == 0 || v == 1)) {
+      if (blut_) return 0;  // the smooth-M route has no unfused form
       fused_ = (v == 1) && blu_ && eng_->can_fuse_bluestein();
       small_fused_ = (v == 1) && blu_ && eng_->enable_bluestein_small();
       return 0;
@@ -358,7 +410,7 @@ template <typename T> class Plan {
     if (small_fused_) return batch;  // whole chirp-z in one launch: no work array
     reserve([&](size_t c) {
       work_.ensure(c * m_ * ELEM);
-      if (eng_->needs_scratch(true) || fused_) scratch_.ensure(c * m_ * ELEM);
+      if (blut_ || eng_->needs_scratch(true) || fused_) scratch_.ensure(c * m_ * ELEM);
     });
     return chunk;
   }
@@ -423,6 +475,13 @@ template <typename T> class Plan {
       return;
     }
     cpx<T>* work = (cpx<T>*)work_.p;
+    if (blut_) {  // smooth M: three sweeps on register tiles (kernels_regtile.h)
+      for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+        const size_t nb = std::min(chunk, batch - b0);
+        blut_->run(in + b0 * n_, out + b0 * n_, work, (cpx<T>*)scratch_.p, nb, xtab_.p, wtab_.p, inverse, scale, stream, prof);
+      }
+      return;
+    }
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
       const size_t nb = std::min(chunk, batch - b0);
       BluArgs pre{in + b0 * n_, work, xtab_.p, (uint64_t)n_, (uint64_t)m_, (uint64_t)nb, inverse, 1.0};
@@ -580,6 +639,20 @@ template <typename T> class Plan {
     m_ = 1;
     while (m_ < 2 * n_ - 1) m_ <<= 1;  // bluesteins.rs:110
     if (2 * n_ > m_) throw EngineError(::fourier::c::FOURIER_HIP_RUNTIME_ERROR, "Bluestein: M < 2N");  // the fused end passes rely on it
+    fused_ = small_fused_ = conv_ = conv_ok_ = chirp_compute_ = false;
+    // M need only reach 2N - 1 (bluesteins.rs:110 rounds up to a power of two: up to 4N).  Beyond the one-launch kernels (M <= 2^15, f64 2^14)
+    // the work array is swept three times: the smallest product of two register-tile lengths instead, where it is at least a fifth shorter
+    // (the tile passes of mixed length run at 5.0 - 5.4 TB/s against 5.5 - 5.9 for the power-of-two tiles)
+    if (smooth_m_allowed_ && !dev_env("FOURIER_NO_SMOOTH_M") && m_ > ((size_t)1 << (sizeof(T) == 4 ? 15 : 14))) {
+      uint32_t l1 = 0, l2 = 0;
+      const uint64_t ms = BluTiledEngine<T>::choose_m(n_, l1, l2);
+      if (ms != 0 && 5 * ms <= 4 * (uint64_t)m_) {
+        m_ = ms;
+        blut_.reset(new BluTiledEngine<T>(n_, l1, l2));
+        build_chirp_tables(false);
+        return;
+      }
+    }
     // forward inner plan: the larger pass first (2048 x 1024 at M = 2^21), so the conv kernel runs at the SHORTER length
     // and the end passes at the longer one.  FOURIER_BLU_SHORT_FIRST=1 (experiment) swaps the roles: 1024 x 2048 forward,
     // end passes of length 1024, conv kernel at 2048.
@@ -660,7 +733,7 @@ template <typename T> class Plan {
       wr[k] = cr[k]; wi[k] = -ci[k];
       if (k) { wr[m_ - k] = cr[k]; wi[m_ - k] = -ci[k]; }
     }
-    host_fft(wr, wi);
+    host_fft_any(wr, wi);
     std::vector<cpx<T>> w(m_);
     const double inv_m = 1.0 / (double)m_;
     for (size_t k = 0; k < m_; ++k) w[k] = {(T)(wr[k] * inv_m), (T)(wi[k] * inv_m)};
@@ -722,6 +795,8 @@ template <typename T> class Plan {
   int device_ = 0;
   bool blu_ = false;
   std::unique_ptr<Pow2Engine<T>> eng_, eng_inv_;  // eng_inv_: mirrored inverse plan of a conv-fused Bluestein
+  std::unique_ptr<BluTiledEngine<T>> blut_;       // Bluestein on a smooth M (then eng_ is empty)
+  bool smooth_m_allowed_ = true;                  // option "bluestein_smooth_m"
   std::unique_ptr<MixedEngine<T>> mix_;
   std::unique_ptr<TiledMixedEngine<T>> tiled_;  // 2^a*3^b, a < 12, beyond the LDS kernels: column tiles of mixed length
   std::unique_ptr<GenericEngine<T>> gen_;  // ... and what has no tile factorisation: one global pass per radix
