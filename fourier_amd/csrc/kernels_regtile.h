@@ -129,14 +129,6 @@ template <typename T, int R> __device__ __forceinline__ void dft_any(cpx<T>* x) 
 }
 
 // one complex number (8 / 16 bytes, 8-byte aligned: an f64 transform of odd length inside a batch) as ONE global access
-template <typename T> __device__ __forceinline__ cpx<T> load_cpx(const cpx<T>* p) {
-  if constexpr (sizeof(T) == 8) {
-    const Unit16<T> u = load_unit_a8<T>(p);
-    return {u.a[0], u.a[1]};
-  } else {
-    return *p;
-  }
-}
 template <typename T> __device__ __forceinline__ void store_cpx(cpx<T>* p, cpx<T> z) {
   if constexpr (sizeof(T) == 8) {
     Unit16<T> u;
@@ -147,9 +139,13 @@ template <typename T> __device__ __forceinline__ void store_cpx(cpx<T>* p, cpx<T
   }
 }
 
+// Threads work on 16-byte UNITS of a row segment: one f64 column, two adjacent f32 columns (VEC) -- every global and LDS access of the
+// stages is 16 bytes per lane (8-byte accesses for f32, one column per thread: 10 - 25 % slower, profiles/r06_s27_*first_version*).
 template <typename T, uint32_t L> struct RegTileCfg {  // the rules: reg_tile_shape (mixed_schedule.h), shared with the host
   static constexpr RegTileShape S = reg_tile_shape(L, (uint32_t)sizeof(cpx<T>));
-  static constexpr uint32_t R1 = S.r1, R2 = S.r2, COLS = S.cols, NT = S.threads, XS = S.xstride, LDO = S.ldo;
+  static constexpr uint32_t R1 = S.r1, R2 = S.r2, COLS = S.cols, NT = S.threads, LDO = S.ldo;
+  static constexpr uint32_t VEC = 16 / (uint32_t)sizeof(cpx<T>), CU = COLS / VEC;  // units per row segment
+  static constexpr uint32_t XSU = R2 * CU;                                          // units between the k1 planes of the exchange buffer
   static constexpr size_t TAB_OFF = S.tab_off, SMEM = S.smem;
 };
 
@@ -207,18 +203,66 @@ __device__ __forceinline__ void reg_tile_copy_out(const cpx<T>* buf, cpx<T>* o, 
     if (idx < total) store_cpx(o + idx, v[it]);
   }
 }
+// the pieces the three kernels share, on a thread's VEC columns
+template <typename T, uint32_t L> struct RegTileOps {
+  using C = RegTileCfg<T, L>;
+  static constexpr uint32_t VEC = C::VEC, CU = C::CU, LDO = C::LDO;
+  template <uint32_t R> static __device__ __forceinline__ void unpack(const Unit16<T>& u, cpx<T> (&x)[VEC][R], uint32_t r) {
+#pragma unroll
+    for (uint32_t v = 0; v < VEC; ++v) x[v][r] = {u.a[2 * v], u.a[2 * v + 1]};
+  }
+  template <uint32_t R> static __device__ __forceinline__ Unit16<T> pack(const cpx<T> (&x)[VEC][R], uint32_t r) {
+    Unit16<T> u;
+#pragma unroll
+    for (uint32_t v = 0; v < VEC; ++v) { u.a[2 * v] = x[v][r].re; u.a[2 * v + 1] = x[v][r].im; }
+    return u;
+  }
+  // exchange: the R values of a thread into planes [k][row][unit] (rows j2 and j2 ^ 1 exchanged in the odd planes where RROW is even:
+  // reg_tile_row), and a plane's RROW values back
+  template <uint32_t R, uint32_t RROW> static __device__ __forceinline__ void xch_write(Unit16<T>* bufu, const cpx<T> (&x)[VEC][R], uint32_t row, uint32_t cu, uint32_t site) {
+#pragma unroll
+    for (uint32_t k = 0; k < R; ++k) {
+      Unit16<T>* d = bufu + k * (RROW * CU) + reg_tile_row(RROW, k, row) * CU + cu;
+      LDS_NOTE(d, 16, true, site);
+      *d = pack<R>(x, k);
+    }
+  }
+  template <uint32_t RROW> static __device__ __forceinline__ void xch_read(const Unit16<T>* bufu, cpx<T> (&y)[VEC][RROW], uint32_t plane, uint32_t cu, uint32_t site) {
+#pragma unroll
+    for (uint32_t j = 0; j < RROW; ++j) {
+      const Unit16<T>* s = bufu + plane * (RROW * CU) + reg_tile_row(RROW, plane, j) * CU + cu;
+      LDS_NOTE(s, 16, false, site);
+      unpack<RROW>(*s, y, j);
+    }
+  }
+  // a first pass's staging: output k = q + RQ * k2 of column c at c * LDO + k
+  template <uint32_t R, uint32_t RQ> static __device__ __forceinline__ void stage_write(cpx<T>* buf, const cpx<T> (&y)[VEC][R], uint32_t q, uint32_t cu) {
+#pragma unroll
+    for (uint32_t v = 0; v < VEC; ++v)
+#pragma unroll
+      for (uint32_t k2 = 0; k2 < R; ++k2) {
+        cpx<T>* d = buf + (cu * VEC + v) * LDO + q + RQ * k2;
+        LDS_NOTE(d, sizeof(cpx<T>), true, 302);
+        *d = y[v][k2];
+      }
+  }
+};
 
 template <typename T, uint32_t L, int IO = IO_PLAIN>
 __global__ void __launch_bounds__((RegTileCfg<T, L>::NT)) tiled_reg_kernel(TiledArgs a) {
   using C = RegTileCfg<T, L>;
-  constexpr uint32_t R1 = C::R1, R2 = C::R2, COLS = C::COLS, NT = C::NT, XS = C::XS, LDO = C::LDO;
+  using O = RegTileOps<T, L>;
+  constexpr uint32_t R1 = C::R1, R2 = C::R2, COLS = C::COLS, NT = C::NT, LDO = C::LDO, VEC = C::VEC, CU = C::CU;
+  constexpr uint32_t EB = (uint32_t)sizeof(cpx<T>);
   static_assert(R1 * R2 == L && R1 >= R2, "tiled_reg_kernel: split");
   FOURIER_DYN_SMEM(smem);
-  cpx<T>* buf = (cpx<T>*)smem;                // exchange: [k1][j2][c] at k1 * XS + reg_tile_row(k1, j2) * COLS + c; first pass, then: [c][k] at c * LDO + k
+  cpx<T>* buf = (cpx<T>*)smem;                // exchange planes (units), then -- first pass -- the staging [c][k] at c * LDO + k
+  Unit16<T>* bufu = (Unit16<T>*)smem;
   cpx<T>* tu = (cpx<T>*)(smem + C::TAB_OFF);  // [COLS][R1]: W_size^{i * k1}
   cpx<T>* tv = tu + COLS * R1;                // [COLS][R2]: W_size^{i * R1 * k2}
   const uint32_t tid = threadIdx.x;
-  const uint32_t c = tid % COLS, q = tid / COLS;  // stage A: q = j2 (< R2); stage B: q = k1 (< R1)
+  const uint32_t cu = tid % CU, q = tid / CU;  // stage A: q = j2 (< R2); stage B: q = k1 (< R1)
+  const uint32_t c = cu * VEC;                 // first column of the thread's unit
   const bool first = (a.s == 1);
   // tile coordinates: block -> (transform b, i, first column c0), as in tiled_mixed_kernel_ct
   const uint32_t tiles_per_row = (uint32_t)a.tiles_per_row;
@@ -228,41 +272,42 @@ __global__ void __launch_bounds__((RegTileCfg<T, L>::NT)) tiled_reg_kernel(Tiled
   const uint32_t i_row = rem / tiles_per_row, c0 = (rem - i_row * tiles_per_row) * COLS;
   const uint32_t ncols_total = first ? (uint32_t)a.m : (uint32_t)a.s;
   const uint32_t ncols = ncols_total - c0 < COLS ? ncols_total - c0 : COLS;
-  // (the Bluestein end passes: the user array holds blu_n points per transform, the work array n = M)
-  const cpx<T>* __restrict__ in = (const cpx<T>*)a.in + (uint64_t)b * (IO == IO_BLU_IN ? a.blu_n : a.n);
-  cpx<T>* __restrict__ out = (cpx<T>*)a.out + (uint64_t)b * (IO == IO_BLU_OUT ? a.blu_n : a.n);
+  // global accesses through bounds-checked descriptors over ONE transform (the Bluestein end passes: over the blu_n points of the user
+  // array -- the zero padding behind it and the outputs beyond it need no branch): a unit that reaches past a ragged tile's last column
+  // loads what lies there (the next row; zero past the end of the transform) and is never stored
+  const uint64_t in_len = IO == IO_BLU_IN ? a.blu_n : a.n, out_len = IO == IO_BLU_OUT ? a.blu_n : a.n;
+  const cpx<T>* in_b = (const cpx<T>*)a.in + (uint64_t)b * in_len;
+  cpx<T>* out_b = (cpx<T>*)a.out + (uint64_t)b * out_len;
+  const BufRsrc rin = make_rsrc(in_b, (uint32_t)(in_len * EB));
   const uint64_t row_stride = a.s * a.m;
   const uint64_t col0 = first ? (uint64_t)c0 : (uint64_t)c0 + a.s * (uint64_t)i_row;
   const bool twiddled = a.m > 1;
-  const bool live = c < ncols;  // a ragged last tile of a row: the columns past it load nothing and store nothing
+  const bool full = c + VEC <= ncols, part = !full && c < ncols;  // part: f32, the last valid column of a ragged tile by itself
 
-  // ---- stage A: rows j2 + R2*j1 of column c, their stage twiddles, and the entries of the inter-pass tables -- every global load
-  // of the thread ahead of its first use
-  cpx<T> x[R1];
+  // ---- stage A: rows j2 + R2*j1 of the unit, then every other global load of the thread ahead of its first use
+  cpx<T> x[VEC][R1];
   if (q < R2) {
+    const uint32_t voff = (uint32_t)((col0 + c + row_stride * (uint64_t)q) * EB), rowb = (uint32_t)(row_stride * (uint64_t)R2 * EB);
+    Unit16<T> d[R1];
+#pragma unroll
+    for (uint32_t j1 = 0; j1 < R1; ++j1) d[j1] = buf_load_unit<T>(rin, voff + j1 * rowb);
     if constexpr (IO == IO_BLU_IN) {
-      // work = x (.) in, zero padded (bluesteins.rs:229-234): element e = column + m * row of the user array and of the chirp table, zero
-      // from blu_n on (more than half of the rows: 2N <= M + 1) -- those loads are never issued
-      cpx<T> ch[R1];
-      const uint64_t e0 = col0 + (live ? c : 0u) + row_stride * (uint64_t)q;
+      // work = x (.) in, zero padded (bluesteins.rs:229-234): element e = column + m * row of the user array and of the chirp table
+      const BufRsrc rc = make_rsrc(a.blu_x, (uint32_t)(a.blu_n * EB));
+      Unit16<T> ch[R1];
 #pragma unroll
-      for (uint32_t j1 = 0; j1 < R1; ++j1) {
-        const uint64_t e = e0 + row_stride * (uint64_t)(R2 * j1);
-        const bool valid = e < a.blu_n;
-        const uint64_t ec = valid ? e : 0u;
-        x[j1] = load_cpx(in + ec);
-        ch[j1] = load_cpx((const cpx<T>*)a.blu_x + ec);
-        if (!valid) x[j1] = cpx<T>{(T)0, (T)0};
-      }
+      for (uint32_t j1 = 0; j1 < R1; ++j1) ch[j1] = buf_load_unit<T>(rc, voff + j1 * rowb);
 #pragma unroll
-      for (uint32_t j1 = 0; j1 < R1; ++j1) {
-        if (a.blu_swap) x[j1] = {x[j1].im, x[j1].re};
-        x[j1] = cmul(ch[j1], x[j1]);
-      }
+      for (uint32_t j1 = 0; j1 < R1; ++j1)
+#pragma unroll
+        for (uint32_t v = 0; v < VEC; ++v) {
+          cpx<T> val{d[j1].a[2 * v], d[j1].a[2 * v + 1]};
+          if (a.blu_swap) val = {val.im, val.re};
+          x[v][j1] = cmul(cpx<T>{ch[j1].a[2 * v], ch[j1].a[2 * v + 1]}, val);
+        }
     } else {
-      const cpx<T>* p = in + col0 + (live ? c : 0u) + row_stride * (uint64_t)q;  // (a column past a ragged tile reads column 0: never stored)
 #pragma unroll
-      for (uint32_t j1 = 0; j1 < R1; ++j1) x[j1] = load_cpx(p + row_stride * (uint64_t)(R2 * j1));
+      for (uint32_t j1 = 0; j1 < R1; ++j1) O::template unpack<R1>(d[j1], x, j1);
     }
   }
   // the twiddle between the stages, W_L^{j2 * k1}, applied on the side with fewer values per thread (stage B: R2 <= R1), loaded with the
@@ -276,88 +321,82 @@ __global__ void __launch_bounds__((RegTileCfg<T, L>::NT)) tiled_reg_kernel(Tiled
   RegTileTabs<T, R1, R2, COLS, NT> tabs;
   const uint32_t tcols = first ? COLS : 1u;  // the later passes have one i for the whole tile: table column 0
   if (twiddled) tabs.load(a, tid, tcols, first, c0, ncols_total, i_row);
+  Unit16<T> chq[R2];  // chirp-out: the chirp at the thread's outputs
+  if constexpr (IO == IO_BLU_OUT) {
+    if (q < R1) {
+      const BufRsrc rc = make_rsrc(a.blu_x, (uint32_t)(a.blu_n * EB));
+      const uint32_t voff = (uint32_t)(((uint64_t)c0 + c + a.s * (uint64_t)q) * EB), rowb = (uint32_t)(a.s * (uint64_t)R1 * EB);
+#pragma unroll
+      for (uint32_t k2 = 0; k2 < R2; ++k2) chq[k2] = buf_load_unit<T>(rc, voff + k2 * rowb);
+    }
+  }
   if (q < R2) {
-    if (a.swap_in) {
 #pragma unroll
-      for (uint32_t j1 = 0; j1 < R1; ++j1) x[j1] = {x[j1].im, x[j1].re};
-    }
-    dft_any<T, (int)R1>(x);
+    for (uint32_t v = 0; v < VEC; ++v) {
+      if (a.swap_in) {
 #pragma unroll
-    for (uint32_t k1 = 0; k1 < R1; ++k1) {
-      cpx<T>* d = buf + k1 * XS + reg_tile_row(R2, k1, q) * COLS + c;
-      LDS_NOTE(d, sizeof(cpx<T>), true, 300);
-      *d = x[k1];
+        for (uint32_t j1 = 0; j1 < R1; ++j1) x[v][j1] = {x[v][j1].im, x[v][j1].re};
+      }
+      dft_any<T, (int)R1>(x[v]);
     }
+    O::template xch_write<R1, R2>(bufu, x, q, cu, 300);
   }
   if (twiddled) tabs.store(tid, tcols, tu, tv);
   __syncthreads();
 
-  // ---- stage B: the R2 values of (column c, k1 = q); output k = k1 + R1*k2
-  cpx<T> y[R2];
+  // ---- stage B: the R2 values of (unit, k1 = q); output k = k1 + R1*k2
+  cpx<T> y[VEC][R2];
   if (q < R1) {
+    O::template xch_read<R2>(bufu, y, q, cu, 301);
 #pragma unroll
-    for (uint32_t j2 = 0; j2 < R2; ++j2) {
-      const cpx<T>* s = buf + q * XS + reg_tile_row(R2, q, j2) * COLS + c;
-      LDS_NOTE(s, sizeof(cpx<T>), false, 301);
-      y[j2] = j2 == 0 ? *s : cmul(*s, w[j2]);
-    }
-    dft_any<T, (int)R2>(y);
-    if (twiddled) {
-      const uint32_t tc = first ? c : 0u;
-      const cpx<T> u = tu[tc * R1 + q];
+    for (uint32_t v = 0; v < VEC; ++v) {
 #pragma unroll
-      for (uint32_t k2 = 0; k2 < R2; ++k2) y[k2] = cmul(y[k2], k2 == 0 ? u : cmul(u, tv[tc * R2 + k2]));
-    } else {  // last pass (mod.rs:238: no twiddle): the user-level scaling and the inverse's trailing swap
-      const T scale = (T)a.scale;
+      for (uint32_t j2 = 1; j2 < R2; ++j2) y[v][j2] = cmul(y[v][j2], w[j2]);
+      dft_any<T, (int)R2>(y[v]);
+      if (twiddled) {
+        const uint32_t tc = first ? c + v : 0u;
+        const cpx<T> u = tu[tc * R1 + q];
 #pragma unroll
-      for (uint32_t k2 = 0; k2 < R2; ++k2) {
-        if (a.swap_out) y[k2] = {y[k2].im, y[k2].re};
-        y[k2] = {y[k2].re * scale, y[k2].im * scale};
+        for (uint32_t k2 = 0; k2 < R2; ++k2) y[v][k2] = cmul(y[v][k2], k2 == 0 ? u : cmul(u, tv[tc * R2 + k2]));
+      } else {  // last pass (mod.rs:238: no twiddle): the user-level scaling and the inverse's trailing swap
+        const T scale = (T)a.scale;
+#pragma unroll
+        for (uint32_t k2 = 0; k2 < R2; ++k2) {
+          if (a.swap_out) y[v][k2] = {y[v][k2].im, y[v][k2].re};
+          y[v][k2] = {y[v][k2].re * scale, y[v][k2].im * scale};
+        }
       }
     }
-  }
-  if constexpr (IO == IO_BLU_OUT) {
-    // out = work (.) x (.) scale, the first blu_n points only (bluesteins.rs:240-258); the last pass: i = 0, element e = j + s * k.
-    // (y was swapped and scaled above: the inverse inner transform's trailing swap; the user-level inverse swaps once more)
-    if (q < R1 && live) {
-      const uint64_t e0 = (uint64_t)c0 + c + a.s * (uint64_t)q;
-      cpx<T> ch[R2];
-#pragma unroll
-      for (uint32_t k2 = 0; k2 < R2; ++k2) {
-        const uint64_t e = e0 + a.s * (uint64_t)(R1 * k2);
-        ch[k2] = load_cpx((const cpx<T>*)a.blu_x + (e < a.blu_n ? e : 0u));
-      }
-#pragma unroll
-      for (uint32_t k2 = 0; k2 < R2; ++k2) {
-        const uint64_t e = e0 + a.s * (uint64_t)(R1 * k2);
-        cpx<T> z = cmul(y[k2], ch[k2]);
-        if (a.blu_swap) z = {z.im, z.re};
-        if (e < a.blu_n) store_cpx(out + e, z);
-      }
-    }
-    return;
   }
   if (!first) {
-    // out[j + L*s*i + s*k]: 128-byte row segments, row k at stride s
-    if (q < R1 && live) {
-      cpx<T>* o = out + (uint64_t)c0 + c + (uint64_t)L * a.s * (uint64_t)i_row + a.s * (uint64_t)q;
+    // out[j + L*s*i + s*k]: 128-byte row segments, row k at stride s.  Chirp-out (the last pass: i = 0): out = work (.) x (.) scale, the
+    // first blu_n points only (bluesteins.rs:240-258) -- y was swapped and scaled above (the inverse inner transform's trailing swap),
+    // the user-level inverse swaps once more; the descriptor drops what lies beyond the user array
+    if (q < R1 && (full || part)) {
+      const BufRsrc rout = make_rsrc(out_b, (uint32_t)(out_len * EB));
+      const uint32_t voff = (uint32_t)(((uint64_t)c0 + c + (uint64_t)L * a.s * (uint64_t)i_row + a.s * (uint64_t)q) * EB);
+      const uint32_t rowb = (uint32_t)(a.s * (uint64_t)R1 * EB);
 #pragma unroll
-      for (uint32_t k2 = 0; k2 < R2; ++k2) store_cpx(o + a.s * (uint64_t)(R1 * k2), y[k2]);
+      for (uint32_t k2 = 0; k2 < R2; ++k2) {
+        if constexpr (IO == IO_BLU_OUT) {
+#pragma unroll
+          for (uint32_t v = 0; v < VEC; ++v) {
+            cpx<T> z = cmul(y[v][k2], cpx<T>{chq[k2].a[2 * v], chq[k2].a[2 * v + 1]});
+            if (a.blu_swap) z = {z.im, z.re};
+            y[v][k2] = z;
+          }
+        }
+        if (full) buf_store_unit<T>(rout, voff + k2 * rowb, O::template pack<R2>(y, k2));
+        else buf_store_elem<T>(rout, voff + k2 * rowb, y[0][k2]);
+      }
     }
     return;
   }
   // first pass: out[L*i + k] -- the tile's output is ONE contiguous run of ncols * L elements; transposed through LDS
   __syncthreads();  // every thread has read its stage-B inputs
-  if (q < R1) {
-#pragma unroll
-    for (uint32_t k2 = 0; k2 < R2; ++k2) {
-      cpx<T>* d = buf + c * LDO + q + R1 * k2;
-      LDS_NOTE(d, sizeof(cpx<T>), true, 302);
-      *d = y[k2];
-    }
-  }
+  if (q < R1) O::template stage_write<R2, R1>(buf, y, q, cu);
   __syncthreads();
-  reg_tile_copy_out<T, L, COLS, NT, LDO>(buf, out + (uint64_t)L * c0, ncols, tid);
+  reg_tile_copy_out<T, L, COLS, NT, LDO>(buf, out_b + (uint64_t)L * c0, ncols, tid);
 }
 
 // Bluestein middle sweep on a smooth M = L1 x L: the LAST pass of the forward inner transform (length L, stride s = M / L, no twiddle:
@@ -370,108 +409,93 @@ __global__ void __launch_bounds__((RegTileCfg<T, L>::NT)) tiled_reg_kernel(Tiled
 template <typename T, uint32_t L>
 __global__ void __launch_bounds__((RegTileCfg<T, L>::NT)) tiled_reg_conv_kernel(TiledArgs a) {
   using C = RegTileCfg<T, L>;
-  constexpr uint32_t R1 = C::R1, R2 = C::R2, COLS = C::COLS, NT = C::NT, XS = C::XS, LDO = C::LDO;
-  constexpr uint32_t XS2 = R1 * COLS;  // second exchange: [k1''][k1][c] at k1'' * XS2 + reg_tile_row(R1, k1'', k1) * COLS + c
+  using O = RegTileOps<T, L>;
+  constexpr uint32_t R1 = C::R1, R2 = C::R2, COLS = C::COLS, NT = C::NT, LDO = C::LDO, VEC = C::VEC, CU = C::CU;
+  constexpr uint32_t EB = (uint32_t)sizeof(cpx<T>);
   FOURIER_DYN_SMEM(smem);
   cpx<T>* buf = (cpx<T>*)smem;
+  Unit16<T>* bufu = (Unit16<T>*)smem;
   cpx<T>* tu = (cpx<T>*)(smem + C::TAB_OFF);  // [COLS][R2]: W_M^{i * k1''}
   cpx<T>* tv = tu + COLS * R2;                // [COLS][R1]: W_M^{i * R2 * k2''}
   const uint32_t tid = threadIdx.x;
-  const uint32_t c = tid % COLS, q = tid / COLS;
+  const uint32_t cu = tid % CU, q = tid / CU, c = cu * VEC;
   const uint32_t tiles_per_row = (uint32_t)a.tiles_per_row;  // ceil(s / COLS)
   const uint32_t blk = xcd_chunked(blockIdx.x, gridDim.x, a.xcd_chunk);
   const uint32_t b = blk / tiles_per_row, c0 = (blk - b * tiles_per_row) * COLS;
   const uint32_t ncols_total = (uint32_t)a.s;
   const uint32_t ncols = ncols_total - c0 < COLS ? ncols_total - c0 : COLS;
-  const cpx<T>* __restrict__ in = (const cpx<T>*)a.in + (uint64_t)b * a.n;
-  cpx<T>* __restrict__ out = (cpx<T>*)a.out + (uint64_t)b * a.n;
-  const bool live = c < ncols;
-  const uint32_t cl = live ? c : 0u;  // (a column past a ragged tile reads column 0: never stored)
+  const cpx<T>* in_b = (const cpx<T>*)a.in + (uint64_t)b * a.n;
+  cpx<T>* out_b = (cpx<T>*)a.out + (uint64_t)b * a.n;
+  const BufRsrc rin = make_rsrc(in_b, (uint32_t)(a.n * EB)), rw = make_rsrc(a.blu_w, (uint32_t)(a.n * EB));
 
-  // ---- forward last pass, stage A: rows j2 + R2*j1 of column c; then every other global load of the thread
-  cpx<T> x[R1];
+  // ---- forward last pass, stage A: rows j2 + R2*j1 of the unit; then every other global load of the thread
+  cpx<T> x[VEC][R1];
   if (q < R2) {
-    const cpx<T>* p = in + c0 + cl + a.s * (uint64_t)q;
+    const uint32_t voff = (uint32_t)(((uint64_t)c0 + c + a.s * (uint64_t)q) * EB), rowb = (uint32_t)(a.s * (uint64_t)R2 * EB);
+    Unit16<T> d[R1];
 #pragma unroll
-    for (uint32_t j1 = 0; j1 < R1; ++j1) x[j1] = load_cpx(p + a.s * (uint64_t)(R2 * j1));
+    for (uint32_t j1 = 0; j1 < R1; ++j1) d[j1] = buf_load_unit<T>(rin, voff + j1 * rowb);
+#pragma unroll
+    for (uint32_t j1 = 0; j1 < R1; ++j1) O::template unpack<R1>(d[j1], x, j1);
   }
-  cpx<T> w[R2], ww[R2];  // W_L^{k1 * j2} (both transforms); w[j + s * k] at the thread's outputs k = q + R1 * k2
+  cpx<T> w[R2];      // W_L^{k1 * j2}: the twiddle between the stages of both transforms
+  Unit16<T> ww[R2];  // w[j + s * k] at the thread's outputs k = q + R1 * k2
   if (q < R1) {
     const cpx<T>* tw = (const cpx<T>*)a.tw + q * R2;
 #pragma unroll
     for (uint32_t j2 = 1; j2 < R2; ++j2) w[j2] = tw[j2];
-    const cpx<T>* pw = (const cpx<T>*)a.blu_w + c0 + cl + a.s * (uint64_t)q;
+    const uint32_t voff = (uint32_t)(((uint64_t)c0 + c + a.s * (uint64_t)q) * EB), rowb = (uint32_t)(a.s * (uint64_t)R1 * EB);
 #pragma unroll
-    for (uint32_t k2 = 0; k2 < R2; ++k2) ww[k2] = load_cpx(pw + a.s * (uint64_t)(R1 * k2));
+    for (uint32_t k2 = 0; k2 < R2; ++k2) ww[k2] = buf_load_unit<T>(rw, voff + k2 * rowb);
   }
   RegTileTabs<T, R2, R1, COLS, NT> tabs;  // the inverse first pass: i = c0 + column, output k'' = k1'' + R2 * k2''
   tabs.load(a, tid, COLS, true, c0, ncols_total, 0u);
   if (q < R2) {
-    dft_any<T, (int)R1>(x);
 #pragma unroll
-    for (uint32_t k1 = 0; k1 < R1; ++k1) {
-      cpx<T>* d = buf + k1 * XS + reg_tile_row(R2, k1, q) * COLS + c;
-      LDS_NOTE(d, sizeof(cpx<T>), true, 310);
-      *d = x[k1];
-    }
+    for (uint32_t v = 0; v < VEC; ++v) dft_any<T, (int)R1>(x[v]);
+    O::template xch_write<R1, R2>(bufu, x, q, cu, 310);
   }
   tabs.store(tid, COLS, tu, tv);
   __syncthreads();
 
   // ---- stage B, (.) w, swap; stage A' of the inverse first pass on the same threads
-  cpx<T> y[R2];
+  cpx<T> y[VEC][R2];
   if (q < R1) {
+    O::template xch_read<R2>(bufu, y, q, cu, 311);
 #pragma unroll
-    for (uint32_t j2 = 0; j2 < R2; ++j2) {
-      const cpx<T>* s = buf + q * XS + reg_tile_row(R2, q, j2) * COLS + c;
-      LDS_NOTE(s, sizeof(cpx<T>), false, 311);
-      y[j2] = j2 == 0 ? *s : cmul(*s, w[j2]);
+    for (uint32_t v = 0; v < VEC; ++v) {
+#pragma unroll
+      for (uint32_t j2 = 1; j2 < R2; ++j2) y[v][j2] = cmul(y[v][j2], w[j2]);
+      dft_any<T, (int)R2>(y[v]);  // y[k2] = Y[q + R1 * k2]
+#pragma unroll
+      for (uint32_t k2 = 0; k2 < R2; ++k2) {
+        const cpx<T> z = cmul(y[v][k2], cpx<T>{ww[k2].a[2 * v], ww[k2].a[2 * v + 1]});
+        y[v][k2] = {z.im, z.re};
+      }
+      dft_any<T, (int)R2>(y[v]);  // over k2: y[k1''], k1'' < R2
+#pragma unroll
+      for (uint32_t k = 1; k < R2; ++k) y[v][k] = cmul(y[v][k], w[k]);  // W_L^{q * k1''}
     }
-    dft_any<T, (int)R2>(y);  // y[k2] = Y[q + R1 * k2]
-#pragma unroll
-    for (uint32_t k2 = 0; k2 < R2; ++k2) {
-      const cpx<T> z = cmul(y[k2], ww[k2]);
-      y[k2] = {z.im, z.re};
-    }
-    dft_any<T, (int)R2>(y);  // over k2: y[k1''], k1'' < R2
-#pragma unroll
-    for (uint32_t k = 1; k < R2; ++k) y[k] = cmul(y[k], w[k]);  // W_L^{q * k1''}
   }
   __syncthreads();  // every thread has read its stage-B inputs
-  if (q < R1) {
-#pragma unroll
-    for (uint32_t k = 0; k < R2; ++k) {
-      cpx<T>* d = buf + k * XS2 + reg_tile_row(R1, k, q) * COLS + c;
-      LDS_NOTE(d, sizeof(cpx<T>), true, 312);
-      *d = y[k];
-    }
-  }
+  if (q < R1) O::template xch_write<R2, R1>(bufu, y, q, cu, 312);  // planes k1'' (< R2), rows k1 (< R1)
   __syncthreads();
-  // ---- stage B' (column c, k1'' = q < R2): the R1 values over k1, DFT_R1, the inter-pass twiddle W_M^{i * (k1'' + R2 * k2'')}
-  cpx<T> v[R1];
+  // ---- stage B' (unit, k1'' = q < R2): the R1 values over k1, DFT_R1, the inter-pass twiddle W_M^{i * (k1'' + R2 * k2'')}
+  cpx<T> z[VEC][R1];
   if (q < R2) {
+    O::template xch_read<R1>(bufu, z, q, cu, 313);
 #pragma unroll
-    for (uint32_t j = 0; j < R1; ++j) {
-      const cpx<T>* s = buf + q * XS2 + reg_tile_row(R1, q, j) * COLS + c;
-      LDS_NOTE(s, sizeof(cpx<T>), false, 313);
-      v[j] = *s;
-    }
-    dft_any<T, (int)R1>(v);
-    const cpx<T> u = tu[c * R2 + q];
+    for (uint32_t v = 0; v < VEC; ++v) {
+      dft_any<T, (int)R1>(z[v]);
+      const cpx<T> u = tu[(c + v) * R2 + q];
 #pragma unroll
-    for (uint32_t k2 = 0; k2 < R1; ++k2) v[k2] = cmul(v[k2], k2 == 0 ? u : cmul(u, tv[c * R1 + k2]));
-  }
-  __syncthreads();
-  if (q < R2) {
-#pragma unroll
-    for (uint32_t k2 = 0; k2 < R1; ++k2) {
-      cpx<T>* d = buf + c * LDO + q + R2 * k2;
-      LDS_NOTE(d, sizeof(cpx<T>), true, 314);
-      *d = v[k2];
+      for (uint32_t k2 = 0; k2 < R1; ++k2) z[v][k2] = cmul(z[v][k2], k2 == 0 ? u : cmul(u, tv[(c + v) * R1 + k2]));
     }
   }
   __syncthreads();
-  reg_tile_copy_out<T, L, COLS, NT, LDO>(buf, out + (uint64_t)L * c0, ncols, tid);
+  if (q < R2) O::template stage_write<R1, R2>(buf, z, q, cu);
+  __syncthreads();
+  reg_tile_copy_out<T, L, COLS, NT, LDO>(buf, out_b + (uint64_t)L * c0, ncols, tid);
 }
 
 }  // namespace fourier_hip

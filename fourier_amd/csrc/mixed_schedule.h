@@ -195,7 +195,7 @@ constexpr TileShape tiled_shape(uint32_t L, uint32_t elem) {
 struct RegTileShape {
   uint32_t r1, r2;
   uint32_t cols;     // 128-byte row segments: 16 (f32) / 8 (f64) columns
-  uint32_t threads;  // COLS x R1, rounded up to whole waves
+  uint32_t threads;  // (COLS / columns per 16-byte unit) x R1, rounded up to whole waves
   uint32_t xstride;  // elements between the k1 planes of the exchange buffer: R2 * COLS
   uint32_t ldo;      // leading dimension of a column in the first pass's output staging: odd
   uint32_t tab_off;  // byte offset of the inter-pass twiddle tables behind the buffer
@@ -213,7 +213,7 @@ constexpr RegTileShape reg_tile_shape(uint32_t L, uint32_t elem) {
   if (r2 == 0 || L / r2 > 4u * r2) return t;
   t.r1 = L / r2; t.r2 = r2;
   t.cols = 128u / elem;
-  t.threads = (t.cols * t.r1 + 63u) & ~63u;
+  t.threads = (t.cols / (16u / elem) * t.r1 + 63u) & ~63u;
   // stage B reads plane k1 = tid / COLS at j2 * COLS + c: the two (f64: four) planes a lane group of a ds_read touches must differ by an
   // odd number of 128-byte row segments -- R2 odd, or (R2 even) rows j2 and j2 ^ 1 exchanged in the odd planes (reg_tile_row); no padding
   t.xstride = t.r2 * t.cols;

@@ -641,12 +641,15 @@ template <typename T> class Plan {
     if (2 * n_ > m_) throw EngineError(::fourier::c::FOURIER_HIP_RUNTIME_ERROR, "Bluestein: M < 2N");  // the fused end passes rely on it
     fused_ = small_fused_ = conv_ = conv_ok_ = chirp_compute_ = false;
     // M need only reach 2N - 1 (bluesteins.rs:110 rounds up to a power of two: up to 4N).  Beyond the one-launch kernels (M <= 2^15, f64 2^14)
-    // the work array is swept three times: the smallest product of two register-tile lengths instead, where it is at least a fifth shorter
-    // (the tile passes of mixed length run at 5.0 - 5.4 TB/s against 5.5 - 5.9 for the power-of-two tiles)
+    // the work array is swept three times: the smallest product of two register-tile lengths instead, where the power-of-two array is at
+    // least 1.75 x (f64: 1.6 x) longer -- f32 +2 ... 33 %, f64 +12 ... 43 % there; below that the power-of-two tiles' higher rate wins (1.63 x:
+    // f32 -7 ... +12 %; 1.35 x: -5 ... -15 %), and so it does where the f64 conv kernel would run at more than 336 points (out of registers: -11 %)
+    // (profiles/r06_s29_smooth_m_units_ab.jsonl)
     if (smooth_m_allowed_ && !dev_env("FOURIER_NO_SMOOTH_M") && m_ > ((size_t)1 << (sizeof(T) == 4 ? 15 : 14))) {
       uint32_t l1 = 0, l2 = 0;
       const uint64_t ms = BluTiledEngine<T>::choose_m(n_, l1, l2);
-      if (ms != 0 && 5 * ms <= 4 * (uint64_t)m_) {
+      const bool pays = sizeof(T) == 4 ? 7 * ms <= 4 * (uint64_t)m_ : (8 * ms <= 5 * (uint64_t)m_ && l2 <= 336);
+      if (ms != 0 && pays) {
         m_ = ms;
         blut_.reset(new BluTiledEngine<T>(n_, l1, l2));
         build_chirp_tables(false);

@@ -297,6 +297,8 @@ def test_bluestein_conv_kernel_matches_separate_passes(fa, oracle):
                                  (10001, np.complex128, False, 5e-11), (70001, np.complex128, True, 5e-11)):
         x = np.stack([hash_normal(7 + b, n) for b in range(2)]).astype(dtype)
         conv, plain = make(fa, n, dtype), make(fa, n, dtype)
+        for p in (conv, plain):
+            p.set_option("bluestein_smooth_m", 0)  # the power-of-two work array (10001 / 70001 f64 take a smooth M by default: round 6)
         plain.set_option("bluestein_conv", 0)
         y = np.empty_like(x)
         names = [p[0] for p in conv.profile_batch_ptr(x.ctypes.data, y.ctypes.data, 2, 0) if p[2] > 0]
@@ -337,6 +339,8 @@ def test_bluestein_chirp_in_pass_computes_the_chirp(fa, oracle):
     for n, dtype, tol in ((40001, np.complex64, 2e-6), (70001, np.complex64, 2e-6), (40001, np.complex128, 5e-11)):
         x = np.stack([hash_normal(600 + b, n) for b in range(2)]).astype(dtype)
         comp, read = make(fa, n, dtype), make(fa, n, dtype)
+        for p in (comp, read):
+            p.set_option("bluestein_smooth_m", 0)  # (the smooth-M route reads the chirp table)
         comp.set_option("bluestein_chirp_compute", 1)  # default: on only for long first passes and tables beyond the L2
         read.set_option("bluestein_chirp_compute", 0)
         for code in (0, 1):
@@ -345,6 +349,44 @@ def test_bluestein_chirp_in_pass_computes_the_chirp(fa, oracle):
             assert rel_l2(a, ref) <= tol and rel_l2(b, ref) <= tol, (n, code, rel_l2(a, ref), rel_l2(b, ref))
             assert rel_l2(a, b) <= (3e-7 if dtype == np.complex64 else 1e-12), (n, code, rel_l2(a, b))
             assert not np.array_equal(a, b) or dtype == np.complex128  # the two routes are really different code
+
+
+def test_bluestein_on_a_smooth_work_array(fa, oracle):
+    """Round 6: M need only reach 2N - 1 (bluesteins.rs:110; the reference rounds up to a power of two).  Where the power-of-two work array
+    is at least 1.75 x (f64: 1.6 x) longer than the smallest product of two register-tile lengths, the three sweeps run on that product
+    (kernels_regtile.h: chirp-in first pass, conv, chirp-out last pass).  All five codes against the oracle, in place, a ragged batch; the plan
+    option brings the power-of-two route back and both agree; the reference's chirp angle on request."""
+    for n, dtype, desc, tol in ((16411, np.complex64, "bluestein M=32928 inner mixed tiles 196x168", 2e-6),
+                                (10007, np.complex128, "bluestein M=20160 inner mixed tiles 144x140", 5e-11),
+                                (32771, np.complex128, "bluestein M=65610 inner mixed tiles 270x243", 5e-11)):
+        plan = make(fa, n, dtype)
+        assert desc in plan.describe(), plan.describe()
+        x = np.stack([hash_normal(40 + b, n) for b in range(3)]).astype(dtype)
+        y = np.empty_like(x)
+        names = [p[0] for p in plan.profile_batch_ptr(x.ctypes.data, y.ctypes.data, 3, 0) if p[2] > 0]
+        assert names == ["chirp_in_pass", "conv_pass", "chirp_out_pass"], names
+        pow2 = make(fa, n, dtype)
+        pow2.set_option("bluestein_smooth_m", 0)
+        assert "mixed tiles" not in pow2.describe() and "bluestein M=%d " % (1 << int(np.ceil(np.log2(2 * n - 1)))) in pow2.describe(), pow2.describe()
+        for code in range(5):
+            ref = oracle.transform_batch(x, code)
+            a = run_batch(plan, x, code)
+            assert rel_l2(a, ref) <= tol, (n, code, rel_l2(a, ref))
+            assert np.array_equal(run_batch(plan, x, code, inplace=True), a), (n, code)
+            assert rel_l2(a, run_batch(pow2, x, code)) <= (4e-7 if dtype == np.complex64 else 4e-15), (n, code)
+        assert rel_l2(run_batch(plan, x, 0), np.fft.fft(x.astype(np.complex128), axis=1)) <= (4e-7 if dtype == np.complex64 else 4e-15)
+        pow2.set_option("bluestein_smooth_m", 1)  # ... and back
+        assert pow2.describe() == plan.describe()
+        assert np.array_equal(run_batch(pow2, x, 0), run_batch(plan, x, 0))
+    plan = make(fa, 10007, np.complex128)
+    plan.set_option("bluestein_reference_chirp", 1)
+    x = np.stack([hash_normal(50 + b, 10007) for b in range(2)]).astype(np.complex128)
+    for code in (0, 1):
+        assert rel_l2(run_batch(plan, x, code), oracle.transform_batch(x, code)) <= 5e-15, code
+    # lengths just below a power of two (M / M_smooth < 1.75 / 1.6) and every M within the one-launch kernels keep the power of two
+    assert "mixed tiles" not in make(fa, 24001, np.complex64).describe() and "mixed tiles" not in make(fa, 5003, np.complex128).describe()
+    with pytest.raises(fa.FourierError):
+        make(fa, 4096, np.complex64).set_option("bluestein_smooth_m", 0)
 
 
 def test_bluestein_conv_three_pass_inner_plan(fa):
@@ -881,7 +923,7 @@ def test_every_route_string_describe_can_return_is_named_in_the_public_header(fa
              96, 1000, 1001, 18432,                                 # LDS mixed-radix: per-length and runtime-parameterised kernels
              62208, 3 ** 10 * 2, 3 ** 16,                           # mixed tiles (a < 12), three tile passes, global passes
              100000, 44100,                                         # tile passes with factors 5 / 7
-             17, 1013, 40001, 999983]                               # Bluestein: one-launch ("fused") and fused passes
+             17, 1013, 40001, 999983, 16411]                        # Bluestein: one-launch ("fused"), fused passes, smooth M
     seen = set()
     for n in sizes:
         for dtype in (np.complex64, np.complex128):

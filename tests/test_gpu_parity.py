@@ -250,6 +250,8 @@ def test_bluestein_conv_kernel_vs_separate_passes_and_oracle(torch, fa, oracle, 
     separate-pass form and the oracle, every transform code, in and out of place."""
     x = np.stack([hash_uniform(170 + b, n) for b in range(2)]).astype(dtype)
     conv, plain = make(fa, n, dtype), make(fa, n, dtype)
+    for p in (conv, plain):
+        p.set_option("bluestein_smooth_m", 0)  # the power-of-two work array (65537 f32, 10001 f64 take a smooth M by default: round 6)
     plain.set_option("bluestein_conv", 0)
     d = torch.from_numpy(x).cuda()
     o = torch.empty_like(d)
@@ -1012,6 +1014,8 @@ def test_bluestein_chirp_in_pass_computes_the_chirp(torch, fa, oracle, n, dtype,
     HBM-side traffic).  Against the oracle and against the table-reading route, forward and inverse."""
     x = np.stack([hash_uniform(880 + b, n) for b in range(2)]).astype(dtype)
     comp, read = make(fa, n, dtype), make(fa, n, dtype)
+    for p in (comp, read):
+        p.set_option("bluestein_smooth_m", 0)  # (the smooth-M route reads the chirp table)
     comp.set_option("bluestein_chirp_compute", 1)  # the default turns it on only for long first passes and large tables
     read.set_option("bluestein_chirp_compute", 0)
     for code in (0, 1, 3):
@@ -1394,3 +1398,78 @@ def test_plan_option_specialise_compiles_the_lengths_own_kernel_with_hiprtc(torc
         assert plan.describe() == desc
         x = hash_normal(7, n).astype(np.complex64)[None, :]
         assert rel_l2(gpu_batch(torch, fa, plan, x, 0), oracle.transform_batch(x, 0)) <= 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,dtype,desc,tol", [(16411, np.complex64, "M=32928 inner mixed tiles 196x168", 2e-6), (65537, np.complex64, "M=131220 inner mixed tiles 405x324", 2e-6),
+                                              (70001, np.complex64, "M=140625 inner mixed tiles 375x375", 2e-6), (18221, np.complex64, "mixed tiles", 2e-6),
+                                              (8209, np.complex128, "M=16464 inner mixed tiles", 5e-11), (10007, np.complex128, "M=20160 inner mixed tiles 144x140", 5e-11),
+                                              (20011, np.complex128, "M=40320 inner mixed tiles 210x192", 5e-11), (40001, np.complex128, "M=80640 inner mixed tiles 288x280", 5e-11),
+                                              (65537, np.complex128, "M=131220 inner mixed tiles 405x324", 1e-10)])
+def test_bluestein_on_a_smooth_work_array(torch, fa, oracle, n, dtype, desc, tol):
+    """Round 6: Bluestein's M need only reach 2N - 1 (bluesteins.rs:110; the reference rounds up to a power of two, up
+    to 4N).  Where the power-of-two work array is swept three times and is at least 1.75 x (f64: 1.6 x) longer, the plan takes the smallest
+    product of two tile lengths and runs the same three sweeps on register tiles (kernels_regtile.h): every code against the oracle and the
+    f64 truth, in place, a ragged batch, against the power-of-two route (plan option bluestein_smooth_m = 0) and back."""
+    plan, pow2 = make(fa, n, dtype), make(fa, n, dtype)
+    assert "bluestein" in plan.describe() and desc in plan.describe(), plan.describe()
+    pow2.set_option("bluestein_smooth_m", 0)
+    assert "mixed tiles" not in pow2.describe() and "M=%d " % (1 << int(np.ceil(np.log2(2 * n - 1)))) in pow2.describe(), pow2.describe()
+    x = np.stack([hash_uniform(3300 + b, n) for b in range(5)]).astype(dtype)
+    d = torch.from_numpy(x).cuda()
+    o = torch.empty_like(d)
+    names = [p[0] for p in plan.profile_batch_ptr(d.data_ptr(), o.data_ptr(), 5, 0, 0) if p[2] > 0]
+    assert names == ["chirp_in_pass", "conv_pass", "chirp_out_pass"], names
+    truth = torch.fft.fft(torch.from_numpy(x).to(torch.complex128)).numpy()
+    for code in range(5):
+        a = gpu_batch(torch, fa, plan, x, code)
+        assert np.array_equal(gpu_batch(torch, fa, plan, x, code, inplace=True), a), (n, code)
+        assert rel_l2(a, gpu_batch(torch, fa, pow2, x, code)) <= (4e-7 if dtype == np.complex64 else 4e-15), (n, code)
+        if code in (0, 1, 4):
+            ref = oracle.transform_batch(x, code, nthreads=2)
+            assert rel_l2(a, ref) <= tol, (n, code, rel_l2(a, ref))
+    assert rel_l2(gpu_batch(torch, fa, plan, x, 0), truth) <= (4e-7 if dtype == np.complex64 else 4e-15), n
+    back = gpu_batch(torch, fa, plan, gpu_batch(torch, fa, plan, x, 0), 1)
+    assert rel_l2(back, x) <= (6e-7 if dtype == np.complex64 else 6e-15), n
+    pow2.set_option("bluestein_smooth_m", 1)
+    assert pow2.describe() == plan.describe()
+    assert np.array_equal(gpu_batch(torch, fa, pow2, x, 0), gpu_batch(torch, fa, plan, x, 0)), n
+
+
+@pytest.mark.gpu
+def test_bluestein_smooth_work_array_only_where_it_pays(torch, fa):
+    """Lengths just below a power of two (M / M_smooth below 1.75, f64 1.6), every M the one-launch kernels hold, and f64 lengths whose conv
+    kernel would run beyond 336 points keep the reference's power of two; the option is refused on plans that are not Bluestein."""
+    for n, dtype in ((24001, np.complex64), (40001, np.complex64), (100003, np.complex64), (5003, np.complex128), (12289, np.complex128),
+                     (70001, np.complex128), (999983, np.complex64)):
+        d = make(fa, n, dtype).describe()
+        assert "bluestein" in d and "mixed tiles" not in d, (n, d)
+    with pytest.raises(fa.FourierError):
+        make(fa, 4096, np.complex64).set_option("bluestein_smooth_m", 0)
+    with pytest.raises(fa.FourierError):
+        make(fa, 44100, np.complex64).set_option("bluestein_smooth_m", 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,dtype,tol", [(44100, np.complex64, 2e-6), (100000, np.complex64, 2e-6), (20736, np.complex64, 1e-6), (59049, np.complex64, 1e-6),
+                                         (1000000, np.complex64, 2e-6), (30870, np.complex64, 2e-6),
+                                         (44100, np.complex128, 1e-9), (13122, np.complex128, 5e-14), (250000, np.complex128, 1e-9), (15625, np.complex128, 1e-9)])
+def test_register_resident_tile_passes_against_the_lds_tile_passes(torch, fa, fa_exp, oracle, monkeypatch, n, dtype, tol):
+    """Round 6: the mixed-length tile passes keep a column's transform in registers (kernels_regtile.h: L = R1 x R2, one LDS round trip) where
+    the length splits into two factors of at most 32; the LDS kernels of rounds 4 - 5 (kernels_tiled.h) stay for the other lengths (125,
+    245, 343, 490, everything compiled at run time) and as the A/B arm of the experiments library (FOURIER_NO_REGTILE).  Both against the
+    oracle, every code, in place, a ragged batch, ragged tiles; and against each other."""
+    x = np.stack([hash_normal(4100 + b, n) for b in range(3 if n < 500000 else 2)]).astype(dtype)
+    reg = make(fa, n, dtype)  # (fa_exp is bound: the experiments library, same kernels)
+    monkeypatch.setenv("FOURIER_NO_REGTILE", "1")
+    lds = make(fa, n, dtype)
+    monkeypatch.delenv("FOURIER_NO_REGTILE")
+    assert "mixed tiles" in reg.describe() and reg.describe() == lds.describe(), (reg.describe(), lds.describe())
+    for code in range(5):
+        ref = oracle.transform_batch(x, code, nthreads=2)
+        a, b = gpu_batch(torch, fa, reg, x, code), gpu_batch(torch, fa, lds, x, code)
+        assert rel_l2(a, ref) <= tol and rel_l2(b, ref) <= tol, (n, code, rel_l2(a, ref), rel_l2(b, ref))
+        assert rel_l2(a, b) <= (4e-7 if dtype == np.complex64 else 2e-15), (n, code, rel_l2(a, b))
+        assert np.array_equal(gpu_batch(torch, fa, reg, x, code, inplace=True), a), (n, code)
+    if n != 15625:  # (125 x 125: both plans run the LDS kernel)
+        assert not np.array_equal(gpu_batch(torch, fa, reg, x, 0), gpu_batch(torch, fa, lds, x, 0))  # two different kernels really ran
