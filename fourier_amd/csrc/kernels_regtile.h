@@ -128,6 +128,8 @@ template <typename T, int R> __device__ __forceinline__ void dft_any(cpx<T>* x) 
   }
 }
 
+// Cache policy: plain loads and stores everywhere.  Streaming hints lose 1 ... 40 % (loads; stores 1 ... 12 %) -- most where row segments straddle
+// 128-byte lines and neighbouring tiles meet in the L2 (44100 = 210 x 210: -34 % / -10 % / both -40 %; profiles/r06_s30_regtile_policy_ab.jsonl)
 // one complex number (8 / 16 bytes, 8-byte aligned: an f64 transform of odd length inside a batch) as ONE global access
 template <typename T> __device__ __forceinline__ void store_cpx(cpx<T>* p, cpx<T> z) {
   if constexpr (sizeof(T) == 8) {
