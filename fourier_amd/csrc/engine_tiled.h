@@ -7,12 +7,10 @@
 
 namespace fourier_hip {
 
-#ifndef FOURIER_TILE_CHUNK  // (A/B, round 6 session 24)
-#define FOURIER_TILE_CHUNK 8
-#endif
-#ifndef FOURIER_TILE_CHUNK_ALIGNED
-#define FOURIER_TILE_CHUNK_ALIGNED 0
-#endif
+// workgroup -> tile order of the mixed-length tile passes (xcd_chunked, kernels_common.h): runs of 8 neighbouring tiles per XCD where row
+// segments straddle 128-byte lines (+3 ... 15 %; 2 / 4 / 8 / 32 within 2 % of each other), the plain order where they do not (chunks there:
+// -3 ... +1 %) -- profiles/r06_s24_regtile_chunk_ab.jsonl
+constexpr uint32_t FOURIER_TILE_CHUNK = 8, FOURIER_TILE_CHUNK_ALIGNED = 0;
 
 template <typename T> class TiledMixedEngine {
  public:
@@ -94,12 +92,10 @@ template <typename T> class TiledMixedEngine {
   // the ahead-of-time kernel of a tile pass of length L: the register-resident one (kernels_regtile.h) where the length splits into two
   // factors of at most 32, else the LDS one (kernels_tiled.h); FOURIER_NO_REGTILE (experiments library, emulator): always the latter
   static TiledKernel pass_kernel(uint32_t L) {
-#ifndef FOURIER_AB_NO_REGTILE
     if (!dev_env("FOURIER_NO_REGTILE")) {
       const TiledKernel k = get_regtile_kernel(Real<T>{}, L);
       if (k.fn) return k;
     }
-#endif
     return get_tiled_kernel(Real<T>{}, L);
   }
   // launch shape of a tile pass of length L for a kernel compiled at run time: tiled_shape (mixed_schedule.h), the function the

@@ -255,6 +255,30 @@ def test_mixed_radix_sizes_beyond_the_lds_limit_with_a_small_power_of_two_run_as
     assert rel_l2(run_batch(blu, x, 0), run_batch(make(fa, 62208, np.complex64), x, 0)) <= 2e-6
 
 
+def test_register_resident_tile_passes_against_the_lds_tile_passes(fa, oracle, monkeypatch):
+    """Round 6 (kernels_regtile.h): a tile pass of mixed length L = R1 x R2 keeps a column's transform in registers -- stage A (DFT_R1 on rows
+    loaded straight from global memory), one LDS exchange, stage B (DFT_R2, inter-pass twiddle, store) -- where L splits into two factors of
+    at most 32 (and not worse than 4 : 1); the LDS kernels (kernels_tiled.h) stay for 125, 245, 343, 490 and as the A/B arm
+    (FOURIER_NO_REGTILE).  Both against the oracle, all five codes, in place, ragged batch and ragged tiles (column counts without a factor
+    16; f32 units of two columns: a last column by itself), two and three passes; and against each other."""
+    for n, dtype, tol in ((44100, np.complex64, 2e-6), (30870, np.complex64, 2e-6), (20736, np.complex64, 1e-6), (59049, np.complex64, 1e-6),
+                          (13122, np.complex128, 5e-14), (44100, np.complex128, 1e-9), (15625, np.complex128, 1e-9), (1000000, np.complex64, 2e-6)):
+        reg = make(fa, n, dtype)
+        monkeypatch.setenv("FOURIER_NO_REGTILE", "1")
+        lds = make(fa, n, dtype)
+        monkeypatch.delenv("FOURIER_NO_REGTILE")
+        assert "mixed tiles" in reg.describe() and reg.describe() == lds.describe(), (reg.describe(), lds.describe())
+        x = np.stack([hash_normal(800 + b, n) for b in range(3 if n < 100000 else 1)]).astype(dtype)
+        for code in (range(5) if n < 50000 else (0, 1)):
+            ref = oracle.transform_batch(x, code)
+            a, b = run_batch(reg, x, code), run_batch(lds, x, code)
+            assert rel_l2(a, ref) <= tol and rel_l2(b, ref) <= tol, (n, code, rel_l2(a, ref), rel_l2(b, ref))
+            assert rel_l2(a, b) <= (4e-7 if dtype == np.complex64 else 2e-15), (n, code)
+            assert np.array_equal(run_batch(reg, x, code, inplace=True), a), (n, code)
+        if n != 15625:  # (125 = 25 x 5 stays on the LDS kernel: the same plan twice)
+            assert not np.array_equal(run_batch(reg, x, 0), run_batch(lds, x, 0)), n
+
+
 def test_bluestein_fusion_matches_unfused(fa):
     """The fused Bluestein forms (whole chirp-z in one launch for M <= 2^15; chirp steps fused into the
     inner passes above) give the same values, to rounding, as the separate blu_pre / blu_post sweeps
@@ -617,7 +641,8 @@ def test_profile_hook_reports_every_kernel(fa):
 
 def test_lds_layouts_are_bank_conflict_light(fa):
     """Bank-conflict model of MI355X_MICROARCH.md (LDS table) applied to the headline tile (1024-point f32 pass, split planes) and -- round 6 --
-    to the whole-transform (row-mode) kernels and the one-launch chirp-z kernels built on them: total LDS-array cycles within 1.1x of
+    to the whole-transform (row-mode) kernels, the one-launch chirp-z kernels built on them and the register-tile passes of mixed length
+    (exchange planes with rows swapped in the odd planes, odd leading dimension in the staging): total LDS-array cycles within 1.1x of
     conflict-free for the pass, exactly conflict-free for the row-mode swizzle (tools/lds_rows_swizzle_search.py found one per shape; under
     the skew layout of rounds 1 - 5 these were 2.3x (L = 512, 1024) to 6.7x (L = 128), and SQ_LDS_BANK_CONFLICT agreed: 57 % at M = 512)."""
     import subprocess
@@ -632,7 +657,8 @@ def test_lds_layouts_are_bank_conflict_light(fa):
         "import fourier_amd as fa\n"
         "a, b, d = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()\n"
         "for n, real, batch in ((1 << 20, 'f32', 1), (64, 'f32', 32), (128, 'f32', 64), (256, 'f32', 32), (512, 'f32', 32), (1024, 'f32', 16), (128, 'f64', 32), (512, 'f64', 16),\n"
-        "                       (37, 'f32', 32), (97, 'f32', 16), (191, 'f32', 8), (439, 'f32', 4), (97, 'f64', 16), (191, 'f64', 8), (439, 'f64', 8)):\n"
+        "                       (37, 'f32', 32), (97, 'f32', 16), (191, 'f32', 8), (439, 'f32', 4), (97, 'f64', 16), (191, 'f64', 8), (439, 'f64', 8),\n"
+        "                       (44100, 'f32', 2), (48000, 'f32', 2), (20736, 'f64', 2), (100000, 'f64', 1), (16411, 'f32', 2), (10007, 'f64', 2)):\n"
         "    p = (fa.create_fft_f32 if real == 'f32' else fa.create_fft_f64)(n); x = np.ones((batch, n), np.complex64 if real == 'f32' else np.complex128); y = np.empty_like(x)\n"
         "    c.fourier_emu_lds_stats(ctypes.byref(a), ctypes.byref(b), ctypes.byref(d), 1)\n"
         "    p.transform_batch_ptr(x.ctypes.data, y.ctypes.data, batch, 0)\n"
@@ -643,9 +669,11 @@ def test_lds_layouts_are_bank_conflict_light(fa):
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stderr[-2000:]
     rows = [l.split() for l in out.stdout.strip().splitlines() if len(l.split()) == 3]
-    assert len(rows) == 15, out.stdout
-    for n, real, ratio in rows:
+    assert len(rows) == 21, out.stdout
+    for n, real, ratio in rows[:15]:
         assert float(ratio) <= (1.1 if n == str(1 << 20) else 1.0), (n, real, ratio)
+    for n, real, ratio in rows[15:]:  # round 6: the register-tile passes (two-pass plans and the three Bluestein sweeps on a smooth M)
+        assert float(ratio) <= 1.05, (n, real, ratio)
 
 
 def test_lds_mixed_radix_passes_are_bank_conflict_free():

@@ -15,13 +15,6 @@ from fourier_amd import build as B  # noqa: E402
 VARIANTS = {
     "base": [],
     "slp": ["-fslp-vectorize"],
-    "no_regtile": ["-DFOURIER_AB_NO_REGTILE=1"],
-    "chunk0": ["-DFOURIER_TILE_CHUNK=0"],  # round 6 session 24: workgroup -> tile order of the mixed-length tile passes (default: 4 where row segments straddle lines)
-    "chunk2": ["-DFOURIER_TILE_CHUNK=2"],
-    "chunk8": ["-DFOURIER_TILE_CHUNK=8"],
-    "chunk32": ["-DFOURIER_TILE_CHUNK=32"],
-    "chunk4_always": ["-DFOURIER_TILE_CHUNK_ALIGNED=4"],
-    "old_chunk0": ["-DFOURIER_AB_NO_REGTILE=1", "-DFOURIER_TILE_CHUNK=0"],  # round 6 session 21: the mixed-length tile passes on the LDS kernels of rounds 4 - 5 (kernels_tiled.h)
     # ablations (timing only, wrong results): experiments translation units, their templates in the inline namespace `ablated`
     "abl1": ["-DFOURIER_EXPERIMENTS_TU=1", "-DFOURIER_ABLATE=1"],
     "abl2": ["-DFOURIER_EXPERIMENTS_TU=1", "-DFOURIER_ABLATE=2"],
@@ -35,11 +28,6 @@ def groups_of(flags):
     """Translation-unit groups (fourier_amd/build.py) a variant's flags can reach: the LDS mixed-radix knobs touch only the
     'mixed' objects, everything else only the tile / one-launch / small kernels; the other objects come from the base build."""
     g = set()
-    if any("NO_REGTILE" in f or "TILE_CHUNK" in f for f in flags):
-        g |= {"host"}  # a plan-layer choice (engine_tiled.h)
-        flags = [f for f in flags if "NO_REGTILE" not in f and "TILE_CHUNK" not in f]
-        if not flags:
-            return g
     mixed = any("MIX" in f for f in flags)
     other = any("MIX" not in f and not f.startswith("-f") for f in flags)  # a code-generation flag follows the knobs it comes with
     if mixed:
