@@ -265,18 +265,38 @@ template <typename T> class BluTiledEngine {
     }();
     return m;
   }
-  // the smallest M = L1 x L2 >= 2n - 1 (L1 >= L2: the conv kernel, the heavier one, at the shorter length; ties: the more balanced pair); 0: none
+  // M = L1 x L2 >= 2n - 1, L1 >= L2 (the conv kernel, the heavier one, at the shorter length): the smallest product -- or one up to 4 % longer
+  // whose lengths split more evenly into their two register stages: the conv kernel at 243 = 27 x 9 takes 0.83 ms where 240 = 16 x 15 would
+  // take 0.55 (profiles/r06_s31_smooth_m_pruned_ab.jsonl).  0: no product of two tile lengths reaches 2n - 1
   static uint64_t choose_m(size_t n, uint32_t& l1, uint32_t& l2) {
-    uint64_t best = 0;
     const uint64_t need = 2 * (uint64_t)n - 1;
+    uint64_t smallest = 0;
     for (uint32_t a : menu())
       for (uint32_t b : menu()) {
         if (b > a) break;
         const uint64_t m = (uint64_t)a * b;
         if (m < need) continue;
-        if (best == 0 || m < best || (m == best && a < l1)) { best = m; l1 = a; l2 = b; }
+        if (smallest == 0 || m < smallest) smallest = m;
         break;  // larger b only grows m
       }
+    if (smallest == 0) return 0;
+    auto imbalance = [](uint32_t L) {  // r1 / r2 of the length's two register stages, >= 1
+      const RegTileShape t = reg_tile_shape(L, (uint32_t)sizeof(cpx<T>));
+      return (double)t.r1 / (double)t.r2;
+    };
+    uint64_t best = 0;
+    double best_score = 0;
+    for (int relaxed = 0; relaxed < 2 && best == 0; ++relaxed)  // the two lengths within a factor two of each other, if there is such a pair
+      for (uint32_t a : menu())
+        for (uint32_t b : menu()) {
+          if (b > a) break;
+          const uint64_t m = (uint64_t)a * b;
+          if (m < need) continue;
+          if (m * 100 > smallest * 104) break;
+          if (a > 2 * b && !relaxed) continue;
+          const double score = (double)m * (1.0 + 0.10 * (imbalance(b) - 1.0) + 0.03 * (imbalance(a) - 1.0));
+          if (best == 0 || score < best_score) { best = m; best_score = score; l1 = a; l2 = b; }
+        }
     return best;
   }
   BluTiledEngine(size_t n_user, uint32_t l1, uint32_t l2) : n_(n_user), m_((uint64_t)l1 * l2), l1_(l1), l2_(l2) {

@@ -290,19 +290,25 @@ __global__ void __launch_bounds__((RegTileCfg<T, L>::NT)) tiled_reg_kernel(Tiled
   cpx<T> x[VEC][R1];
   if (q < R2) {
     const uint32_t voff = (uint32_t)((col0 + c + row_stride * (uint64_t)q) * EB), rowb = (uint32_t)(row_stride * (uint64_t)R2 * EB);
+    // (chirp-in: 2N <= M + 1, so every row from L / 2 + 1 on is padding -- rows q + R2 * j1 with R2 * j1 beyond that are compile-time zeros,
+    // never loaded and folded out of the first transform; the descriptor zeroes what is left of the padding)
+    auto pad = [](uint32_t j1) { return IO == IO_BLU_IN && R2 * j1 >= L / 2 + 1; };
     Unit16<T> d[R1];
 #pragma unroll
-    for (uint32_t j1 = 0; j1 < R1; ++j1) d[j1] = buf_load_unit<T>(rin, voff + j1 * rowb);
+    for (uint32_t j1 = 0; j1 < R1; ++j1)
+      if (!pad(j1)) d[j1] = buf_load_unit<T>(rin, voff + j1 * rowb);
     if constexpr (IO == IO_BLU_IN) {
       // work = x (.) in, zero padded (bluesteins.rs:229-234): element e = column + m * row of the user array and of the chirp table
       const BufRsrc rc = make_rsrc(a.blu_x, (uint32_t)(a.blu_n * EB));
       Unit16<T> ch[R1];
 #pragma unroll
-      for (uint32_t j1 = 0; j1 < R1; ++j1) ch[j1] = buf_load_unit<T>(rc, voff + j1 * rowb);
+      for (uint32_t j1 = 0; j1 < R1; ++j1)
+        if (!pad(j1)) ch[j1] = buf_load_unit<T>(rc, voff + j1 * rowb);
 #pragma unroll
       for (uint32_t j1 = 0; j1 < R1; ++j1)
 #pragma unroll
         for (uint32_t v = 0; v < VEC; ++v) {
+          if (pad(j1)) { x[v][j1] = cpx<T>{(T)0, (T)0}; continue; }
           cpx<T> val{d[j1].a[2 * v], d[j1].a[2 * v + 1]};
           if (a.blu_swap) val = {val.im, val.re};
           x[v][j1] = cmul(cpx<T>{ch[j1].a[2 * v], ch[j1].a[2 * v + 1]}, val);
@@ -329,7 +335,8 @@ __global__ void __launch_bounds__((RegTileCfg<T, L>::NT)) tiled_reg_kernel(Tiled
       const BufRsrc rc = make_rsrc(a.blu_x, (uint32_t)(a.blu_n * EB));
       const uint32_t voff = (uint32_t)(((uint64_t)c0 + c + a.s * (uint64_t)q) * EB), rowb = (uint32_t)(a.s * (uint64_t)R1 * EB);
 #pragma unroll
-      for (uint32_t k2 = 0; k2 < R2; ++k2) chq[k2] = buf_load_unit<T>(rc, voff + k2 * rowb);
+      for (uint32_t k2 = 0; k2 < R2; ++k2)
+        if (R1 * k2 < L / 2 + 1) chq[k2] = buf_load_unit<T>(rc, voff + k2 * rowb);  // (outputs k = q + R1 * k2 from L / 2 + 1 on lie beyond the user array)
     }
   }
   if (q < R2) {
@@ -381,6 +388,7 @@ __global__ void __launch_bounds__((RegTileCfg<T, L>::NT)) tiled_reg_kernel(Tiled
 #pragma unroll
       for (uint32_t k2 = 0; k2 < R2; ++k2) {
         if constexpr (IO == IO_BLU_OUT) {
+          if (R1 * k2 >= L / 2 + 1) continue;  // 2N <= M + 1: beyond the user array, never stored
 #pragma unroll
           for (uint32_t v = 0; v < VEC; ++v) {
             cpx<T> z = cmul(y[v][k2], cpx<T>{chq[k2].a[2 * v], chq[k2].a[2 * v + 1]});

@@ -243,11 +243,11 @@ template <typename T> class Plan {
     }
     // Bluestein's M: 1 (default) = the smallest product of two tile lengths where that saves a quarter of the power-of-two work array,
     // 0 = always the reference's next power of two (bluesteins.rs:110).  Rebuilds the plan's tables now; not while a transform is in flight.
-    if (key == "bluestein_smooth_m" && (v == 0 || v == 1)) {
+    if (key == "bluestein_smooth_m" && v >= 0 && v <= 2) {  // (2: wherever a product of two tile lengths exists -- for measurements)
       if (!blu_) return ::fourier::c::FOURIER_HIP_INVALID_ARGUMENT;
-      if ((v == 1) != smooth_m_allowed_) {
+      if ((int)v != smooth_m_mode_) {
         HIP_CHECK(hipDeviceSynchronize());
-        smooth_m_allowed_ = (v == 1);
+        smooth_m_mode_ = (int)v;
         blut_.reset(); eng_.reset(); eng_inv_.reset();
         init_bluestein();
         if (reference_chirp_) { build_chirp_tables(true); chirp_compute_saved_ = chirp_compute_; chirp_compute_ = false; }
@@ -641,14 +641,13 @@ template <typename T> class Plan {
     if (2 * n_ > m_) throw EngineError(::fourier::c::FOURIER_HIP_RUNTIME_ERROR, "Bluestein: M < 2N");  // the fused end passes rely on it
     fused_ = small_fused_ = conv_ = conv_ok_ = chirp_compute_ = false;
     // M need only reach 2N - 1 (bluesteins.rs:110 rounds up to a power of two: up to 4N).  Beyond the one-launch kernels (M <= 2^15, f64 2^14)
-    // the work array is swept three times: the smallest product of two register-tile lengths instead, where the power-of-two array is at
-    // least 1.75 x (f64: 1.6 x) longer -- f32 +2 ... 33 %, f64 +12 ... 43 % there; below that the power-of-two tiles' higher rate wins (1.63 x:
-    // f32 -7 ... +12 %; 1.35 x: -5 ... -15 %), and so it does where the f64 conv kernel would run at more than 336 points (out of registers: -11 %)
-    // (profiles/r06_s29_smooth_m_units_ab.jsonl)
-    if (smooth_m_allowed_ && !dev_env("FOURIER_NO_SMOOTH_M") && m_ > ((size_t)1 << (sizeof(T) == 4 ? 15 : 14))) {
+    // the work array is swept three times: a product of two register-tile lengths instead, where the power-of-two array is at least 1.6 x
+    // longer -- f32 +4 ... 32 %, f64 +18 ... 46 % there; below that the power-of-two tiles' higher rate wins (1.49 x: -12 ... +5 %; 1.35 x: -10 ...
+    // +2 %; profiles/r06_s31_smooth_m_pruned_ab.jsonl)
+    if (smooth_m_mode_ != 0 && !dev_env("FOURIER_NO_SMOOTH_M") && m_ > ((size_t)1 << (sizeof(T) == 4 ? 15 : 14))) {
       uint32_t l1 = 0, l2 = 0;
       const uint64_t ms = BluTiledEngine<T>::choose_m(n_, l1, l2);
-      const bool pays = sizeof(T) == 4 ? 7 * ms <= 4 * (uint64_t)m_ : (8 * ms <= 5 * (uint64_t)m_ && l2 <= 336);
+      const bool pays = smooth_m_mode_ == 2 || 8 * ms <= 5 * (uint64_t)m_;
       if (ms != 0 && pays) {
         m_ = ms;
         blut_.reset(new BluTiledEngine<T>(n_, l1, l2));
@@ -799,7 +798,7 @@ template <typename T> class Plan {
   bool blu_ = false;
   std::unique_ptr<Pow2Engine<T>> eng_, eng_inv_;  // eng_inv_: mirrored inverse plan of a conv-fused Bluestein
   std::unique_ptr<BluTiledEngine<T>> blut_;       // Bluestein on a smooth M (then eng_ is empty)
-  bool smooth_m_allowed_ = true;                  // option "bluestein_smooth_m"
+  int smooth_m_mode_ = 1;                         // option "bluestein_smooth_m"
   std::unique_ptr<MixedEngine<T>> mix_;
   std::unique_ptr<TiledMixedEngine<T>> tiled_;  // 2^a*3^b, a < 12, beyond the LDS kernels: column tiles of mixed length
   std::unique_ptr<GenericEngine<T>> gen_;  // ... and what has no tile factorisation: one global pass per radix

@@ -377,12 +377,12 @@ def test_bluestein_chirp_in_pass_computes_the_chirp(fa, oracle):
 
 def test_bluestein_on_a_smooth_work_array(fa, oracle):
     """Round 6: M need only reach 2N - 1 (bluesteins.rs:110; the reference rounds up to a power of two).  Where the power-of-two work array
-    is at least 1.75 x (f64: 1.6 x) longer than the smallest product of two register-tile lengths, the three sweeps run on that product
-    (kernels_regtile.h: chirp-in first pass, conv, chirp-out last pass).  All five codes against the oracle, in place, a ragged batch; the plan
+    is at least 1.6 x longer than a product of two register-tile lengths (the smallest, or one up to 4 % longer whose lengths split more
+    evenly into their register stages), the three sweeps run on that product (kernels_regtile.h: chirp-in first pass, conv, chirp-out last pass).  All five codes against the oracle, in place, a ragged batch; the plan
     option brings the power-of-two route back and both agree; the reference's chirp angle on request."""
     for n, dtype, desc, tol in ((16411, np.complex64, "bluestein M=32928 inner mixed tiles 196x168", 2e-6),
-                                (10007, np.complex128, "bluestein M=20160 inner mixed tiles 144x140", 5e-11),
-                                (32771, np.complex128, "bluestein M=65610 inner mixed tiles 270x243", 5e-11)):
+                                (10007, np.complex128, "bluestein M=20160 inner mixed tiles 168x120", 5e-11),
+                                (32771, np.complex128, "bluestein M=65856 inner mixed tiles 336x196", 5e-11)):
         plan = make(fa, n, dtype)
         assert desc in plan.describe(), plan.describe()
         x = np.stack([hash_normal(40 + b, n) for b in range(3)]).astype(dtype)
@@ -407,7 +407,7 @@ def test_bluestein_on_a_smooth_work_array(fa, oracle):
     x = np.stack([hash_normal(50 + b, 10007) for b in range(2)]).astype(np.complex128)
     for code in (0, 1):
         assert rel_l2(run_batch(plan, x, code), oracle.transform_batch(x, code)) <= 5e-15, code
-    # lengths just below a power of two (M / M_smooth < 1.75 / 1.6) and every M within the one-launch kernels keep the power of two
+    # lengths just below a power of two (M / M_smooth < 1.6) and every M within the one-launch kernels keep the power of two
     assert "mixed tiles" not in make(fa, 24001, np.complex64).describe() and "mixed tiles" not in make(fa, 5003, np.complex128).describe()
     with pytest.raises(fa.FourierError):
         make(fa, 4096, np.complex64).set_option("bluestein_smooth_m", 0)

@@ -1402,14 +1402,14 @@ def test_plan_option_specialise_compiles_the_lengths_own_kernel_with_hiprtc(torc
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,dtype,desc,tol", [(16411, np.complex64, "M=32928 inner mixed tiles 196x168", 2e-6), (65537, np.complex64, "M=131220 inner mixed tiles 405x324", 2e-6),
-                                              (70001, np.complex64, "M=140625 inner mixed tiles 375x375", 2e-6), (18221, np.complex64, "mixed tiles", 2e-6),
-                                              (8209, np.complex128, "M=16464 inner mixed tiles", 5e-11), (10007, np.complex128, "M=20160 inner mixed tiles 144x140", 5e-11),
-                                              (20011, np.complex128, "M=40320 inner mixed tiles 210x192", 5e-11), (40001, np.complex128, "M=80640 inner mixed tiles 288x280", 5e-11),
-                                              (65537, np.complex128, "M=131220 inner mixed tiles 405x324", 1e-10)])
+                                              (70001, np.complex64, "inner mixed tiles", 2e-6), (18221, np.complex64, "inner mixed tiles", 2e-6), (40001, np.complex64, "inner mixed tiles", 2e-6),
+                                              (8209, np.complex128, "inner mixed tiles", 5e-11), (10007, np.complex128, "M=20160 inner mixed tiles 168x120", 5e-11),
+                                              (20011, np.complex128, "M=40320 inner mixed tiles", 5e-11), (40001, np.complex128, "inner mixed tiles", 5e-11),
+                                              (65537, np.complex128, "M=131220 inner mixed tiles 405x324", 1e-10), (80021, np.complex128, "inner mixed tiles", 1e-10)])
 def test_bluestein_on_a_smooth_work_array(torch, fa, oracle, n, dtype, desc, tol):
     """Round 6: Bluestein's M need only reach 2N - 1 (bluesteins.rs:110; the reference rounds up to a power of two, up
-    to 4N).  Where the power-of-two work array is swept three times and is at least 1.75 x (f64: 1.6 x) longer, the plan takes the smallest
-    product of two tile lengths and runs the same three sweeps on register tiles (kernels_regtile.h): every code against the oracle and the
+    to 4N).  Where the power-of-two work array is swept three times and is at least 1.6 x longer, the plan takes a product of two tile
+    lengths (the smallest, or one up to 4 % longer that splits more evenly) and runs the same three sweeps on register tiles (kernels_regtile.h): every code against the oracle and the
     f64 truth, in place, a ragged batch, against the power-of-two route (plan option bluestein_smooth_m = 0) and back."""
     plan, pow2 = make(fa, n, dtype), make(fa, n, dtype)
     assert "bluestein" in plan.describe() and desc in plan.describe(), plan.describe()
@@ -1438,10 +1438,10 @@ def test_bluestein_on_a_smooth_work_array(torch, fa, oracle, n, dtype, desc, tol
 
 @pytest.mark.gpu
 def test_bluestein_smooth_work_array_only_where_it_pays(torch, fa):
-    """Lengths just below a power of two (M / M_smooth below 1.75, f64 1.6), every M the one-launch kernels hold, and f64 lengths whose conv
-    kernel would run beyond 336 points keep the reference's power of two; the option is refused on plans that are not Bluestein."""
-    for n, dtype in ((24001, np.complex64), (40001, np.complex64), (100003, np.complex64), (5003, np.complex128), (12289, np.complex128),
-                     (70001, np.complex128), (999983, np.complex64)):
+    """Lengths just below a power of two (M / M_smooth below 1.6), every M the one-launch kernels hold and lengths beyond the products of two
+    tile lengths (M > 512 x 512) keep the reference's power of two; the option is refused on plans that are not Bluestein."""
+    for n, dtype in ((24001, np.complex64), (44017, np.complex64), (100003, np.complex64), (5003, np.complex128), (12289, np.complex128),
+                     (90001, np.complex128), (999983, np.complex64)):
         d = make(fa, n, dtype).describe()
         assert "bluestein" in d and "mixed tiles" not in d, (n, d)
     with pytest.raises(fa.FourierError):

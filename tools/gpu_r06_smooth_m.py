@@ -23,6 +23,7 @@ def main():
             ref = torch.fft.fft(x[:32].to(torch.complex128), dim=1)
             make = F.create_fft_f32 if real == "f32" else F.create_fft_f64
             plans = [("smooth", make(n, 0), []), ("pow2", make(n, 0), [])]
+            plans[0][1].set_option("bluestein_smooth_m", 2 if os.environ.get("SMOOTH_FORCE") else 1)  # 2: wherever a product of two tile lengths exists
             plans[1][1].set_option("bluestein_smooth_m", 0)
             if plans[0][1].describe() == plans[1][1].describe():
                 print(json.dumps(dict(real=real, n=n, plan=plans[0][1].describe(), note="same route")), flush=True)
