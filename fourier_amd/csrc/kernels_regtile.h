@@ -150,6 +150,8 @@ template <typename T, uint32_t L> struct RegTileCfg {  // the rules: reg_tile_sh
   static constexpr uint32_t XSU = R2 * CU;                                          // units between the k1 planes of the exchange buffer
   static constexpr size_t TAB_OFF = S.tab_off, SMEM = S.smem;
 };
+// (no register bound in the launch bounds: hipcc spreads these kernels over up to 256 registers, two workgroups per CU where the LDS would hold
+// three -- bounds that aim at three or four spill in 79 / 120 of the 560 instantiations and lose up to 67 %, profiles/r06_s34_regtile_budget_ab.jsonl)
 
 // the two halves of an inter-pass twiddle table build (W_size^{i * k} from the two-level tables, k = r for r < RA, RA * (r - RA) beyond): the
 // global loads first, the products and LDS writes once the data loads are under way
@@ -329,16 +331,19 @@ __global__ void __launch_bounds__((RegTileCfg<T, L>::NT)) tiled_reg_kernel(Tiled
   RegTileTabs<T, R1, R2, COLS, NT> tabs;
   const uint32_t tcols = first ? COLS : 1u;  // the later passes have one i for the whole tile: table column 0
   if (twiddled) tabs.load(a, tid, tcols, first, c0, ncols_total, i_row);
-  Unit16<T> chq[R2];  // chirp-out: the chirp at the thread's outputs
-  if constexpr (IO == IO_BLU_OUT) {
-    if (q < R1) {
-      const BufRsrc rc = make_rsrc(a.blu_x, (uint32_t)(a.blu_n * EB));
-      const uint32_t voff = (uint32_t)(((uint64_t)c0 + c + a.s * (uint64_t)q) * EB), rowb = (uint32_t)(a.s * (uint64_t)R1 * EB);
+  Unit16<T> chq[R2];  // chirp-out: the chirp at the thread's outputs, needed after stage B's transform (f64: loaded before the barrier, f32: with the data -- see the conv kernel)
+  auto load_chq = [&]() {
+    if constexpr (IO == IO_BLU_OUT) {
+      if (q < R1) {
+        const BufRsrc rc = make_rsrc(a.blu_x, (uint32_t)(a.blu_n * EB));
+        const uint32_t voff = (uint32_t)(((uint64_t)c0 + c + a.s * (uint64_t)q) * EB), rowb = (uint32_t)(a.s * (uint64_t)R1 * EB);
 #pragma unroll
-      for (uint32_t k2 = 0; k2 < R2; ++k2)
-        if (R1 * k2 < L / 2 + 1) chq[k2] = buf_load_unit<T>(rc, voff + k2 * rowb);  // (outputs k = q + R1 * k2 from L / 2 + 1 on lie beyond the user array)
+        for (uint32_t k2 = 0; k2 < R2; ++k2)
+          if (R1 * k2 < L / 2 + 1) chq[k2] = buf_load_unit<T>(rc, voff + k2 * rowb);  // (outputs k = q + R1 * k2 from L / 2 + 1 on lie beyond the user array)
+      }
     }
-  }
+  };
+  if constexpr (sizeof(T) == 4) load_chq();
   if (q < R2) {
 #pragma unroll
     for (uint32_t v = 0; v < VEC; ++v) {
@@ -351,6 +356,7 @@ __global__ void __launch_bounds__((RegTileCfg<T, L>::NT)) tiled_reg_kernel(Tiled
     O::template xch_write<R1, R2>(bufu, x, q, cu, 300);
   }
   if (twiddled) tabs.store(tid, tcols, tu, tv);
+  if constexpr (sizeof(T) == 8) load_chq();
   __syncthreads();
 
   // ---- stage B: the R2 values of (unit, k1 = q); output k = k1 + R1*k2
@@ -454,10 +460,19 @@ __global__ void __launch_bounds__((RegTileCfg<T, L>::NT)) tiled_reg_conv_kernel(
     const cpx<T>* tw = (const cpx<T>*)a.tw + q * R2;
 #pragma unroll
     for (uint32_t j2 = 1; j2 < R2; ++j2) w[j2] = tw[j2];
-    const uint32_t voff = (uint32_t)(((uint64_t)c0 + c + a.s * (uint64_t)q) * EB), rowb = (uint32_t)(a.s * (uint64_t)R1 * EB);
-#pragma unroll
-    for (uint32_t k2 = 0; k2 < R2; ++k2) ww[k2] = buf_load_unit<T>(rw, voff + k2 * rowb);
   }
+  // w is needed after stage B's transform.  f64: loaded before the barrier, not with the data -- R2 units (4 registers each) fewer held through
+  // stage A, the conv kernel of 324 points no longer spills into AGPRs (N = 75011: +4 -> +28 % over the power-of-two route); f32: with the data
+  // (late: -3 ... 7 % at the long tiles) -- profiles/r06_s35_smooth_m_late_loads_ab.jsonl against r06_s32_*
+  constexpr bool LATE = sizeof(T) == 8;
+  auto load_w = [&]() {
+    if (q < R1) {
+      const uint32_t voff = (uint32_t)(((uint64_t)c0 + c + a.s * (uint64_t)q) * EB), rowb = (uint32_t)(a.s * (uint64_t)R1 * EB);
+#pragma unroll
+      for (uint32_t k2 = 0; k2 < R2; ++k2) ww[k2] = buf_load_unit<T>(rw, voff + k2 * rowb);
+    }
+  };
+  if constexpr (!LATE) load_w();
   RegTileTabs<T, R2, R1, COLS, NT> tabs;  // the inverse first pass: i = c0 + column, output k'' = k1'' + R2 * k2''
   tabs.load(a, tid, COLS, true, c0, ncols_total, 0u);
   if (q < R2) {
@@ -466,6 +481,7 @@ __global__ void __launch_bounds__((RegTileCfg<T, L>::NT)) tiled_reg_conv_kernel(
     O::template xch_write<R1, R2>(bufu, x, q, cu, 310);
   }
   tabs.store(tid, COLS, tu, tv);
+  if constexpr (LATE) load_w();
   __syncthreads();
 
   // ---- stage B, (.) w, swap; stage A' of the inverse first pass on the same threads

@@ -642,12 +642,13 @@ template <typename T> class Plan {
     fused_ = small_fused_ = conv_ = conv_ok_ = chirp_compute_ = false;
     // M need only reach 2N - 1 (bluesteins.rs:110 rounds up to a power of two: up to 4N).  Beyond the one-launch kernels (M <= 2^15, f64 2^14)
     // the work array is swept three times: a product of two register-tile lengths instead, where the power-of-two array is at least 1.6 x
-    // longer -- f32 +4 ... 32 %, f64 +18 ... 46 % there; below that the power-of-two tiles' higher rate wins (1.49 x: -12 ... +5 %; 1.35 x: -10 ...
-    // +2 %; profiles/r06_s31_smooth_m_pruned_ab.jsonl)
+    // longer -- f32 +3 ... 43 %, f64 +20 ... 51 % there -- and in f64 from 1.44 x on while the conv kernel stays within 336 points (+5 ... 11 %;
+    // beyond: -8 %).  Below that the power-of-two tiles' higher rate wins (f32 1.49 x: -7 ... -2 %; 1.35 x: -5 ... -1 %; f64 1.35 x: 0 ... +3 %;
+    // profiles/r06_s35_smooth_m_late_loads_*.jsonl)
     if (smooth_m_mode_ != 0 && !dev_env("FOURIER_NO_SMOOTH_M") && m_ > ((size_t)1 << (sizeof(T) == 4 ? 15 : 14))) {
       uint32_t l1 = 0, l2 = 0;
       const uint64_t ms = BluTiledEngine<T>::choose_m(n_, l1, l2);
-      const bool pays = smooth_m_mode_ == 2 || 8 * ms <= 5 * (uint64_t)m_;
+      const bool pays = smooth_m_mode_ == 2 || 8 * ms <= 5 * (uint64_t)m_ || (sizeof(T) == 8 && 36 * ms <= 25 * (uint64_t)m_ && l2 <= 336);
       if (ms != 0 && pays) {
         m_ = ms;
         blut_.reset(new BluTiledEngine<T>(n_, l1, l2));

@@ -110,7 +110,7 @@ enum {
  *   prime factors up to 13, no route above, and     "stockham mixed-radix ... specialised" / "stockham mixed tiles ... specialised": kernels
  *     its run-time kernels in the code-object cache   compiled by an earlier "specialise" (below) -- see fourier_hip_set_default_option
  *   every other length                              "bluestein M=<M> inner <power-of-two plan>[ fused]": chirp-z over a power-of-two transform
- *                                                   (bluesteins.rs:110), or -- round 6, where that work array is at least 1.6 x longer and is
+ *                                                   (bluesteins.rs:110), or -- round 6, where that work array is at least 1.6 x (f64: 1.44 x) longer and is
  *                                                   swept three times (M > 2^15, f64 2^14) -- "bluestein M=<L1*L2> inner mixed tiles
  *                                                   <L1>x<L2>": the same chirp-z over a product of two tile lengths >= 2N - 1
  *                                                   (plan option "bluestein_smooth_m" = 0 brings the power of two back)
@@ -193,7 +193,8 @@ const char *fourier_hip_status_string(int status);
  *                  transformed chirp and the inverse inner FFT's first pass run as one launch
  *   "bluestein_smooth_m" 1 (default) = a Bluestein plan whose power-of-two work array would be swept three times takes M = L1 x L2, a
  *                  product of two tile lengths (64 ... 512, prime factors up to 7; the smallest that reaches 2N - 1, or one up to 4 % longer
- *                  whose lengths split more evenly into register stages), where that is at least 1.6 x shorter (N = 16411: M = 32928 =
+ *                  whose lengths split more evenly into register stages), where that is at least 1.6 x shorter (f64: 1.44 x while the middle sweep's
+ *                  tile stays within 336 points) (N = 16411: M = 32928 =
  *                  196 x 168 instead of 65536, f32 +39 %, f64 +53 %; N = 10007 f64: 20160 instead of 32768, +31 %); 0 = always the
  *                  reference's next power of two (bluesteins.rs:110); 2 = wherever such a product exists (measurements).  Rebuilds the plan's tables when the value changes (not while a
  *                  transform is in flight on the handle); INVALID_ARGUMENT on a plan that is not Bluestein.  Same tolerance class.
