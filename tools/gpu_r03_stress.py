@@ -22,12 +22,14 @@ smooth13 = sorted(v for v in _smooth(18432, [2, 3, 5, 7, 11, 13]) if any(v % p =
 # round 5: lengths with factors 5 / 7 beyond the LDS kernels (ahead-of-time tile passes): a random 120 of the 7-smooth lengths up to 3e6
 smooth7_big = sorted(v for v in _smooth(3_000_000, [2, 3, 5, 7]) if v > 8192 and (v % 5 == 0 or v % 7 == 0))
 smooth7_big = sorted({int(v) for v in rng.choice(smooth7_big, size=min(120, len(smooth7_big)), replace=False)})
+# round 6: lengths whose Bluestein plan takes a product of two tile lengths for M (just above a power of two: M_pow2 / M >= 1.44 ... 1.6), 60 of them
+smooth_m = sorted({int(v) for k in range(13, 17) for v in rng.integers((1 << k) + 1, int(1.27 * (1 << k)), 15)})
 others = sorted({int(v) for v in np.concatenate([rng.integers(2, 5000, 150), rng.integers(5000, 200000, 80), rng.integers(200000, 3000000, 25)])})
 worst = {}
 fails = 0
 t0 = time.time()
 count = 0
-for n in smooth + smooth13 + smooth7_big + others:
+for n in smooth + smooth13 + smooth7_big + smooth_m + others:
     for dtype, tol in ((np.complex64, 2e-6), (np.complex128, 1e-9 if n > 100000 else 5e-11)):
         if dtype == np.complex128 and rng.random() < 0.5:
             continue
@@ -43,7 +45,7 @@ for n in smooth + smooth13 + smooth7_big + others:
         got = o.cpu().numpy()
         ref = O.transform_batch(x, code)
         err = float(np.linalg.norm(got.astype(np.complex128) - ref) / max(np.linalg.norm(ref), 1e-300))
-        fam = plan.describe().split()[0] + " " + plan.describe().split()[1][:12]
+        fam = plan.describe().split()[0] + " " + plan.describe().split()[1][:12] + (" smooth M" if "bluestein" in plan.describe() and "mixed tiles" in plan.describe() else "")
         worst[(fam, dtype.__name__)] = max(worst.get((fam, dtype.__name__), 0.0), err)
         count += 1
         if not (err <= tol):
