@@ -402,6 +402,8 @@ def test_bluestein_on_a_smooth_work_array(fa, oracle):
         pow2.set_option("bluestein_smooth_m", 1)  # ... and back
         assert pow2.describe() == plan.describe()
         assert np.array_equal(run_batch(pow2, x, 0), run_batch(plan, x, 0))
+        pow2.set_option("chunk_bytes", 2 * n * x.itemsize)  # chunks of one transform (work array and scratch of one chunk): the same bits
+        assert np.array_equal(run_batch(pow2, x, 0), run_batch(plan, x, 0)) and np.array_equal(run_batch(pow2, x, 1, inplace=True), run_batch(plan, x, 1))
     plan = make(fa, 10007, np.complex128)
     plan.set_option("bluestein_reference_chirp", 1)
     x = np.stack([hash_normal(50 + b, 10007) for b in range(2)]).astype(np.complex128)
