@@ -43,6 +43,7 @@ static inline void host_fft_any(std::vector<double>& re, std::vector<double>& im
   while (cur > 1) {
     size_t p = 2;
     while (cur % p) ++p;
+    if (p > 16) throw EngineError(::fourier::c::FOURIER_HIP_RUNTIME_ERROR, "host_fft_any: a prime factor above 16");  // (tile lengths: up to 7)
     const size_t mm = cur / p;
     std::vector<double> wr(p * p), wi(p * p);
     for (size_t e = 0; e < p * p; ++e) unit_root(e % p, p, wr[e], wi[e]);  // W_p^{r*k} at [r * p + k] via (r*k) % p below
