@@ -15,20 +15,31 @@ constexpr uint32_t FOURIER_TILE_CHUNK = 8, FOURIER_TILE_CHUNK_ALIGNED = 0;
 template <typename T> class TiledMixedEngine {
  public:
   static constexpr size_t MAX_N = (size_t)1 << 26;
+  // every length with an ahead-of-time kernel: prime factors up to 7 (kernels_regtile.cpp, kernels_tiled.cpp); without the register-tile kernels
+  // (FOURIER_NO_REGTILE: experiments library, emulator) the LDS kernels' lengths alone, up to 512 points
   static const std::vector<uint32_t>& menu() {
-    static const std::vector<uint32_t> m = [] {
+    static const std::vector<uint32_t> with_reg = [] {
       std::vector<uint32_t> v;
-      for (uint32_t L = 64; L <= 512; ++L)  // every length with an ahead-of-time kernel: prime factors up to 7 (kernels_tiled.cpp)
+      for (uint32_t L = 64; L <= max_len(false); ++L)
+        if (get_regtile_kernel(Real<T>{}, L).fn || get_tiled_kernel(Real<T>{}, L).fn) v.push_back(L);
+      return v;
+    }();
+    static const std::vector<uint32_t> lds_only = [] {
+      std::vector<uint32_t> v;
+      for (uint32_t L = 64; L <= 512; ++L)
         if (get_tiled_kernel(Real<T>{}, L).fn) v.push_back(L);
       return v;
     }();
-    return m;
+    return dev_env("FOURIER_NO_REGTILE") ? lds_only : with_reg;
   }
   // longest tile pass: 512 points ahead of time; 1024 for a kernel compiled at run time (a 16-column f32 / 8-column f64 tile of 1024 rows is
   // 128 KiB of LDS, one 1024-thread workgroup per CU: 2.4 - 3.2 TB/s per pass against 4.2 - 4.9 for the short tiles -- level with a three-pass
   // plan of short tiles, but it reaches lengths that have no split into factors of 64 ... 512 at all: 5^8 = 625 x 625 15 % of the HBM peak
   // against 9 % as Bluestein, 500000 = 800 x 625 18 % against 11 %, profiles/r05_s21_long_tiles_ab.jsonl)
-  static uint32_t max_len(bool rtc) { return rtc ? 1024u : 512u; }
+  // (ahead of time: 512 points for the LDS kernels; 28 lengths of 513 ... 1024 points run on register tiles of 64-byte rows, round 6)
+  // 390625 = 625 x 625: 0.09 (Bluestein) -> 0.26; 500000 = 800 x 625: 0.11 -> 0.24; 640000, 729000 (three passes of 80 ... 100 points before):
+  // +28 ... 52 % (profiles/r06_s40_long_tiles_ab.jsonl)
+  static uint32_t max_len(bool rtc) { (void)rtc; return 1024u; }
   // every length a tile pass can have once it is compiled at run time (plan option "specialise"): prime factors up to 13
   static const std::vector<uint32_t>& menu_rtc() {
     static const std::vector<uint32_t> m = [] {

@@ -212,7 +212,9 @@ constexpr RegTileShape reg_tile_shape(uint32_t L, uint32_t elem) {
   // (125 = 25 x 5: 40 of 256 threads transform in stage A -- f64 15625 = 125 x 125 0.26 against 0.31 on the LDS kernel, r06_s25)
   if (r2 == 0 || L / r2 > 4u * r2) return t;
   t.r1 = L / r2; t.r2 = r2;
-  t.cols = 128u / elem;  // (256-byte segments: -26 ... +5 %, profiles/r06_s38_regtile_wide_ab.jsonl)
+  // 128-byte row segments (256-byte ones: -26 ... +5 %, profiles/r06_s38_regtile_wide_ab.jsonl); 64-byte ones beyond 512 points: the tile stays
+  // within 64 KiB of LDS, two workgroups per CU
+  t.cols = (L > 512u ? 64u : 128u) / elem;
   t.threads = (t.cols / (16u / elem) * t.r1 + 63u) & ~63u;
   // stage B reads plane k1 = tid / COLS at j2 * COLS + c: the two (f64: four) planes a lane group of a ds_read touches must differ by an
   // odd number of 128-byte row segments -- R2 odd, or (R2 even) rows j2 and j2 ^ 1 exchanged in the odd planes (reg_tile_row); no padding

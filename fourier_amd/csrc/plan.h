@@ -91,7 +91,8 @@ template <typename T> class Plan {
       if (sizeof(T) == 4 && n == ((size_t)1 << 20) && !dev_env("FOURIER_NO_BAND_WALK")) nxcd_ = 8u | (4u << 8) | (8u << 12);
     } else if (tiled_before_pow2_tiles(n)) {
       // 2^a * 3^b with a >= 12 as TWO mixed-length tile passes instead of power-of-two tiles + odd passes (three or four round
-      // trips): 1 - 25 % faster up to 384 x 384, slower from 512 x 432 on (profiles/r04_s8_pow2_tiles_plus_odd_passes_vs_mixed_tiles_ab.jsonl)
+      // trips).  Round 6, register tiles: 512 x 384 +25 %, 512 x 432 +26 ... 41 %, 576 x 576 +34 ... 50 %; 768 x 576 level, 768 x 768 -3 ... 5 %,
+      // 1024 x 768 / 864 f32 -13 ... 17 % (profiles/r06_s40_long_tiles_ab.jsonl; the LDS tile passes of round 4 paid up to 384 x 384 only)
       tiled_.reset(new TiledMixedEngine<T>(n));
     } else if (Pow2Engine<T>::handles_mixed(n)) {
       // big-radix passes over the 2^a part (a >= 12), then a radix-3^b pass: three HBM round trips at full tile
@@ -152,7 +153,7 @@ template <typename T> class Plan {
   static bool tiled_before_pow2_tiles(size_t n) {
     if (!Pow2Engine<T>::handles_mixed(n) || dev_env("FOURIER_POW2_TILES_FIRST") || !TiledMixedEngine<T>::handles(n, true)) return false;
     const std::vector<uint32_t> f = TiledMixedEngine<T>::factorise(n);
-    return f.size() == 2 && f[0] <= 384 && f[1] <= 384;
+    return f.size() == 2 && f[0] <= 576 && f[1] <= 576;
   }
   // the longest LDS plans ask for the whole 160 KiB of a CU: where the runtime refuses, the next route takes the length
   bool try_mixed(size_t n) {

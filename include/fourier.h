@@ -95,18 +95,19 @@ enum {
  *   powers of two                                   "stockham <L1>[x<L2>[x<L3>]]", "stockham <L1>x<L2> one-launch", "stockham tiny(<n>)":
  *                                                   big-radix Stockham passes, one, two or three HBM round trips
  *   2^a * 3^b, a >= 12, N = L1 x L2 with both tile  "stockham mixed tiles <L1>x<L2>": two column-tile passes of mixed length
- *     lengths <= 384 (12288 ... 147456)
+ *     lengths <= 576 (12288 ... 331776)
  *   2^a * 3^b, a >= 12, every other length          "stockham <L1>x...x<27|9|3>": the power-of-two passes over 2^a, then radix-27 / 9 / 3 passes
  *   2^a * 3^b * 5^c * 7^d * 11^e * 13^f that fit    "stockham mixed-radix <r1>.<r2>...." (+ " specialised" for a kernel compiled at run time):
  *     one compute unit's LDS (<= 20480 points in    every 2^a * 3^b; every such length with factors 5 (and the instantiated ones with a
  *     f32, 10240 in f64) AND have a kernel          factor 7) has a per-length kernel; any other length of this family up to 8192 points runs
  *                                                   the runtime-parameterised kernel (f64 with a factor 11 or 13: up to 2048 points)
  *   2^a * 3^b, a < 12, beyond the LDS limit, with   "stockham mixed tiles <L1>x<L2>[x<L3>]": two or three column-tile passes of mixed length
- *     N = L1 x L2 (x L3), every L in 64 ... 512
- *   2^a * 3^b, a < 12, without such a factorisation "stockham global-pass <r1>.<r2>....": one Stockham pass per radix in global memory
+ *     N = L1 x L2 (x L3), every L in 64 ... 1024
+ *   2^a * 3^b, a < 12, without such a factorisation "stockham global-pass <r1>.<r2>....": one Stockham pass per radix in global memory (since round 6,
+ *                                                   tile lengths up to 1024, no accepted length is left without one: the fallback)
  *   2^a * 3^b * 5^c * 7^d with c + d >= 1 beyond    "stockham mixed tiles <L1>x<L2>[x<L3>]" (round 5; 10^5 = 400x250, 44100 = 210x210,
- *     the LDS kernels, N = L1 x L2 (x L3), every      10^6 = 100x100x100): column-tile passes whose lengths have prime factors up to 7
- *     L in 64 ... 512
+ *     the LDS kernels, N = L1 x L2 (x L3), every      10^6 = 100x100x100; round 6: 390625 = 625x625, 500000 = 800x625): column-tile passes whose
+ *     L in 64 ... 1024 (28 lengths above 512)         lengths have prime factors up to 7
  *   prime factors up to 13, no route above, and     "stockham mixed-radix ... specialised" / "stockham mixed tiles ... specialised": kernels
  *     its run-time kernels in the code-object cache   compiled by an earlier "specialise" (below) -- see fourier_hip_set_default_option
  *   every other length                              "bluestein M=<M> inner <power-of-two plan>[ fused]": chirp-z over a power-of-two transform

@@ -197,10 +197,10 @@ def test_length_specialised_mixed_kernels_equal_the_generic_one(fa, monkeypatch)
 def test_large_mixed_radix_sizes_run_natively(fa, oracle, monkeypatch):
     """N = 2^a*3^b (a >= 12, any b): big-radix passes over the 2^a part, then the odd part as radix-27 Stockham passes
     plus one of radix 3 / 9 / 27 -- twiddled middle passes and a final one (the reference's order, RADICES =
-    [4,8,4,3,2]) -- or, where the length splits into two tile lengths of at most 384 (round 4: measured faster), two
-    mixed-length tile passes; every code, in and out of place, against the oracle, on both routes."""
+    [4,8,4,3,2]) -- or, where the length splits into two tile lengths of at most 576 (round 6, register tiles: measured faster; round 4: 384),
+    two mixed-length tile passes; every code, in and out of place, against the oracle, on both routes."""
     cases = ((3 * 4096, "64x64x3", "mixed tiles 128x96"), (9 * 8192, "128x64x9", "mixed tiles 288x256"), (27 * 4096, "64x64x27", "mixed tiles 384x288"),
-             (81 * 4096, "64x64x27x3", None), (243 * 4096, "64x64x27x9", None))
+             (81 * 4096, "64x64x27x3", "mixed tiles 576x576"), (243 * 4096, "64x64x27x9", None))
     for pow2_first in (False, True):
         if pow2_first:
             monkeypatch.setenv("FOURIER_POW2_TILES_FIRST", "1")
@@ -277,6 +277,25 @@ def test_register_resident_tile_passes_against_the_lds_tile_passes(fa, oracle, m
             assert np.array_equal(run_batch(reg, x, code, inplace=True), a), (n, code)
         if n != 15625:  # (125 = 25 x 5 stays on the LDS kernel: the same plan twice)
             assert not np.array_equal(run_batch(reg, x, 0), run_batch(lds, x, 0)), n
+
+
+def test_tile_lengths_of_513_to_1024_points(fa, oracle, monkeypatch):
+    """Round 6: 28 tile lengths above 512 points (two register stages of at most 32 points each) on 64-byte row segments, so that the tile stays
+    within 64 KiB of LDS: two tile passes where three were needed (640000 = 800 x 800 instead of 100 x 80 x 80) or none existed (390625 = 625 x
+    625 took Bluestein), and 2^a 3^b with a >= 12 up to 576 x 576 (81 * 4096: four round trips before).  Against the oracle, in place, a ragged
+    tile (625 columns of 4 f64 / 8 f32 columns per tile); without the register-tile kernels the old plans are back."""
+    for n, dtype, desc, tol in ((390625, np.complex64, "mixed tiles 625x625", 2e-6), (640000, np.complex128, "mixed tiles 800x800", 1e-9),
+                                (81 * 4096, np.complex64, "mixed tiles 576x576", 1e-6)):
+        plan = make(fa, n, dtype)
+        assert desc in plan.describe(), plan.describe()
+        x = np.stack([hash_normal(70 + b, n) for b in range(2)]).astype(dtype)
+        for code in (0, 1):
+            ref = oracle.transform_batch(x, code)
+            a = run_batch(plan, x, code)
+            assert rel_l2(a, ref) <= tol, (n, code, rel_l2(a, ref))
+            assert np.array_equal(run_batch(plan, x, code, inplace=True), a), (n, code)
+    monkeypatch.setenv("FOURIER_NO_REGTILE", "1")
+    assert "bluestein" in make(fa, 390625, np.complex64).describe() and "mixed tiles 100x80x80" in make(fa, 640000, np.complex128).describe()
 
 
 def test_bluestein_fusion_matches_unfused(fa):
@@ -940,7 +959,7 @@ def test_plan_option_specialise_is_refused_without_hiprtc_and_leaves_the_plan_al
     assert "specialised" not in plan.describe()
 
 
-def test_every_route_string_describe_can_return_is_named_in_the_public_header(fa):
+def test_every_route_string_describe_can_return_is_named_in_the_public_header(fa, monkeypatch):
     """include/fourier.h tells callers to match on fourier_hip_describe_* where the accuracy class of a route matters (VERDICT round 4
     item 7: the list there had fallen behind plan.h twice).  Every word of every description the plan factory returns -- one length
     per route of Plan::Plan, both precisions -- must occur in the header's route list."""
@@ -949,18 +968,27 @@ def test_every_route_string_describe_can_return_is_named_in_the_public_header(fa
     header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "fourier.h")).read()
     routes = header[header.index("The routes, in the order they are tried"):header.index("struct fourier_fft_float *fourier_hip_create_float")]
     sizes = [4, 16, 64, 1024, 1 << 12, 1 << 14, 1 << 16, 1 << 23,  # tiny, whole rows, one-launch, two and three passes
-             3 * 4096, 27 * 4096, 512 * 432 * 1,                   # mixed tiles (a >= 12), power-of-two passes + odd passes
+             3 * 4096, 27 * 4096, 512 * 432, 3 << 18,              # mixed tiles (a >= 12), power-of-two passes + odd passes
              96, 1000, 1001, 18432,                                 # LDS mixed-radix: per-length and runtime-parameterised kernels
-             62208, 3 ** 10 * 2, 3 ** 16,                           # mixed tiles (a < 12), three tile passes, global passes
+             62208, 3 ** 10 * 2, 3 ** 16, 625 * 625,                # mixed tiles (a < 12), three tile passes, tiles beyond 512 points
              100000, 44100,                                         # tile passes with factors 5 / 7
              17, 1013, 40001, 999983, 16411]                        # Bluestein: one-launch ("fused"), fused passes, smooth M
     seen = set()
-    for n in sizes:
+
+    def visit(n):
         for dtype in (np.complex64, np.complex128):
             d = make(fa, n, dtype).describe()
             seen.add(re.sub(r"\d+", "#", d))
             for word in re.findall(r"[a-z][a-z\-]{2,}", d):
                 assert word in routes, (word, d)
+
+    for n in sizes:
+        visit(n)
+    # one Stockham pass per radix in global memory: since round 6 (tile lengths up to 1024) every 2^a 3^b, a < 12, the engine accepts has a tile
+    # factorisation -- the route is what is left when that one is switched off (experiments library; the emulator build is one)
+    monkeypatch.setenv("FOURIER_NO_TILED_MIXED", "1")
+    visit(59049)
+    monkeypatch.delenv("FOURIER_NO_TILED_MIXED")
     # every route family was actually visited
     for must in ("stockham tiny", "one-launch", "mixed tiles", "mixed-radix", "global-pass", "bluestein M=", "fused"):
         assert any(must.replace("M=", "M=") in s for s in seen), (must, sorted(seen))

@@ -214,7 +214,8 @@ def test_mixed_radix_sizes_are_bit_identical_to_the_oracle(torch, fa, oracle):
                                81 * 4096, 243 * 4096, 729 * (1 << 13), 2187 * 4096, 81 * (1 << 17)])
 def test_large_mixed_radix_sizes_vs_oracle(torch, fa, oracle, n):
     """2^a*3^b (a >= 12, any b) natively: big-radix passes over 2^a, then radix-27/9/3 passes (middle ones twiddled) -- or two
-    mixed-length tile passes where the length splits into two tile lengths of at most 384 (round 4)."""
+    mixed-length tile passes where the length splits into two tile lengths of at most 576 (round 6: register tiles, lengths beyond 512 points on
+    64-byte rows; round 4: 384)."""
     x = np.stack([hash_uniform(90 + b, n) for b in range(2)])
     for dtype, tl2 in ((np.complex64, 1e-6), (np.complex128, 5e-14)):
         if n > (1 << 24) and dtype == np.complex128:
@@ -222,7 +223,7 @@ def test_large_mixed_radix_sizes_vs_oracle(torch, fa, oracle, n):
         plan = make(fa, n, dtype)
         d = plan.describe()
         assert d.startswith("stockham") and ("mixed tiles" in d or "x3" in d.replace("x9", "x3").replace("x27", "x3")), d
-        assert ("mixed tiles" in d) == (n in (3 * 4096, 9 * 4096, 27 * 4096, 3 * (1 << 15))), d  # 128x96, 192x192, 384x288, 384x256
+        assert ("mixed tiles" in d) == (n in (3 * 4096, 9 * 4096, 27 * 4096, 3 * (1 << 15), 81 * 4096)), d  # 128x96, 192x192, 384x288, 384x256, 576x576
         for code in (0, 1, 3):
             ref = oracle.transform_batch(x.astype(dtype), code, nthreads=2)
             assert rel_l2(gpu_batch(torch, fa, plan, x.astype(dtype), code), ref) <= tl2, (n, code)
@@ -1202,7 +1203,9 @@ def test_lengths_with_factors_5_and_7_beyond_the_lds_kernels_run_as_tile_passes_
     the LDS limit), a ragged case (tile length without a factor 16).  Values against the oracle (chirp-z) and the f64 truth."""
     for n, dtype, want in ((100000, np.complex64, "400x250"), (44100, np.complex64, "210x210"), (1000000, np.complex64, "100x100x100"),
                            (48000, np.complex64, None), (96000, np.complex64, None), (9800, np.complex64, "100x98"), (30870, np.complex64, None),
-                           (100000, np.complex128, "400x250"), (44100, np.complex128, "210x210"), (5 * 7 * 7 * 7 * 7 * 3, np.complex128, None)):
+                           (100000, np.complex128, "400x250"), (44100, np.complex128, "210x210"), (5 * 7 * 7 * 7 * 7 * 3, np.complex128, None),
+                           # round 6: tile lengths of 513 ... 1024 points (register tiles on 64-byte rows): two passes where there were three, or Bluestein
+                           (390625, np.complex64, "625x625"), (500000, np.complex128, "800x625"), (640000, np.complex64, "800x800"), (729000, np.complex128, "900x810")):
         plan = make(fa, n, dtype)
         d = plan.describe()
         assert "stockham mixed tiles" in d and "specialised" not in d, (n, d)
@@ -1369,9 +1372,10 @@ def test_plan_option_specialise_compiles_the_lengths_own_kernel_with_hiprtc(torc
             assert np.array_equal(gpu_batch(torch, fa, spec, x, code, inplace=True), a), (n, dtype, code)
     # beyond one compute unit's LDS: column-tile passes whose lengths may have prime factors up to 13 (Bluestein by default where a
     # tile length has a factor 11 or 13: the ahead-of-time tile kernels stop at 7)
-    # (500000 = 2^5 * 5^6 and 5^8 have no split into factors of 64 ... 512: tile passes of up to 1024 points, run-time kernels only)
+    # (286000 = 2^4 * 5^3 * 11 * 13: tile passes of more than 512 points compiled at run time -- 500000 and 5^8, the cases of round 5, have
+    # ahead-of-time register-tile kernels since round 6)
     for n, dtype, want in ((143000, np.complex64, "440x325"), (57200, np.complex64, "260x220"),
-                           (143000, np.complex128, "440x325"), (500000, np.complex64, "800x625"), (390625, np.complex128, "625x625")):
+                           (143000, np.complex128, "440x325"), (286000, np.complex64, "550x520"), (286000, np.complex128, "550x520")):
         x = np.stack([hash_normal(2600 + b, n) for b in range(3)]).astype(dtype)
         base, spec = make(fa, n, dtype), make(fa, n, dtype)
         assert "bluestein" in base.describe()
