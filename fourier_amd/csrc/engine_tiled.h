@@ -36,7 +36,8 @@ template <typename T> class TiledMixedEngine {
   // 128 KiB of LDS, one 1024-thread workgroup per CU: 2.4 - 3.2 TB/s per pass against 4.2 - 4.9 for the short tiles -- level with a three-pass
   // plan of short tiles, but it reaches lengths that have no split into factors of 64 ... 512 at all: 5^8 = 625 x 625 15 % of the HBM peak
   // against 9 % as Bluestein, 500000 = 800 x 625 18 % against 11 %, profiles/r05_s21_long_tiles_ab.jsonl)
-  // (ahead of time: 512 points for the LDS kernels; 28 lengths of 513 ... 1024 points run on register tiles of 64-byte rows, round 6)
+  // (ahead of time: 512 points for the LDS kernels; 28 lengths of 513 ... 1024 points run on register tiles of 64-byte rows, round 6;
+  // f32: five more with a 40- or 35-point stage -- 875, 945, 972, 980, 1000 --, 10^6 = 1000 x 1000 0.20 -> 0.29, profiles/r06_s42_1000_point_tiles.jsonl)
   // 390625 = 625 x 625: 0.09 (Bluestein) -> 0.26; 500000 = 800 x 625: 0.11 -> 0.24; 640000, 729000 (three passes of 80 ... 100 points before):
   // +28 ... 52 % (profiles/r06_s40_long_tiles_ab.jsonl)
   static uint32_t max_len(bool rtc) { (void)rtc; return 1024u; }

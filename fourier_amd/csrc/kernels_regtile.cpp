@@ -25,12 +25,17 @@ template <typename T, uint32_t L> static TiledKernel make_regtile(int which) {
 
 // 513 ... 1024 points (64-byte row segments): the plain pass only -- two passes where three tile passes of at most 512 points were needed
 template <typename T, uint32_t L> static TiledKernel make_regtile_long(int which) {
-  if (which != 0) return TiledKernel();
-  using C = RegTileCfg<T, L>;
-  TiledKernel k;
-  k.fn = &tiled_reg_kernel<T, L, IO_PLAIN>;
-  k.L = L; k.cols = C::COLS; k.threads = C::NT; k.smem = C::SMEM; k.r1 = C::R1; k.r2 = C::R2;
-  return k;
+  if constexpr (reg_tile_shape(L, (uint32_t)sizeof(cpx<T>)).r1 != 0) {
+    if (which != 0) return TiledKernel();
+    using C = RegTileCfg<T, L>;
+    TiledKernel k;
+    k.fn = &tiled_reg_kernel<T, L, IO_PLAIN>;
+    k.L = L; k.cols = C::COLS; k.threads = C::NT; k.smem = C::SMEM; k.r1 = C::R1; k.r2 = C::R2;
+    return k;
+  } else {
+    (void)which;
+    return TiledKernel();  // (f64: a stage of more than 32 points)
+  }
 }
 #define FOURIER_TILED(LL) case LL: return make_regtile<T, LL>(which);
 #define FOURIER_LONG(LL) case LL: return make_regtile_long<T, LL>(which);
@@ -80,6 +85,7 @@ TiledKernel get_regtile_kernel_s3(Real<TUReal>, uint32_t L, int which) {
     FOURIER_TILED(375) FOURIER_TILED(378) FOURIER_TILED(392) FOURIER_TILED(400) FOURIER_TILED(405) FOURIER_TILED(420) FOURIER_TILED(441)
     FOURIER_TILED(448) FOURIER_TILED(450) FOURIER_TILED(480) FOURIER_TILED(490) FOURIER_TILED(500) FOURIER_TILED(504)
     FOURIER_LONG(810) FOURIER_LONG(840) FOURIER_LONG(864) FOURIER_LONG(896) FOURIER_LONG(900) FOURIER_LONG(960) FOURIER_LONG(1024)
+    FOURIER_LONG(875) FOURIER_LONG(945) FOURIER_LONG(972) FOURIER_LONG(980) FOURIER_LONG(1000)
     default: return TiledKernel();
   }
 }

@@ -207,8 +207,11 @@ constexpr uint32_t reg_tile_row(uint32_t r2, uint32_t k1, uint32_t j2) { return 
 constexpr RegTileShape reg_tile_shape(uint32_t L, uint32_t elem) {
   RegTileShape t{};
   uint32_t r2 = 0;
+  // (f32 beyond 512 points: stages of up to 40 points -- 1000 = 40 x 25, so that 10^6 is two passes: 0.20 -> 0.29 of the HBM peak; f64 spills
+  // into AGPRs at 40 points and stays on three passes: 0.19 against 0.21, profiles/r06_s42_1000_point_tiles*.jsonl)
+  const uint32_t max_factor = (elem == 8u && L > 512u) ? 40u : REG_TILE_MAX_FACTOR;
   for (uint32_t b = 2; b * b <= L; ++b)
-    if (L % b == 0 && L / b <= REG_TILE_MAX_FACTOR) r2 = b;
+    if (L % b == 0 && L / b <= max_factor) r2 = b;
   // (125 = 25 x 5: 40 of 256 threads transform in stage A -- f64 15625 = 125 x 125 0.26 against 0.31 on the LDS kernel, r06_s25)
   if (r2 == 0 || L / r2 > 4u * r2) return t;
   t.r1 = L / r2; t.r2 = r2;

@@ -106,8 +106,9 @@ enum {
  *   2^a * 3^b, a < 12, without such a factorisation "stockham global-pass <r1>.<r2>....": one Stockham pass per radix in global memory (since round 6,
  *                                                   tile lengths up to 1024, no accepted length is left without one: the fallback)
  *   2^a * 3^b * 5^c * 7^d with c + d >= 1 beyond    "stockham mixed tiles <L1>x<L2>[x<L3>]" (round 5; 10^5 = 400x250, 44100 = 210x210,
- *     the LDS kernels, N = L1 x L2 (x L3), every      10^6 = 100x100x100; round 6: 390625 = 625x625, 500000 = 800x625): column-tile passes whose
- *     L in 64 ... 1024 (28 lengths above 512)         lengths have prime factors up to 7
+ *     the LDS kernels, N = L1 x L2 (x L3), every      10^6 = 1000x1000 in f32, 100x100x100 in f64; 390625 = 625x625, 500000 = 800x625): column-tile passes whose
+ *     L in 64 ... 1024 (28 lengths above 512,         lengths have prime factors up to 7
+ *     f32: 33)
  *   prime factors up to 13, no route above, and     "stockham mixed-radix ... specialised" / "stockham mixed tiles ... specialised": kernels
  *     its run-time kernels in the code-object cache   compiled by an earlier "specialise" (below) -- see fourier_hip_set_default_option
  *   every other length                              "bluestein M=<M> inner <power-of-two plan>[ fused]": chirp-z over a power-of-two transform

@@ -262,7 +262,7 @@ def test_register_resident_tile_passes_against_the_lds_tile_passes(fa, oracle, m
     (FOURIER_NO_REGTILE).  Both against the oracle, all five codes, in place, ragged batch and ragged tiles (column counts without a factor
     16; f32 units of two columns: a last column by itself), two and three passes; and against each other."""
     for n, dtype, tol in ((44100, np.complex64, 2e-6), (30870, np.complex64, 2e-6), (20736, np.complex64, 1e-6), (59049, np.complex64, 1e-6),
-                          (13122, np.complex128, 5e-14), (44100, np.complex128, 1e-9), (15625, np.complex128, 1e-9), (1000000, np.complex64, 2e-6)):
+                          (13122, np.complex128, 5e-14), (44100, np.complex128, 1e-9), (15625, np.complex128, 1e-9), (1000000, np.complex128, 1e-9)):
         reg = make(fa, n, dtype)
         monkeypatch.setenv("FOURIER_NO_REGTILE", "1")
         lds = make(fa, n, dtype)
@@ -285,7 +285,9 @@ def test_tile_lengths_of_513_to_1024_points(fa, oracle, monkeypatch):
     625 took Bluestein), and 2^a 3^b with a >= 12 up to 576 x 576 (81 * 4096: four round trips before).  Against the oracle, in place, a ragged
     tile (625 columns of 4 f64 / 8 f32 columns per tile); without the register-tile kernels the old plans are back."""
     for n, dtype, desc, tol in ((390625, np.complex64, "mixed tiles 625x625", 2e-6), (640000, np.complex128, "mixed tiles 800x800", 1e-9),
-                                (81 * 4096, np.complex64, "mixed tiles 576x576", 1e-6)):
+                                (81 * 4096, np.complex64, "mixed tiles 576x576", 1e-6),
+                                # f32 only: a 40-point stage (1000 = 40 x 25); f64 keeps the three passes (spills at 40 points, r06_s42)
+                                (1000000, np.complex64, "mixed tiles 1000x1000", 2e-6)):
         plan = make(fa, n, dtype)
         assert desc in plan.describe(), plan.describe()
         x = np.stack([hash_normal(70 + b, n) for b in range(2)]).astype(dtype)

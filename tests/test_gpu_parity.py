@@ -1201,11 +1201,13 @@ def test_lengths_with_factors_5_and_7_beyond_the_lds_kernels_run_as_tile_passes_
     lengths the reference sends to Bluestein (fourier/src/lib.rs:38-42) but that factor into two or three such tile lengths take
     direct Stockham passes from plain create_fft_*: 10^5, 44100, 48000, 96000, 10^6, 9800 (between the runtime kernel's reach and
     the LDS limit), a ragged case (tile length without a factor 16).  Values against the oracle (chirp-z) and the f64 truth."""
-    for n, dtype, want in ((100000, np.complex64, "400x250"), (44100, np.complex64, "210x210"), (1000000, np.complex64, "100x100x100"),
+    for n, dtype, want in ((100000, np.complex64, "400x250"), (44100, np.complex64, "210x210"), (1000000, np.complex64, "1000x1000"), (1000000, np.complex128, "100x100x100"),
                            (48000, np.complex64, None), (96000, np.complex64, None), (9800, np.complex64, "100x98"), (30870, np.complex64, None),
                            (100000, np.complex128, "400x250"), (44100, np.complex128, "210x210"), (5 * 7 * 7 * 7 * 7 * 3, np.complex128, None),
                            # round 6: tile lengths of 513 ... 1024 points (register tiles on 64-byte rows): two passes where there were three, or Bluestein
-                           (390625, np.complex64, "625x625"), (500000, np.complex128, "800x625"), (640000, np.complex64, "800x800"), (729000, np.complex128, "900x810")):
+                           (390625, np.complex64, "625x625"), (500000, np.complex128, "800x625"), (640000, np.complex64, "800x800"), (729000, np.complex128, "900x810"),
+                           # f32 only: stages of up to 40 points (1000 = 40 x 25; f64 spills there and keeps three passes, r06_s42)
+                           (765625, np.complex64, "875x875"), (945000, np.complex64, "1000x945")):
         plan = make(fa, n, dtype)
         d = plan.describe()
         assert "stockham mixed tiles" in d and "specialised" not in d, (n, d)
