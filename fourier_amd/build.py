@@ -56,7 +56,7 @@ def mix_shards():
 
 def translation_units():
     """(object name, source file, extra -D flags, group) for every object of the two libraries.  Groups: 'host', 'env_product',
-    'env_experiments', 'pass', 'onelaunch', 'misc', 'mixed', 'experiments' (tools/build_variants.py rebuilds by group)."""
+    'env_experiments', 'pass', 'onelaunch', 'misc', 'mixed', 'chirpz', 'experiments' (tools/build_variants.py rebuilds by group)."""
     tus = [("engine", "engine.cpp", [], "host"),
            ("rtc", "rtc.cpp", [], "host"),
            ("env_product", "env_product.cpp", [], "env_product"),
@@ -75,6 +75,7 @@ def translation_units():
         for i in range(4):
             tus.append((f"kernels_tiled_{tag}_{i}", "kernels_tiled.cpp", d + [f"-DFOURIER_TILED_SHARD={i}"], "mixed"))
             tus.append((f"kernels_regtile_{tag}_{i}", "kernels_regtile.cpp", d + [f"-DFOURIER_TILED_SHARD={i}"], "mixed"))
+            tus.append((f"kernels_chirpz_{tag}_{i}", "kernels_chirpz.cpp", d + [f"-DFOURIER_TILED_SHARD={i}"], "chirpz"))
         tus.append((f"kernels_experiments_{tag}", "kernels_experiments.cpp", d, "experiments"))
         tus.append((f"kernels_skeleton_{tag}", "kernels_skeleton.cpp", d, "experiments"))
     return tus

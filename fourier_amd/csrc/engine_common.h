@@ -173,6 +173,8 @@ typedef void (*TiledKernelFn)(TiledArgs);
 // a tile pass of mixed length L: columns per tile, threads, LDS bytes
 // r1 != 0: the register-resident kernel of kernels_regtile.h (L = r1 x r2; its `tw` table is W_L^{j2 * k1}, [r1][r2])
 struct TiledKernel { TiledKernelFn fn = nullptr; uint32_t L = 0, cols = 0, threads = 0; size_t smem = 0; uint32_t r1 = 0, r2 = 0; };
+typedef void (*ChirpzKernelFn)(ChirpzArgs);
+struct ChirpzKernel { ChirpzKernelFn fn = nullptr; uint32_t m = 0, r1 = 0, r2 = 0, r3 = 0, tpw = 0, threads = 64; size_t smem = 0; };  // tpw: transforms per workgroup
 // a mixed-radix LDS kernel with its launch shape: transforms per workgroup, LDS buffers of `group` transforms, threads
 struct MixKernel { MixKernelFn fn; uint32_t group; size_t nbuf; uint32_t threads; };
 
@@ -243,6 +245,10 @@ template <typename T> struct Real {};
   TiledKernel get_regtile_kernel(Real<T>, uint32_t L, int which = 0);                                                  \
   TiledKernel get_regtile_kernel_s0(Real<T>, uint32_t L, int which); TiledKernel get_regtile_kernel_s1(Real<T>, uint32_t L, int which); \
   TiledKernel get_regtile_kernel_s2(Real<T>, uint32_t L, int which); TiledKernel get_regtile_kernel_s3(Real<T>, uint32_t L, int which); \
+  /* kernels_chirpz.cpp (4 shards): the whole chirp-z in one launch on a smooth M = R1 x R2 [x R3] (registers); fn == nullptr: none */ \
+  ChirpzKernel get_chirpz_kernel(Real<T>, uint32_t m);                                                                 \
+  ChirpzKernel get_chirpz_kernel_s0(Real<T>, uint32_t m); ChirpzKernel get_chirpz_kernel_s1(Real<T>, uint32_t m);     \
+  ChirpzKernel get_chirpz_kernel_s2(Real<T>, uint32_t m); ChirpzKernel get_chirpz_kernel_s3(Real<T>, uint32_t m);     \
   /* kernels_experiments.cpp (experiments library) or env_product.cpp (product: nothing available) */                  \
   bool get_fused_kernel(Real<T>, int k, FusedInfo& info);                                                              \
   KernelInfo get_split_kernel(Real<T>, int L, int io);                                                                 \

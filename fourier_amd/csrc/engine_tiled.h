@@ -386,4 +386,74 @@ template <typename T> class BluTiledEngine {
   DevBuf tw1_, tw2_, tw_lo_, tw_hi_;
 };
 
+// ---- Bluestein of a SHORT transform on a smooth M = R1 x R2 in one launch, both M-point transforms in registers (kernels_chirpz.h) ----
+template <typename T> class BluRegEngine {
+ public:
+  static const std::vector<uint32_t>& menu() {
+    static const std::vector<uint32_t> m = [] {
+      std::vector<uint32_t> v;
+      for (uint32_t mm = 32; mm <= 9261; ++mm)
+        if (get_chirpz_kernel(Real<T>{}, mm).fn) v.push_back(mm);
+      return v;
+    }();
+    return m;
+  }
+  // the smallest M of the menu that reaches 2n - 1; 0: none
+  static uint32_t choose_m(size_t n) {
+    for (uint32_t m : menu())
+      if ((uint64_t)m >= 2 * (uint64_t)n - 1) return m;
+    return 0;
+  }
+  BluRegEngine(size_t n_user, uint32_t m) : n_(n_user), k_(get_chirpz_kernel(Real<T>{}, m)) {
+    if (!k_.fn || (uint64_t)m < 2 * (uint64_t)n_user - 1) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "no one-launch chirp-z kernel of this length");
+    raise_smem_limit((const void*)k_.fn, k_.smem);
+    std::vector<cpx<T>> tw;
+    auto root = [&](uint64_t e, uint64_t size) {
+      double re, im;
+      unit_root(e % size, size, re, im);
+      tw.push_back({(T)re, (T)im});
+    };
+    const uint64_t r1 = k_.r1, r2 = k_.r2, r3 = k_.r3;
+    if (r3 == 0) {  // [j2][k1]: W_M^{j2 * k1}
+      for (uint64_t j2 = 0; j2 < r2; ++j2)
+        for (uint64_t k1 = 0; k1 < r1; ++k1) root(j2 * k1, k_.m);
+    } else {  // the four tables of chirpz_reg3_kernel, one after the other
+      for (uint64_t j2 = 0; j2 < r2; ++j2)  // [j2][k1 * R3 + j3]: W_M^{(j3 + R3 * j2) * k1}
+        for (uint64_t k1 = 0; k1 < r1; ++k1)
+          for (uint64_t j3 = 0; j3 < r3; ++j3) root((j3 + r3 * j2) * k1, k_.m);
+      for (uint64_t k2 = 0; k2 < r2; ++k2)  // [k2][j3]: W_{R2 R3}^{j3 * k2}
+        for (uint64_t j3 = 0; j3 < r3; ++j3) root(j3 * k2, r2 * r3);
+      for (uint64_t c3 = 0; c3 < r3; ++c3)  // [c3][a]: W_M^{a * c3}
+        for (uint64_t a = 0; a < r1 * r2; ++a) root(a * c3, k_.m);
+      for (uint64_t c2 = 0; c2 < r2; ++c2)  // [c2][k1]: W_{R1 R2}^{k1 * c2}
+        for (uint64_t k1 = 0; k1 < r1; ++k1) root(k1 * c2, r1 * r2);
+    }
+    tw_.upload(tw);
+  }
+  uint64_t m() const { return k_.m; }
+  bool three_stages() const { return k_.r3 != 0; }
+  std::string describe() const {
+    return "registers " + std::to_string(k_.r1) + "x" + std::to_string(k_.r2) + (k_.r3 ? "x" + std::to_string(k_.r3) : std::string()) + " one-launch";
+  }
+  // in, out: user arrays (n per transform); in == out is fine: a wave reads its transforms completely before it writes them
+  void run(const cpx<T>* in, cpx<T>* out, size_t batch, const void* xtab, const void* wtab, bool inverse, double scale, hipStream_t stream,
+           Profiler* prof) const {
+    if (batch == 0) return;
+    ChirpzArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.in = in; a.out = out; a.chirp = xtab; a.w = wtab; a.tw = tw_.p;
+    a.n = n_; a.batch = batch; a.swap = inverse ? 1 : 0; a.scale = scale;
+    const uint64_t grid = ((uint64_t)batch + k_.tpw - 1) / k_.tpw;
+    if (grid > 0x7fffffffull) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "grid too large; lower chunk_bytes");
+    PROF_BEGIN(prof, 0);
+    FOURIER_LAUNCH(k_.fn, grid, k_.threads, k_.smem, stream, a);
+    PROF_END(prof);
+  }
+
+ private:
+  size_t n_;
+  ChirpzKernel k_;
+  DevBuf tw_;
+};
+
 }  // namespace fourier_hip

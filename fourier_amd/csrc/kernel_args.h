@@ -127,6 +127,17 @@ struct TiledArgs {
   int blu_swap;
 };
 
+// ---- whole chirp-z of a short transform in one launch on a smooth M = R1 x R2, both transforms in registers (kernels_chirpz.h)
+struct ChirpzArgs {
+  const void* in; void* out;
+  const void* chirp;          // x[0 .. n): exp(-i pi k^2 / n) (bluesteins.rs:51-61)
+  const void* w;              // FFT_M(conj chirp, mirrored) / M (bluesteins.rs:18-48), M entries
+  const void* tw;             // [j2 < R2][k1 < R1]: W_M^{j2 * k1}
+  uint64_t n, batch;          // user transform length (batch stride), transforms
+  int swap;                   // user-level inverse: swap re / im of the user data
+  double scale;
+};
+
 // ---- XCD-fused one-launch plan (kernels_experiments.h)
 struct FusedArgs {
   PassArgs a, b;       // pass A / pass B arguments; a.in, a.out, b.in, b.out are set per item

@@ -169,6 +169,7 @@ template <typename T> class Plan {
     if (mix_) desc_ = "stockham mixed-radix " + mix_->describe();
     else if (tiled_) desc_ = "stockham mixed tiles " + tiled_->describe();
     else if (gen_) desc_ = "stockham global-pass " + gen_->describe();
+    else if (blur_) desc_ = "bluestein M=" + std::to_string(m_) + " " + blur_->describe();
     else if (blut_) desc_ = "bluestein M=" + std::to_string(m_) + " inner " + blut_->describe();
     else if (blu_) desc_ = "bluestein M=" + std::to_string(m_) + " inner " + eng_->describe() + (small_fused_ ? " fused" : "");
     else desc_ = "stockham " + eng_->describe();
@@ -199,6 +200,7 @@ template <typename T> class Plan {
     auto passes = [&](const char* tag) {
       for (size_t p = 0; p < (blu_ ? eng_->num_passes() : eng_->hbm_round_trips()); ++p) d += std::string(d.empty() ? "" : ",") + tag + std::to_string(p);
     };
+    if (blur_) return "bluestein_one_launch";
     if (blut_) return "chirp_in_pass,conv_pass,chirp_out_pass";
     if (!blu_) { passes("pass"); return d; }
     if (small_fused_) return "bluestein_one_launch";
@@ -218,7 +220,7 @@ template <typename T> class Plan {
     // unfused: pre (n + table read, m write) + 2 inner FFTs + w table + post (n + table read, n write);
     // fused: the first / last inner pass read / write the n-point user array instead of an m-point sweep
     if (blut_) return (double)ELEM * (5.0 * m_ + 4.0 * n_);  // (n + n, m) + (m + m, m) + (m + n, n)
-    if (small_fused_) return (double)ELEM * 2.0 * n_;  // tables stay L2-resident
+    if (small_fused_ || blur_) return (double)ELEM * 2.0 * n_;  // tables stay L2-resident
     const double chirp_reads = (chirp_compute_ ? 1.0 : 2.0) * n_;  // the n-entry chirp table: the chirp-out pass reads it, the chirp-in pass only without bluestein_chirp_compute
     if (fused_ && conv_) return (double)ELEM * (2.0 * m_ * (2.0 * eng_->num_passes() - 1.0) - 2.0 * (m_ - n_) + m_ + chirp_reads);
     // without the conv kernel the product with w is a sweep of its own over the M-point spectrum: 2 m on top of the w table
@@ -247,18 +249,15 @@ template <typename T> class Plan {
     // 0 = always the reference's next power of two (bluesteins.rs:110).  Rebuilds the plan's tables now; not while a transform is in flight.
     if (key == "bluestein_smooth_m" && v >= 0 && v <= 2) {  // (2: wherever a product of two tile lengths exists -- for measurements)
       if (!blu_) return ::fourier::c::FOURIER_HIP_INVALID_ARGUMENT;
-      if ((int)v != smooth_m_mode_) {
-        HIP_CHECK(hipDeviceSynchronize());
-        smooth_m_mode_ = (int)v;
-        blut_.reset(); eng_.reset(); eng_inv_.reset();
-        init_bluestein();
-        if (reference_chirp_) { build_chirp_tables(true); chirp_compute_saved_ = chirp_compute_; chirp_compute_ = false; }
-        refresh_desc();
-      }
+      if ((int)v != smooth_m_mode_) rebuild_bluestein((int)v);
       return 0;
     }
     if (key == "bluestein_fusion" && (v == 0 || v == 1)) {
       if (blut_) return 0;  // the smooth-M route has no unfused form
+      if (blur_) {          // nor has the register route: the unfused sweeps run on the reference's power-of-two M
+        if (v == 1) return 0;
+        rebuild_bluestein(0);
+      }
       fused_ = (v == 1) && blu_ && eng_->can_fuse_bluestein();
       small_fused_ = (v == 1) && blu_ && eng_->enable_bluestein_small();
       return 0;
@@ -409,7 +408,7 @@ template <typename T> class Plan {
       if (need) reserve([&](size_t c) { scratch_.ensure(c * n_ * ELEM); });
       return chunk;
     }
-    if (small_fused_) return batch;  // whole chirp-z in one launch: no work array
+    if (small_fused_ || blur_) return batch;  // whole chirp-z in one launch: no work array
     reserve([&](size_t c) {
       work_.ensure(c * m_ * ELEM);
       if (blut_ || eng_->needs_scratch(true) || fused_) scratch_.ensure(c * m_ * ELEM);
@@ -474,6 +473,10 @@ template <typename T> class Plan {
     // Bluestein (bluesteins.rs:215-259): work = x.in (zero padded) ; FFT_M ; .w ; IFFT_M ; out = work.x.scale
     if (small_fused_) {  // M <= 2^15: the whole chirp-z in one launch, no work array
       eng_->run_bluestein_small(in, out, batch, xtab_.p, wtab_.p, n_, inverse, scale, stream, prof, nxcd_);
+      return;
+    }
+    if (blur_) {  // a short transform on a smooth M = R1 x R2: one launch, both transforms in registers (kernels_chirpz.h)
+      blur_->run(in, out, batch, xtab_.p, wtab_.p, inverse, scale, stream, prof);
       return;
     }
     cpx<T>* work = (cpx<T>*)work_.p;
@@ -635,6 +638,15 @@ template <typename T> class Plan {
     return (unsigned)std::min<size_t>(std::max<size_t>(blocks, 1), 256 * 32);
   }
 
+  // option "bluestein_smooth_m" (and "bluestein_fusion" = 0 on the register route): the Bluestein route chosen again under another rule
+  void rebuild_bluestein(int mode) {
+    HIP_CHECK(hipDeviceSynchronize());
+    smooth_m_mode_ = mode;
+    blur_.reset(); blut_.reset(); eng_.reset(); eng_inv_.reset();
+    init_bluestein();
+    if (reference_chirp_) { build_chirp_tables(true); chirp_compute_saved_ = chirp_compute_; chirp_compute_ = false; }
+    refresh_desc();
+  }
   void init_bluestein() {
     blu_ = true;
     if (n_ > ((size_t)1 << 26)) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "Bluestein sizes above 2^26 are not supported");
@@ -647,6 +659,24 @@ template <typename T> class Plan {
     // longer -- f32 +3 ... 43 %, f64 +20 ... 51 % there -- and in f64 from 1.44 x on while the conv kernel stays within 336 points (+5 ... 11 %;
     // beyond: -8 %).  Below that the power-of-two tiles' higher rate wins (f32 1.49 x: -7 ... -2 %; 1.35 x: -5 ... -1 %; f64 1.35 x: 0 ... +3 %;
     // profiles/r06_s35_smooth_m_late_loads_*.jsonl)
+    // A short transform (M up to 1024 points, f32 1152): the whole chirp-z in one launch on M = R1 x R2 with both transforms in registers
+    // (kernels_chirpz.h).  f64: wherever such an M exists -- 1.15 ... 2.05 x the power-of-two one-launch kernels, 1.2 - 1.3 x at the SAME M (64, 256,
+    // 1024).  f32 (two transforms per lane, packed arithmetic): where M is at least 1.1 x shorter (1.1 ... 1.55 x up to M = 784; 480 against 512
+    // and the stages of 30 and 32 points against 1024: 0.88 ... 0.99), up to M = 64 regardless (1.2 x at 64 against 64), 1152 against 2048
+    // (1.37 x) -- profiles/r06_s45_chirpz_reg_ab.jsonl
+    if (smooth_m_mode_ != 0 && !dev_env("FOURIER_NO_SMOOTH_M")) {
+      const uint32_t mr = BluRegEngine<T>::choose_m(n_);
+      // Three stages (M = R1 x R2 x R3, 1296 ... 3072 and 8820 / 9261): where M is at least 1.25 x shorter -- f32 1.13 ... 1.6 x, f64 1.05 ... 1.55 x
+      // the power-of-two one-launch kernels of M = 2048, 4096, 16384 (profiles/r06_s46_chirpz_reg3_ab.jsonl)
+      const bool pays = mr > 1152 ? 5 * (uint64_t)mr <= 4 * (uint64_t)m_
+                                  : (sizeof(T) == 8 || mr <= 64 || (mr <= 800 && 11 * (uint64_t)mr <= 10 * (uint64_t)m_) || 17 * (uint64_t)mr <= 10 * (uint64_t)m_);
+      if (mr != 0 && (smooth_m_mode_ == 2 || pays)) {
+        m_ = mr;
+        blur_.reset(new BluRegEngine<T>(n_, mr));
+        build_chirp_tables(false);
+        return;
+      }
+    }
     if (smooth_m_mode_ != 0 && !dev_env("FOURIER_NO_SMOOTH_M") && m_ > ((size_t)1 << (sizeof(T) == 4 ? 15 : 14))) {
       uint32_t l1 = 0, l2 = 0;
       const uint64_t ms = BluTiledEngine<T>::choose_m(n_, l1, l2);
@@ -801,6 +831,7 @@ template <typename T> class Plan {
   bool blu_ = false;
   std::unique_ptr<Pow2Engine<T>> eng_, eng_inv_;  // eng_inv_: mirrored inverse plan of a conv-fused Bluestein
   std::unique_ptr<BluTiledEngine<T>> blut_;       // Bluestein on a smooth M (then eng_ is empty)
+  std::unique_ptr<BluRegEngine<T>> blur_;         // ... of a short transform: one launch, transforms in registers (then eng_ is empty)
   int smooth_m_mode_ = 1;                         // option "bluestein_smooth_m"
   std::unique_ptr<MixedEngine<T>> mix_;
   std::unique_ptr<TiledMixedEngine<T>> tiled_;  // 2^a*3^b, a < 12, beyond the LDS kernels: column tiles of mixed length

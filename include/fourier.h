@@ -115,6 +115,11 @@ enum {
  *                                                   (bluesteins.rs:110), or -- round 6, where that work array is at least 1.6 x (f64: 1.44 x) longer and is
  *                                                   swept three times (M > 2^15, f64 2^14) -- "bluestein M=<L1*L2> inner mixed tiles
  *                                                   <L1>x<L2>": the same chirp-z over a product of two tile lengths >= 2N - 1
+ *                                                   -- or, for a short length (2N - 1 <= 1024; f32 where that saves a tenth of the power of two),
+ *                                                   "bluestein M=<R1*R2> registers <R1>x<R2> one-launch": the whole chirp-z in one launch
+ *                                                   over M = R1 x R2 >= 2N - 1 with both M-point transforms in registers; up to 2N - 1 = 9261
+ *                                                   "... registers <R1>x<R2>x<R3> one-launch" where such an M (1296 ... 3072, 8820, 9261) is
+ *                                                   at least 1.25 x shorter than the power of two
  *                                                   (plan option "bluestein_smooth_m" = 0 brings the power of two back)
  * Rely on `fourier_hip_describe_*`, not on this list, where the accuracy class (direct versus chirp-z) matters.  NULL on failure. */
 struct fourier_fft_float *fourier_hip_create_float(FOURIER_SIZE_TYPE size, int device);

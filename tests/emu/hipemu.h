@@ -97,7 +97,7 @@ inline unsigned lds_cost(const uint32_t* addr, int nl, unsigned bytes, bool is_w
   for (auto& g : groups) {
     std::map<unsigned, std::vector<uint32_t>> bank2addrs;
     for (int l : g) {
-      if (l >= nl) continue;
+      if (l >= nl || addr[l] == 0xffffffffu) continue;  // (0xffffffff: the lane is masked off in this instruction)
       for (unsigned d = 0; d < bytes / 4 + (bytes < 4); ++d) {
         uint32_t dw = addr[l] / 4 + d;
         auto& v = bank2addrs[dw % modulus];
@@ -248,21 +248,29 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, K kernel, A arg) {
         if (lds_trace_on()) {  // between two barriers: k-th access of every lane in a wave = one instruction
           for (unsigned w = 0; w < nthreads; w += 64) {
             unsigned nl = std::min(64u, nthreads - w);
-            size_t na = tlog[w].size();
+            // (a lane without any access between the two barriers is masked off in these instructions: the stages of kernels_chirpz.h run on
+            // part of a wave's lanes)
+            unsigned first = nl;
+            for (unsigned l = 0; l < nl && first == nl; ++l)
+              if (!tlog[w + l].empty()) first = l;
+            if (first == nl) continue;
+            const unsigned f = w + first;
+            size_t na = tlog[f].size();
             for (size_t k = 0; k < na; ++k) {
               uint32_t addr[64] = {0};
               bool ok = true;
               for (unsigned l = 0; l < nl; ++l) {
-                if (tlog[w + l].size() != na || tlog[w + l][k].site != tlog[w][k].site) { ok = false; break; }
+                if (tlog[w + l].empty()) { addr[l] = 0xffffffffu; continue; }
+                if (tlog[w + l].size() != na || tlog[w + l][k].site != tlog[f][k].site) { ok = false; break; }
                 addr[l] = tlog[w + l][k].addr;
               }
               if (!ok) continue;
               unsigned ideal;
-              unsigned c = lds_cost(addr, (int)nl, tlog[w][k].bytes, tlog[w][k].is_write, &ideal);
+              unsigned c = lds_cost(addr, (int)nl, tlog[f][k].bytes, tlog[f][k].is_write, &ideal);
               lds_stats().instr++; lds_stats().cycles += c; lds_stats().ideal += ideal;
               if (getenv("HIPEMU_LDS_VERBOSE") && b == 0 && w == 0)
-                fprintf(stderr, "lds site %u %s b%u: %u cycles (ideal %u)\n", tlog[w][k].site, tlog[w][k].is_write ? "W" : "R",
-                        tlog[w][k].bytes, c, ideal);
+                fprintf(stderr, "lds site %u %s b%u: %u cycles (ideal %u)\n", tlog[f][k].site, tlog[f][k].is_write ? "W" : "R",
+                        tlog[f][k].bytes, c, ideal);
             }
           }
           for (auto& v : tlog) v.clear();

@@ -300,6 +300,53 @@ def test_tile_lengths_of_513_to_1024_points(fa, oracle, monkeypatch):
     assert "bluestein" in make(fa, 390625, np.complex64).describe() and "mixed tiles 100x80x80" in make(fa, 640000, np.complex128).describe()
 
 
+def test_one_launch_chirpz_on_a_smooth_m_in_registers(fa, oracle):
+    """Round 6 (kernels_chirpz.h): a short Bluestein length runs the whole chirp-z in one launch on M = R1 x R2 >= 2N - 1 (bluesteins.rs:110 asks
+    for no more) with both M-point transforms in registers, 64 / R1 lane groups per one-wave workgroup, where that M is
+    shorter than the reference's power of two (f64: wherever such an M exists, f32 -- two transforms per lane on packed arithmetic -- where it is a
+    tenth shorter).  Against the oracle (its own chirp-z on the power of two) and the naive DFT, all five codes, in
+    place, batches that do not fill the last wave; option bluestein_smooth_m = 0 brings the power-of-two kernels back, = 2 forces the
+    register route wherever the menu reaches (every shape of it is run here)."""
+    for dtype, tol in ((np.complex64, 2e-6), (np.complex128, 1e-12)):  # (f64: the ORACLE's unreduced chirp angle, bluesteins.rs:10,31,57)
+        for n, want in ((17, "M=36 registers 6x6"), (191, "M=400 registers 20x20"), (331, "M=675 registers 27x25"), (307, "M=625 registers 25x25"),
+                        (149, "M=324 registers 18x18"), (37, "M=81 registers 9x9"), (31, "M=64 registers 8x8")) + \
+                       (((575, "M=1152 registers 36x32"),) if dtype == np.complex64 else ((222, "M=480 registers 24x20"), (511, "M=1024 registers 32x32"))):
+            plan = make(fa, n, dtype)
+            assert want in plan.describe() and "one-launch" in plan.describe(), plan.describe()
+            for batch in (1, 7):
+                x = np.stack([hash_normal(40 + b, n) for b in range(batch)]).astype(dtype)
+                for code in range(5):
+                    ref = oracle.transform_batch(x, code)
+                    a = run_batch(plan, x, code)
+                    assert rel_l2(a, ref) <= tol, (n, code, rel_l2(a, ref))
+                    assert np.array_equal(run_batch(plan, x, code, inplace=True), a), (n, code)
+            assert max_rel(run_batch(plan, x[:1], 0)[0], naive_dft(x[0])) <= (3e-6 if dtype == np.complex64 else 5e-13), n  # (the naive sum itself: 1e-13 at 511 points)
+            plan.set_option("bluestein_smooth_m", 0)
+            assert "registers" not in plan.describe() and "bluestein M=" in plan.describe(), plan.describe()
+            assert rel_l2(run_batch(plan, x, 0), oracle.transform_batch(x, 0)) <= tol, n
+        # every kernel of the menu, forced: the largest n its M reaches, a ragged batch
+        menu = [36, 49, 64, 81, 100, 120, 144, 168, 196, 225, 256, 288, 324, 360, 400, 441, 480, 525, 576, 625, 675, 729, 784, 840, 900, 960, 1024]
+        if dtype == np.complex64:
+            menu += [1152]
+        menu3 = [1296, 1440, 1600, 2304, 2560, 3072, 8820, 9261]  # M = R1 x R2 x R3: a workgroup per transform, three register stages each way
+        full, menu = menu + menu3, menu + (menu3[::2] if dtype == np.complex64 else menu3[1::2])
+        def rough(n):  # a prime factor above 13: a Bluestein length
+            for p in (2, 3, 5, 7, 11, 13):
+                while n % p == 0:
+                    n //= p
+            return n > 1
+        for m in menu:
+            n = next(v for v in range((m + 1) // 2, 0, -1) if rough(v))
+            plan = make(fa, n, dtype)
+            plan.set_option("bluestein_smooth_m", 2)
+            assert f"bluestein M={min(v for v in full if v >= 2 * n - 1)} registers" in plan.describe(), (n, plan.describe())
+            x = np.stack([hash_normal(90 + b, n) for b in range(5 if m <= 1152 else 3)]).astype(dtype)
+            truth = np.fft.fft(x.astype(np.complex128), axis=1)
+            assert rel_l2(run_batch(plan, x, 0), truth) <= (1e-6 if dtype == np.complex64 else 3e-15), (m, rel_l2(run_batch(plan, x, 0), truth))
+            back = run_batch(plan, run_batch(plan, x, 0), 1)
+            assert rel_l2(back, x) <= (2e-6 if dtype == np.complex64 else 6e-15), m
+
+
 def test_bluestein_fusion_matches_unfused(fa):
     """The fused Bluestein forms (whole chirp-z in one launch for M <= 2^15; chirp steps fused into the
     inner passes above) give the same values, to rounding, as the separate blu_pre / blu_post sweeps
@@ -312,7 +359,7 @@ def test_bluestein_fusion_matches_unfused(fa):
             a, b = run_batch(fused, x, code), run_batch(plain, x, code)
             assert rel_l2(a, b) <= 3e-7, (n, code, rel_l2(a, b))
             assert np.array_equal(run_batch(fused, x, code, inplace=True), a), (n, code)
-    assert "fused" in make(fa, 3001, np.complex64).describe()
+    assert "fused" in make(fa, 3001, np.complex64).describe() and "fused" in make(fa, 1013, np.complex64).describe()
 
 
 def test_lane_per_transform_and_small_row_kernels_with_ragged_batches(fa):
@@ -693,8 +740,13 @@ def test_lds_layouts_are_bank_conflict_light(fa):
     assert out.returncode == 0, out.stderr[-2000:]
     rows = [l.split() for l in out.stdout.strip().splitlines() if len(l.split()) == 3]
     assert len(rows) == 21, out.stdout
-    for n, real, ratio in rows[:15]:
+    for n, real, ratio in rows[:8]:
         assert float(ratio) <= (1.1 if n == str(1 << 20) else 1.0), (n, real, ratio)
+    # short Bluestein lengths: since session 45 the chirp-z kernels in registers (kernels_chirpz.h; 439 f32 stays on the row-mode kernels): padded
+    # planes, 16-byte elements -- conflict-free at 9 x 9 and 20 x 20, 1.08 at 30 x 30 (SQ_LDS_BANK_CONFLICT on the GPU: 0 and 7.7 %,
+    # profiles/r06_s45_sq_chirpz_reg.json), 1.25 at 14 x 14; the LDS instructions are 5 % of these kernels' wave cycles
+    for n, real, ratio in rows[8:15]:
+        assert float(ratio) <= 1.25, (n, real, ratio)
     for n, real, ratio in rows[15:]:  # round 6: the register-tile passes (two-pass plans and the three Bluestein sweeps on a smooth M)
         assert float(ratio) <= 1.05, (n, real, ratio)
 
@@ -992,5 +1044,5 @@ def test_every_route_string_describe_can_return_is_named_in_the_public_header(fa
     visit(59049)
     monkeypatch.delenv("FOURIER_NO_TILED_MIXED")
     # every route family was actually visited
-    for must in ("stockham tiny", "one-launch", "mixed tiles", "mixed-radix", "global-pass", "bluestein M=", "fused"):
+    for must in ("stockham tiny", "one-launch", "mixed tiles", "mixed-radix", "global-pass", "bluestein M=", "fused", "registers"):
         assert any(must.replace("M=", "M=") in s for s in seen), (must, sorted(seen))

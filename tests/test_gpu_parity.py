@@ -1450,6 +1450,20 @@ def test_bluestein_smooth_work_array_only_where_it_pays(torch, fa):
                      (90001, np.complex128), (999983, np.complex64)):
         d = make(fa, n, dtype).describe()
         assert "bluestein" in d and "mixed tiles" not in d, (n, d)
+    # short lengths: f64 takes the register route wherever its menu reaches (2N - 1 <= 1024), f32 only where that M is a tenth shorter than the
+    # power of two (or up to 64 points) -- the reference's own bench sizes 222 and 439 (fft_bench.rs:157-158) stay on the power-of-two kernels
+    for n in (59, 127, 222, 439, 511, 863, 1013, 1700, 3001):
+        d = make(fa, n, np.complex64).describe()
+        assert "bluestein" in d and "registers" not in d, (n, d)
+    for n, want in ((17, "M=36 registers 6x6"), (31, "M=64 registers 8x8"), (191, "M=400 registers 20x20"), (575, "M=1152 registers 36x32")):
+        assert want in make(fa, n, np.complex64).describe(), n
+    for n, want in ((59, "M=120 registers 12x10"), (127, "M=256 registers 16x16"), (222, "M=480 registers 24x20"), (439, "M=900 registers 30x30"), (511, "M=1024 registers 32x32")):
+        assert want in make(fa, n, np.complex128).describe(), n
+    # from 2N - 1 > 1152 on: M = R1 x R2 x R3 (a workgroup per transform) where that is at least 1.25 x shorter than the power of two
+    for n, dtype, want in ((647, np.complex64, "M=1296 registers 12x12x9"), (722, np.complex128, "M=1600 registers 16x10x10"), (1031, np.complex64, "M=2304 registers 16x12x12"),
+                           (1418, np.complex64, "M=3072 registers 16x16x12"), (4097, np.complex128, "M=8820 registers 21x21x20"), (4099, np.complex64, "M=8820 registers 21x21x20")):
+        assert want in make(fa, n, dtype).describe(), (n, make(fa, n, dtype).describe())
+    assert "registers" not in make(fa, 863, np.complex128).describe() and "registers" not in make(fa, 5003, np.complex128).describe()
     with pytest.raises(fa.FourierError):
         make(fa, 4096, np.complex64).set_option("bluestein_smooth_m", 0)
     with pytest.raises(fa.FourierError):
@@ -1479,3 +1493,52 @@ def test_register_resident_tile_passes_against_the_lds_tile_passes(torch, fa, fa
         assert np.array_equal(gpu_batch(torch, fa, reg, x, code, inplace=True), a), (n, code)
     if n != 15625:  # (125 x 125: both plans run the LDS kernel)
         assert not np.array_equal(gpu_batch(torch, fa, reg, x, 0), gpu_batch(torch, fa, lds, x, 0))  # two different kernels really ran
+
+
+CHIRPZ_REG3_MENU = [1296, 1440, 1600, 2304, 2560, 3072, 8820, 9261]  # M = R1 x R2 x R3
+CHIRPZ_REG_MENU = [36, 49, 64, 81, 100, 120, 144, 168, 196, 225, 256, 288, 324, 360, 400, 441, 480, 525, 576, 625, 675, 729, 784, 840, 900, 960, 1024]
+
+
+def _bluestein_length(n):  # a prime factor above 13
+    for p in (2, 3, 5, 7, 11, 13):
+        while n % p == 0:
+            n //= p
+    return n > 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_one_launch_chirpz_on_a_smooth_m_in_registers(torch, fa, oracle, dtype):
+    """Round 6 (kernels_chirpz.h): a short Bluestein length runs the whole chirp-z in ONE launch on M = R1 x R2 >= 2N - 1
+    (bluesteins.rs:110 asks for no more; the reference takes the next power of two) with both M-point transforms in registers and 64 / R1
+    lane groups per one-wave workgroup -- or, from 2N - 1 > 1152 on, on M = R1 x R2 x R3 <= 9261 with a workgroup per transform and three
+    register stages each way.  Every kernel of the menu, forced (plan option bluestein_smooth_m = 2), at the longest Bluestein length
+    its M reaches: all five codes against the oracle, the f64 truth, in place, a batch that does not fill the last wave, against the
+    power-of-two kernels (option 0) -- and the default rule on the reference's own prime bench sizes (fft_bench.rs:158)."""
+    menu = CHIRPZ_REG_MENU + ([1152] if dtype == np.complex64 else []) + CHIRPZ_REG3_MENU
+    tol = 2e-6 if dtype == np.complex64 else 1e-12  # f64: the ORACLE's unreduced chirp angle (bluesteins.rs:10,31,57)
+    for m in menu:
+        n = next(v for v in range((m + 1) // 2, 0, -1) if _bluestein_length(v))
+        plan, pow2 = make(fa, n, dtype), make(fa, n, dtype)
+        plan.set_option("bluestein_smooth_m", 2)
+        pow2.set_option("bluestein_smooth_m", 0)
+        assert f"bluestein M={min(v for v in menu if v >= 2 * n - 1)} registers" in plan.describe() and "one-launch" in plan.describe(), (n, plan.describe())
+        assert "registers" not in pow2.describe() and "M=%d " % (1 << int(np.ceil(np.log2(2 * n - 1)))) in pow2.describe(), pow2.describe()
+        batch = 133 if m <= 1152 else 7
+        x = np.stack([hash_uniform(5100 + b, n) for b in range(batch)]).astype(dtype)
+        truth = torch.fft.fft(torch.from_numpy(x).to(torch.complex128)).numpy()
+        for code in range(5):
+            a = gpu_batch(torch, fa, plan, x, code)
+            assert np.array_equal(gpu_batch(torch, fa, plan, x, code, inplace=True), a), (n, code)
+            assert rel_l2(a, gpu_batch(torch, fa, pow2, x, code)) <= (4e-7 if dtype == np.complex64 else 4e-15), (n, code)
+            if code in (0, 3):
+                ref = oracle.transform_batch(x[:7], code)
+                assert rel_l2(a[:7], ref) <= tol, (n, code, rel_l2(a[:7], ref))
+        assert rel_l2(gpu_batch(torch, fa, plan, x, 0), truth) <= (4e-7 if dtype == np.complex64 else 4e-15), n
+        back = gpu_batch(torch, fa, plan, gpu_batch(torch, fa, plan, x, 0), 1)
+        assert rel_l2(back, x) <= (6e-7 if dtype == np.complex64 else 6e-15), n
+        d = torch.from_numpy(x).cuda()
+        names = [p[0] for p in plan.profile_batch_ptr(d.data_ptr(), torch.empty_like(d).data_ptr(), batch, 0, 0) if p[2] > 0]
+        assert names == ["bluestein_one_launch"], names
+    with pytest.raises(fa.FourierError):
+        make(fa, 400, dtype).set_option("bluestein_smooth_m", 2)  # not a Bluestein length

@@ -14,6 +14,9 @@ if len(sys.argv) > 5:
 cdt = torch.complex64 if real == "f32" else torch.complex128
 x = torch.empty((batch, n), dtype=cdt, device="cuda"); torch.view_as_real(x).uniform_(0, 1); y = torch.empty_like(x)
 plan = (F.create_fft_f32 if real == "f32" else F.create_fft_f64)(n, 0)
+for kv in os.environ.get("RUN_CONFIG_OPTIONS", "").split(","):  # plan options, e.g. RUN_CONFIG_OPTIONS=bluestein_smooth_m:2
+    if kv:
+        plan.set_option(kv.split(":")[0], int(kv.split(":")[1]))
 for _ in range(reps):
     plan.transform(x, y, F.Transform.Fft)
 torch.cuda.synchronize()
