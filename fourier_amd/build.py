@@ -49,9 +49,9 @@ def gen_rtc_sources():
     return gen_rtc_sources.main()
 
 
-def mix_shards():
+def mix_shards(name="MIX"):
     with open(os.path.join(CSRC, "engine_common.h")) as f:
-        return int(re.search(r"#define FOURIER_MIX_SHARDS (\d+)", f.read()).group(1))
+        return int(re.search(r"#define FOURIER_%s_SHARDS (\d+)" % name, f.read()).group(1))
 
 
 def translation_units():
@@ -66,6 +66,8 @@ def translation_units():
         d = [f"-DFOURIER_TU_REAL={real}"]
         for i in range(mix_shards()):  # the longest compilations first
             tus.append((f"kernels_mixed_ct_{tag}_{i}", "kernels_mixed_ct.cpp", d + [f"-DFOURIER_MIX_SHARD={i}"], "mixed"))
+        for i in range(mix_shards("REGFFT")):
+            tus.append((f"kernels_regfft_{tag}_{i}", "kernels_regfft.cpp", d + [f"-DFOURIER_REGFFT_SHARD={i}"], "chirpz"))
     for real, tag in (("float", "f32"), ("double", "f64")):
         d = [f"-DFOURIER_TU_REAL={real}"]
         tus.append((f"kernels_pass_{tag}", "kernels_pass.cpp", d, "pass"))

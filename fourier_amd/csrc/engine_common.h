@@ -219,6 +219,10 @@ template <typename T> struct Real {};
 #define FOURIER_MIX_SHARDS 8
 #define FOURIER_MIX_SHARD_LIST(X, T) X(0, T) X(1, T) X(2, T) X(3, T) X(4, T) X(5, T) X(6, T) X(7, T)
 #define FOURIER_DECLARE_MIX_SHARD(I, T) bool get_mixed_ct_kernel_s##I(Real<T>, size_t n, MixKernel& k);
+// ... and the per-length register-stage kernels (kernels_regfft.cpp; fourier_amd/build.py reads this line too)
+#define FOURIER_REGFFT_SHARDS 8
+#define FOURIER_REGFFT_SHARD_LIST(X, T) X(0, T) X(1, T) X(2, T) X(3, T) X(4, T) X(5, T) X(6, T) X(7, T)
+#define FOURIER_DECLARE_REGFFT_SHARD(I, T) ChirpzKernel get_regfft_kernel_s##I(Real<T>, uint32_t n);
 #define FOURIER_DECLARE_REGISTRY(T)                                                                                    \
   /* kernels_pass.cpp: one tile shape (CG) per pass length L; conv = forward LAST + (.) w + inverse FIRST */           \
   KernelInfo get_kernel(Real<T>, int L, int mode, int io);                                                             \
@@ -249,6 +253,10 @@ template <typename T> struct Real {};
   ChirpzKernel get_chirpz_kernel(Real<T>, uint32_t m);                                                                 \
   ChirpzKernel get_chirpz_kernel_s0(Real<T>, uint32_t m); ChirpzKernel get_chirpz_kernel_s1(Real<T>, uint32_t m);     \
   ChirpzKernel get_chirpz_kernel_s2(Real<T>, uint32_t m); ChirpzKernel get_chirpz_kernel_s3(Real<T>, uint32_t m);     \
+  /* kernels_regfft.cpp (FOURIER_REGFFT_SHARDS shards): a length with factors 5 ... 13 as a direct transform on the same register */ \
+  /* stages, n = R1 x R2 [x R3], the lengths of regfft_shapes.h; fn == nullptr: none                                              */ \
+  ChirpzKernel get_regfft_kernel(Real<T>, uint32_t n);                                                                 \
+  FOURIER_REGFFT_SHARD_LIST(FOURIER_DECLARE_REGFFT_SHARD, T)                                                           \
   /* kernels_experiments.cpp (experiments library) or env_product.cpp (product: nothing available) */                  \
   bool get_fused_kernel(Real<T>, int k, FusedInfo& info);                                                              \
   KernelInfo get_split_kernel(Real<T>, int L, int io);                                                                 \

@@ -404,8 +404,12 @@ template <typename T> class BluRegEngine {
       if ((uint64_t)m >= 2 * (uint64_t)n - 1) return m;
     return 0;
   }
-  BluRegEngine(size_t n_user, uint32_t m) : n_(n_user), k_(get_chirpz_kernel(Real<T>{}, m)) {
-    if (!k_.fn || (uint64_t)m < 2 * (uint64_t)n_user - 1) throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "no one-launch chirp-z kernel of this length");
+  // direct: the same register stages as a plain transform of n_user = m points (kernels_regfft.h) -- lengths with factors 5 ... 13
+  static bool has_direct(size_t n) { return n <= 16384 && !dev_env("FOURIER_NO_REGFFT") && get_regfft_kernel(Real<T>{}, (uint32_t)n).fn != nullptr; }
+  BluRegEngine(size_t n_user, uint32_t m, bool direct = false)
+      : n_(n_user), direct_(direct), k_(direct ? get_regfft_kernel(Real<T>{}, m) : get_chirpz_kernel(Real<T>{}, m)) {
+    if (!k_.fn || (direct ? (uint64_t)m != n_user : (uint64_t)m < 2 * (uint64_t)n_user - 1))
+      throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "no one-launch register kernel of this length");
     raise_smem_limit((const void*)k_.fn, k_.smem);
     std::vector<cpx<T>> tw;
     auto root = [&](uint64_t e, uint64_t size) {
@@ -435,6 +439,7 @@ template <typename T> class BluRegEngine {
   std::string describe() const {
     return "registers " + std::to_string(k_.r1) + "x" + std::to_string(k_.r2) + (k_.r3 ? "x" + std::to_string(k_.r3) : std::string()) + " one-launch";
   }
+  bool direct() const { return direct_; }
   // in, out: user arrays (n per transform); in == out is fine: a wave reads its transforms completely before it writes them
   void run(const cpx<T>* in, cpx<T>* out, size_t batch, const void* xtab, const void* wtab, bool inverse, double scale, hipStream_t stream,
            Profiler* prof) const {
@@ -452,6 +457,7 @@ template <typename T> class BluRegEngine {
 
  private:
   size_t n_;
+  bool direct_ = false;
   ChirpzKernel k_;
   DevBuf tw_;
 };

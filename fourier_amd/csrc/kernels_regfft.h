@@ -1,0 +1,161 @@
+// kernels_regfft.h -- a length with factors 5 ... 13 as a DIRECT transform in one launch on the register stages of kernels_chirpz.h (round 6,
+// sessions 48 - 49): N = R1 x R2 (x R3), one Cooley-Tukey step between register-resident transforms, ONE LDS exchange per step.
+//
+// The reference sends every length that is not 2^a 3^b to Bluestein (fourier/src/lib.rs:38-42: Autosort::new fails, autosort/mod.rs:24-46).
+// Here such lengths had the LDS mixed-radix kernels (kernels_mixed.h): a per-length kernel for the common ones, the runtime-parameterised
+// kernel for the rest (factors 7 / 11 / 13: 0.25 ... 0.35 of the HBM peak, one LDS round trip per SMALL radix, four to six per transform).
+// regfft_kernel / regfft3_kernel are ahead-of-time kernels per length (regfft_shapes.h, kernels_regfft.cpp) that keep the lane layout, the
+// packed f32 arithmetic (two transforms per lane) and the exchange layouts of the chirp-z kernels' forward half.  Tolerance-only route like
+// every length beyond 2^a 3^b (include/fourier.h); 2^a 3^b keep the reference's own schedule (bit-identical to the CPU restatement).
+#pragma once
+#include "kernels_chirpz.h"
+
+namespace fourier_hip {
+
+// n = j2 + R2*j1: DFT_R1 over j1 -> k1; W_N^{j2*k1}; DFT_R2 over j2 -> k2: X[k1 + R1*k2] -- loads coalesced along j2, stores along k1, ONE exchange.
+// Inverse = swap . DFT . swap at the load and the store; the five scalings on the store (fft.rs:4-16).
+template <typename T, uint32_t R1, uint32_t R2>
+__global__ void __launch_bounds__(64, (ChirpzRegCfg<T, R1, R2>::MINW)) regfft_kernel(ChirpzArgs a) {
+  using C = ChirpzRegCfg<T, R1, R2>;
+  using P = typename C::P;
+  using LV = LaneVal<P, T>;
+  constexpr uint32_t GPW = C::GPW, TPW = C::TPW, NV = C::NV, P1 = C::P1, N = R1 * R2;
+  constexpr uint32_t EB = (uint32_t)sizeof(cpx<T>), XB = (uint32_t)sizeof(cpx<P>);
+  FOURIER_DYN_SMEM(smem);
+  const uint32_t lane = threadIdx.x, c = lane / R1, q = lane - c * R1;
+  const bool active = c < GPW;
+  const uint64_t b0 = (uint64_t)blockIdx.x * TPW;
+  const uint32_t nb = a.batch - b0 < TPW ? (uint32_t)(a.batch - b0) : TPW;
+  const BufRsrc rin = make_rsrc((const cpx<T>*)a.in + b0 * N, nb * N * EB), rout = make_rsrc((cpx<T>*)a.out + b0 * N, nb * N * EB);
+  cpx<P>* xb = (cpx<P>*)smem + (active ? c : 0u) * (R1 * P1);
+  const uint32_t tbase = c * NV * N;
+  if (active && q < R2) {
+    cpx<P> x[R1];
+    cpx<T> d[NV][R1];
+#pragma unroll
+    for (uint32_t j1 = 0; j1 < R1; ++j1)
+#pragma unroll
+      for (uint32_t v = 0; v < NV; ++v) d[v][j1] = buf_load_elem<T>(rin, (tbase + v * N + q + R2 * j1) * EB);
+#pragma unroll
+    for (uint32_t j1 = 0; j1 < R1; ++j1) {
+      T re[NV], im[NV];
+#pragma unroll
+      for (uint32_t v = 0; v < NV; ++v) { re[v] = d[v][j1].re; im[v] = d[v][j1].im; }
+      x[j1] = a.swap ? cpx<P>{LV::make(im), LV::make(re)} : cpx<P>{LV::make(re), LV::make(im)};
+    }
+    dft_any<P, (int)R1>(x);
+#pragma unroll
+    for (uint32_t k1 = 0; k1 < R1; ++k1) {
+      cpx<P>* p = xb + k1 * P1 + q;
+      LDS_NOTE(p, XB, true, 340);
+      *p = x[k1];
+    }
+  }
+  __syncthreads();
+  if (active) {
+    cpx<P> y[R2];
+#pragma unroll
+    for (uint32_t j2 = 0; j2 < R2; ++j2) {
+      const cpx<P>* p = xb + q * P1 + j2;
+      LDS_NOTE(p, XB, false, 341);
+      y[j2] = *p;
+    }
+    chirpz_table_product<P, T, R2, 8u>(y, (const cpx<T>*)a.tw + q, R1, false);
+    dft_any<P, (int)R2>(y);
+    const T scale = (T)a.scale;
+#pragma unroll
+    for (uint32_t k2 = 0; k2 < R2; ++k2) {
+      const cpx<P> o = a.swap ? cpx<P>{y[k2].im, y[k2].re} : y[k2];
+#pragma unroll
+      for (uint32_t v = 0; v < NV; ++v)
+        buf_store_elem<T>(rout, (tbase + v * N + q + R1 * k2) * EB, cpx<T>{LV::get(o.re, v) * scale, LV::get(o.im, v) * scale});
+    }
+  }
+}
+
+// N = R1 x R2 x R3: a workgroup per transform (f32: per pair), lanes and exchanges as the forward half of chirpz_reg3_kernel; X[a + R1R2*k3] leaves
+// stage C's lanes a = k1 + R1*k2 coalesced
+template <typename T, uint32_t R1, uint32_t R2, uint32_t R3>
+__global__ void __launch_bounds__((Chirpz3Cfg<T, R1, R2, R3>::NT), (Chirpz3Cfg<T, R1, R2, R3>::MINW)) regfft3_kernel(ChirpzArgs a) {
+  using C = Chirpz3Cfg<T, R1, R2, R3>;
+  using P = typename C::P;
+  using LV = LaneVal<P, T>;
+  constexpr uint32_t NV = C::NV, LA = C::LA, LB = C::LB, LC = C::LC, S1 = C::S1, S2 = C::S2, N = C::M;
+  constexpr uint32_t EB = (uint32_t)sizeof(cpx<T>), XB = (uint32_t)sizeof(cpx<P>), TB = 8u;
+  FOURIER_DYN_SMEM(smem);
+  cpx<P>* xb = (cpx<P>*)smem;
+  const uint32_t t = threadIdx.x;
+  const uint64_t b0 = (uint64_t)blockIdx.x * NV;
+  const uint32_t nb = a.batch - b0 < NV ? (uint32_t)(a.batch - b0) : NV;
+  const BufRsrc rin = make_rsrc((const cpx<T>*)a.in + b0 * N, nb * N * EB), rout = make_rsrc((cpx<T>*)a.out + b0 * N, nb * N * EB);
+  const cpx<T>* t1 = (const cpx<T>*)a.tw;   // [j2 < R2][lane k1*R3 + j3]: W_N^{(j3 + R3*j2) * k1}
+  const cpx<T>* t2 = t1 + (size_t)R2 * LB;  // [k2 < R2][j3 < R3]: W_{R2R3}^{j3 * k2}
+  if (t < LA) {
+    cpx<P> x[R1];
+    cpx<T> d[NV][R1];
+#pragma unroll
+    for (uint32_t j1 = 0; j1 < R1; ++j1)
+#pragma unroll
+      for (uint32_t v = 0; v < NV; ++v) d[v][j1] = buf_load_elem<T>(rin, (v * N + t + LA * j1) * EB);
+#pragma unroll
+    for (uint32_t j1 = 0; j1 < R1; ++j1) {
+      T re[NV], im[NV];
+#pragma unroll
+      for (uint32_t v = 0; v < NV; ++v) { re[v] = d[v][j1].re; im[v] = d[v][j1].im; }
+      x[j1] = a.swap ? cpx<P>{LV::make(im), LV::make(re)} : cpx<P>{LV::make(re), LV::make(im)};
+    }
+    dft_any<P, (int)R1>(x);
+    const uint32_t j2 = t / R3, j3 = t - j2 * R3;
+#pragma unroll
+    for (uint32_t k1 = 0; k1 < R1; ++k1) {
+      cpx<P>* p = xb + j2 * S1 + k1 * R3 + j3;
+      LDS_NOTE(p, XB, true, 350);
+      *p = x[k1];
+    }
+  }
+  __syncthreads();
+  cpx<P> y[R2];
+  if (t < LB) {
+#pragma unroll
+    for (uint32_t j2 = 0; j2 < R2; ++j2) {
+      const cpx<P>* p = xb + j2 * S1 + t;
+      LDS_NOTE(p, XB, false, 351);
+      y[j2] = *p;
+    }
+    chirpz_table_product<P, T, R2, TB>(y, t1 + t, LB, false);
+    dft_any<P, (int)R2>(y);
+    FOURIER_SCHED_FENCE();
+    chirpz_table_product<P, T, R2, TB>(y, t2 + t % R3, R3, false);
+  }
+  __syncthreads();  // exchange 1 is read
+  if (t < LB) {
+    const uint32_t k1 = t / R3, j3 = t - k1 * R3;
+#pragma unroll
+    for (uint32_t k2 = 0; k2 < R2; ++k2) {
+      cpx<P>* p = xb + j3 * S2 + k1 + R1 * k2;
+      LDS_NOTE(p, XB, true, 352);
+      *p = y[k2];
+    }
+  }
+  __syncthreads();
+  if (t < LC) {
+    cpx<P> z[R3];
+#pragma unroll
+    for (uint32_t j3 = 0; j3 < R3; ++j3) {
+      const cpx<P>* p = xb + j3 * S2 + t;
+      LDS_NOTE(p, XB, false, 353);
+      z[j3] = *p;
+    }
+    dft_any<P, (int)R3>(z);
+    const T scale = (T)a.scale;
+#pragma unroll
+    for (uint32_t k3 = 0; k3 < R3; ++k3) {
+      const cpx<P> o = a.swap ? cpx<P>{z[k3].im, z[k3].re} : z[k3];
+#pragma unroll
+      for (uint32_t v = 0; v < NV; ++v)
+        buf_store_elem<T>(rout, (v * N + t + LC * k3) * EB, cpx<T>{LV::get(o.re, v) * scale, LV::get(o.im, v) * scale});
+    }
+  }
+}
+
+}  // namespace fourier_hip

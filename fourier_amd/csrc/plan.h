@@ -98,6 +98,11 @@ template <typename T> class Plan {
       // big-radix passes over the 2^a part (a >= 12), then a radix-3^b pass: three HBM round trips at full tile
       // efficiency beat the one-workgroup-per-CU LDS kernel where both apply (3*2^12 f32: 23 % vs 14 %)
       eng_.reset(new Pow2Engine<T>(n));
+    } else if (regfft_route(n)) {
+      // a length with factors 5 ... 13 that regfft_shapes.h lists in this precision: ONE launch with the transform on two or three register
+      // stages (kernels_regfft.h) instead of the LDS mixed-radix kernel's round trip per small radix, two tile passes or Bluestein -- each
+      // length at least 1.04 x faster than the route below it had (profiles/r06_s49 ... s51_regfft_*_ab.jsonl)
+      regf_.reset(new BluRegEngine<T>(n, (uint32_t)n, true));
     } else if (MixedEngine<T>::handles(n) && try_mixed(n)) {
       // a length on the runtime-parameterised kernel takes its own kernel where the code-object cache has it (policy 2: compiles it)
       if (specialise_policy() >= 1) (void)mix_->specialise(nullptr, specialise_policy() >= 2);
@@ -150,6 +155,13 @@ template <typename T> class Plan {
     w = "not a length whose prime factors stop at 13 with a kernel to specialise";
     return false;
   }
+  // 2^a 3^b keep the LDS kernels on the reference's own schedule (bit-identical to the CPU restatement)
+  static bool regfft_route(size_t n) {
+    size_t p = n;
+    while (p % 2 == 0) p /= 2;
+    while (p % 3 == 0) p /= 3;
+    return p != 1 && BluRegEngine<T>::has_direct(n);
+  }
   static bool tiled_before_pow2_tiles(size_t n) {
     if (!Pow2Engine<T>::handles_mixed(n) || dev_env("FOURIER_POW2_TILES_FIRST") || !TiledMixedEngine<T>::handles(n, true)) return false;
     const std::vector<uint32_t> f = TiledMixedEngine<T>::factorise(n);
@@ -166,7 +178,8 @@ template <typename T> class Plan {
     }
   }
   void refresh_desc() {
-    if (mix_) desc_ = "stockham mixed-radix " + mix_->describe();
+    if (regf_) desc_ = "stockham " + regf_->describe();
+    else if (mix_) desc_ = "stockham mixed-radix " + mix_->describe();
     else if (tiled_) desc_ = "stockham mixed tiles " + tiled_->describe();
     else if (gen_) desc_ = "stockham global-pass " + gen_->describe();
     else if (blur_) desc_ = "bluestein M=" + std::to_string(m_) + " " + blur_->describe();
@@ -194,6 +207,7 @@ template <typename T> class Plan {
   // kernel "slots" in launch order, as reported by profile(): names for bench.py / rocprof matching
   std::string slot_names() const {
     std::string d;
+    if (regf_) return "registers_one_launch";
     if (mix_) return "mixed_radix";
     if (tiled_) { for (size_t p = 0; p < tiled_->num_passes(); ++p) d += std::string(d.empty() ? "" : ",") + "pass" + std::to_string(p); return d; }
     if (gen_) { for (size_t p = 0; p < gen_->num_passes(); ++p) d += std::string(d.empty() ? "" : ",") + "pass" + std::to_string(p); return d; }
@@ -213,7 +227,7 @@ template <typename T> class Plan {
   }
 
   double model_bytes() const {
-    if (mix_) return 2.0 * n_ * ELEM;
+    if (mix_ || regf_) return 2.0 * n_ * ELEM;
     if (tiled_) return 2.0 * n_ * ELEM * tiled_->num_passes();
     if (gen_) return 2.0 * n_ * ELEM * gen_->num_passes();
     if (!blu_) return 2.0 * n_ * ELEM * eng_->hbm_round_trips();
@@ -303,6 +317,7 @@ template <typename T> class Plan {
         if (st != ::fourier::c::FOURIER_HIP_OK && getenv("FOURIER_HIP_VERBOSE")) fprintf(stderr, "libfourier: specialise(%zu): %s\n", n_, why.c_str());
         return st;
       };
+      if (regf_) return ::fourier::c::FOURIER_HIP_OK;  // already on a kernel of its own
       if (mix_) { const int st = mix_->specialise(&why); refresh_desc(); return report(st); }
       if (blu_) {  // exec() takes the new route from here on; the Bluestein tables stay allocated but unused
         if (specialised_route(n_, true, &why)) { refresh_desc(); return ::fourier::c::FOURIER_HIP_OK; }
@@ -355,7 +370,7 @@ template <typename T> class Plan {
   // transform_batch of at most that batch never allocates (hipMalloc / hipFree synchronise the device) and can be
   // captured into a HIP graph.  Returns the number of transforms per chunk.
   size_t prepare(size_t batch, bool in_place) const {
-    if (mix_ || batch == 0) return batch;
+    if (mix_ || regf_ || batch == 0) return batch;
     if (tiled_) {  // one scratch of a chunk for in-place calls and three-pass plans
       size_t chunk = batch;
       if (chunk_bytes_) chunk = std::max<size_t>(1, std::min<size_t>(batch, chunk_bytes_ / (n_ * ELEM)));
@@ -435,6 +450,10 @@ template <typename T> class Plan {
     const cpx<T>* in = (const cpx<T>*)d_in;
     cpx<T>* out = (cpx<T>*)d_out;
     const bool in_place = (d_in == d_out);
+    if (regf_) {  // the whole transform in registers: one launch, in place allowed (a workgroup reads its transforms first)
+      regf_->run(in, out, batch, nullptr, nullptr, inverse, scale, stream, prof);
+      return;
+    }
     if (mix_) {  // every pass stays in LDS: one launch, in place allowed (a workgroup reads its transforms first)
       const bool scaled = code == ::fourier::c::FOURIER_TRANSFORM_IFFT || code == ::fourier::c::FOURIER_TRANSFORM_SQRT_SCALED_FFT ||
                           code == ::fourier::c::FOURIER_TRANSFORM_SQRT_SCALED_IFFT;  // mod.rs:381-385
@@ -832,6 +851,7 @@ template <typename T> class Plan {
   std::unique_ptr<Pow2Engine<T>> eng_, eng_inv_;  // eng_inv_: mirrored inverse plan of a conv-fused Bluestein
   std::unique_ptr<BluTiledEngine<T>> blut_;       // Bluestein on a smooth M (then eng_ is empty)
   std::unique_ptr<BluRegEngine<T>> blur_;         // ... of a short transform: one launch, transforms in registers (then eng_ is empty)
+  std::unique_ptr<BluRegEngine<T>> regf_;         // a length with factors 5 ... 13 as a direct transform on the same register stages
   int smooth_m_mode_ = 1;                         // option "bluestein_smooth_m"
   std::unique_ptr<MixedEngine<T>> mix_;
   std::unique_ptr<TiledMixedEngine<T>> tiled_;  // 2^a*3^b, a < 12, beyond the LDS kernels: column tiles of mixed length

@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, hash_normal, load_ref10, naive_dft, near, rel_l2, max_rel
+from helpers import GOLDEN, hash_normal, load_ref10, naive_dft, near, regfft_shape, rel_l2, max_rel
 
 F32_EPS, F64_EPS = 1e-4, 1e-11  # fourier/tests/integrity.rs:92,120
 
@@ -135,7 +135,7 @@ def test_lengths_with_prime_factors_5_to_13_run_as_stockham_passes(fa, oracle):
             if dtype == np.complex128 and n > 2048 and (n % 11 == 0 or n % 13 == 0):
                 assert "bluestein" in plan.describe()  # f64 radix 11 / 13 beyond the 256-thread kernels: does not fit the registers
                 continue
-            assert plan.describe().startswith("stockham mixed-radix"), plan.describe()
+            assert plan.describe().startswith("stockham registers" if regfft_shape(n, dtype, emu=True) else "stockham mixed-radix"), plan.describe()
             xs = x.astype(dtype)
             for code in range(5):
                 ref = oracle.transform_batch(xs, code)
@@ -345,6 +345,38 @@ def test_one_launch_chirpz_on_a_smooth_m_in_registers(fa, oracle):
             assert rel_l2(run_batch(plan, x, 0), truth) <= (1e-6 if dtype == np.complex64 else 3e-15), (m, rel_l2(run_batch(plan, x, 0), truth))
             back = run_batch(plan, run_batch(plan, x, 0), 1)
             assert rel_l2(back, x) <= (2e-6 if dtype == np.complex64 else 6e-15), m
+
+
+REGFFT_LENGTHS = (22, 77, 143, 175, 200, 245, 350, 385, 400, 560, 700, 800, 1001, 2000, 2002, 4000, 5005, 8000, 8960, 9009)  # gen_regfft_shapes.py: EMU
+
+
+def test_lengths_with_factors_5_to_13_as_one_launch_on_register_stages(fa, oracle, monkeypatch):
+    """Round 6, sessions 48 - 51 (kernels_regfft.h, regfft_kernel / regfft3_kernel): a length with factors 5 ... 13 that regfft_shapes.h lists in
+    the precision runs as a direct transform in ONE launch -- n = j2 + R2 j1, DFT_R1, twiddle, DFT_R2 (, DFT_R3) with one LDS exchange per
+    step -- instead of the LDS mixed-radix kernel's round trip per small radix (the reference: Bluestein, fourier/src/lib.rs:38-42; the oracle's
+    chirp-z is the comparison, numpy's f64 transform the truth).  All five codes, in place, batches that do not fill the last wave.  The
+    emulator build holds the lengths below of the table's 588 (those the A/B left on their earlier route keep it here too)."""
+    seen = 0
+    for dtype, tol, tol_truth in ((np.complex64, 2e-6, 4e-7), (np.complex128, 5e-12, 1e-15)):  # (f64: the ORACLE's unreduced chirp angle, 1.4e-12 at 8000)
+        for n in REGFFT_LENGTHS:
+            plan, shape = make(fa, n, dtype), regfft_shape(n, dtype, emu=True)
+            if shape is None:  # a length the A/B left on its earlier route
+                assert "registers" not in plan.describe(), plan.describe()
+                continue
+            seen += 1
+            assert f"stockham registers {shape} one-launch" in plan.describe(), plan.describe()
+            for batch in (1, 7) if n <= 1001 else (3,):
+                x = np.stack([hash_normal(60 + b, n) for b in range(batch)]).astype(dtype)
+                truth = np.fft.fft(x.astype(np.complex128), axis=1)
+                for code in range(5):
+                    a = run_batch(plan, x, code)
+                    assert rel_l2(a, oracle.transform_batch(x, code)) <= tol, (n, code)
+                    assert np.array_equal(run_batch(plan, x, code, inplace=True), a), (n, code)
+                assert rel_l2(run_batch(plan, x, 0), truth) <= tol_truth, (n, rel_l2(run_batch(plan, x, 0), truth))
+                assert rel_l2(run_batch(plan, run_batch(plan, x, 0), 1), x) <= 2 * tol_truth, n
+    assert seen >= 30, seen  # two-stage and three-stage shapes in both precisions
+    monkeypatch.setenv("FOURIER_NO_REGFFT", "1")
+    assert "mixed-radix" in make(fa, 1001, np.complex64).describe() and "mixed-radix" in make(fa, 350, np.complex128).describe()
 
 
 def test_bluestein_fusion_matches_unfused(fa):
@@ -999,8 +1031,8 @@ def test_prefetching_last_pass_is_bit_identical_to_the_plain_last_pass(fa, oracl
 def test_plan_option_specialise_is_refused_without_hiprtc_and_leaves_the_plan_alone(fa, oracle):
     """Under the emulator there is no hipRTC: "specialise" reports UNSUPPORTED (as it does on a box without libhiprtc) for a
     length of the family and for one outside it, and the plan keeps its route and its results; a length that already runs a
-    per-length kernel returns OK."""
-    for n in (1001, 9009, 1013):
+    per-length kernel -- LDS (1000) or register stages (1001, round 6) -- returns OK."""
+    for n in (3003, 11011, 1013):
         plan = make(fa, n, np.complex64)
         desc = plan.describe()
         with pytest.raises(fa.FourierError):
@@ -1008,9 +1040,11 @@ def test_plan_option_specialise_is_refused_without_hiprtc_and_leaves_the_plan_al
         assert plan.describe() == desc
         x = np.stack([hash_normal(3 + b, n) for b in range(3)]).astype(np.complex64)
         assert rel_l2(run_batch(plan, x, 0), oracle.transform_batch(x, 0)) <= 2e-6
-    plan = make(fa, 1000, np.complex64)
-    plan.set_option("specialise", 1)
-    assert "specialised" not in plan.describe()
+    for n in (1000, 1001):
+        plan = make(fa, n, np.complex64)
+        desc = plan.describe()
+        plan.set_option("specialise", 1)
+        assert plan.describe() == desc and "specialised" not in desc and ("registers" in desc) == (n == 1001)
 
 
 def test_every_route_string_describe_can_return_is_named_in_the_public_header(fa, monkeypatch):
@@ -1023,7 +1057,8 @@ def test_every_route_string_describe_can_return_is_named_in_the_public_header(fa
     routes = header[header.index("The routes, in the order they are tried"):header.index("struct fourier_fft_float *fourier_hip_create_float")]
     sizes = [4, 16, 64, 1024, 1 << 12, 1 << 14, 1 << 16, 1 << 23,  # tiny, whole rows, one-launch, two and three passes
              3 * 4096, 27 * 4096, 512 * 432, 3 << 18,              # mixed tiles (a >= 12), power-of-two passes + odd passes
-             96, 1000, 1001, 18432,                                 # LDS mixed-radix: per-length and runtime-parameterised kernels
+             96, 1000, 3003, 18432,                                 # LDS mixed-radix: per-length and runtime-parameterised kernels
+             1001, 350,                                             # register stages (three, two)
              62208, 3 ** 10 * 2, 3 ** 16, 625 * 625,                # mixed tiles (a < 12), three tile passes, tiles beyond 512 points
              100000, 44100,                                         # tile passes with factors 5 / 7
              17, 1013, 40001, 999983, 16411]                        # Bluestein: one-launch ("fused"), fused passes, smooth M

@@ -13,7 +13,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, hash_normal, hash_uniform, load_ref10, naive_dft, near, rel_l2, max_rel, sample_bins
+from helpers import GOLDEN, hash_normal, hash_uniform, load_ref10, naive_dft, near, rel_l2, max_rel, regfft_shape, sample_bins
 
 pytestmark = pytest.mark.gpu
 
@@ -1048,13 +1048,14 @@ def test_mixed_radix_sizes_beyond_the_lds_limit_with_a_small_power_of_two(torch,
             assert rel_l2(gpu_batch(torch, fa, plan, x, code, inplace=True), ref) <= tol, (n, code, route, "in place")
 
 
-@pytest.mark.parametrize("n", [5, 35, 125, 143, 625, 1000, 1001, 2401, 3125, 4095, 5005, 9100, 10000, 15625, 16807, 20000, 20480])
+@pytest.mark.parametrize("n", [5, 35, 77, 125, 143, 350, 625, 1000, 1001, 2401, 3125, 4095, 5005, 8008, 9009, 9100, 10000, 15625, 16807, 20000, 20480])
 def test_lengths_with_prime_factors_5_to_13_run_as_stockham_passes(torch, fa, oracle, n):
     """Beyond the reference (which sends them to Bluestein, fourier/src/lib.rs:38-42): lengths whose prime factors stop at
     13 run the LDS Stockham kernel with the radix list continued [4,8,4,3,2,5,7,11,13] -- per-length kernels for the
     reference's own 5^k benchmark lengths and round decimal lengths, the runtime-parameterised kernel otherwise.  All
     codes, in and out of place, a ragged batch over many workgroups; within the Bluestein tolerance of the oracle and,
-    being a direct factorisation, tighter against f64 truth."""
+    being a direct factorisation, tighter against f64 truth.  Round 6 (sessions 49 - 51): where regfft_shapes.h lists the length in the
+    precision, the transform runs on two or three register stages in one launch instead (kernels_regfft.h)."""
     batch = max(3, min(4099, (1 << 19) // n)) | 1
     x = np.stack([hash_normal(2100 + (b % 7), n) for b in range(7)])
     for dtype, tl2, ttruth in ((np.complex64, 2e-6, 4e-7), (np.complex128, 5e-11, 3e-15)):
@@ -1064,7 +1065,9 @@ def test_lengths_with_prime_factors_5_to_13_run_as_stockham_passes(torch, fa, or
             m //= 2 if m % 2 == 0 else (3 if m % 3 == 0 else 5)
         per_length = (m == 1 or n in (49, 343, 2401, 16807)) and n * np.dtype(dtype).itemsize <= 160 * 1024  # 2^a*3^b*5^c, 7^k
         f64_wide_13 = dtype == np.complex128 and n > 2048 and (n % 11 == 0 or n % 13 == 0)  # does not fit the registers
-        if not per_length and (n > 8192 or f64_wide_13):  # the runtime-parameterised kernel stops at 8192 points
+        if regfft_shape(n, dtype):
+            assert plan.describe().startswith(f"stockham registers {regfft_shape(n, dtype)} one-launch"), plan.describe()
+        elif not per_length and (n > 8192 or f64_wide_13):  # the runtime-parameterised kernel stops at 8192 points
             m7 = n
             while m7 % 2 == 0 or m7 % 3 == 0 or m7 % 5 == 0 or m7 % 7 == 0:
                 m7 //= 2 if m7 % 2 == 0 else (3 if m7 % 3 == 0 else (5 if m7 % 5 == 0 else 7))
@@ -1229,7 +1232,10 @@ def test_code_object_cache_and_the_library_wide_specialise_policy(torch, fa, ora
     "specialise_at_create" = 2 (fourier_hip_set_default_option, or FOURIER_HIP_SPECIALISE=2 in the environment of a program that
     cannot be changed) compiles a length's own kernel inside create and leaves the code object in the on-disk cache; the default
     policy 1 loads it from there in any later process -- in milliseconds, without libhiprtc --, policy 0 never does; a cache file
-    that cannot be loaded is discarded and compiled again."""
+    that cannot be loaded is discarded and compiled again.  (Round 6, sessions 49 - 51: most lengths up to 10240 points with factors 7 / 11 / 13 now
+    have ahead-of-time register-stage kernels, regfft_shapes.h -- 5005, 1001, 3003 and 9009, this test's lengths until then, among them; the
+    lengths here are ones that still take the runtime-parameterised kernel or Bluestein by default: 4459 = 7^3 13, 3773 = 7^3 11, 4802 = 2 7^4,
+    11011 = 7 11^2 13.)"""
     import shutil
     import subprocess
     import sys
@@ -1241,11 +1247,11 @@ def test_code_object_cache_and_the_library_wide_specialise_policy(torch, fa, ora
     prev = fa.get_default_option("specialise_at_create")
     try:
         fa.set_default_option("specialise_at_create", 0)
-        assert "specialised" not in make(fa, 5005, np.complex64).describe()
+        assert "specialised" not in make(fa, 4459, np.complex64).describe()
         fa.set_default_option("specialise_at_create", 1)  # cache only: the cache is empty, nothing may be compiled
-        assert "specialised" not in make(fa, 5005, np.complex64).describe() and not (cache.exists() and list(cache.iterdir()))
+        assert "specialised" not in make(fa, 4459, np.complex64).describe() and not (cache.exists() and list(cache.iterdir()))
         fa.set_default_option("specialise_at_create", 2)
-        for n, dtype, kind in ((5005, np.complex64, "mixed-radix"), (1001, np.complex128, "mixed-radix"), (9009, np.complex64, "mixed-radix"),
+        for n, dtype, kind in ((4459, np.complex64, "mixed-radix"), (4802, np.complex128, "mixed-radix"), (11011, np.complex64, "mixed-radix"),
                                (57200, np.complex64, "mixed tiles")):
             plan = make(fa, n, dtype)
             assert kind in plan.describe() and "specialised" in plan.describe(), plan.describe()
@@ -1263,8 +1269,8 @@ def test_code_object_cache_and_the_library_wide_specialise_policy(torch, fa, ora
     # later processes: the default policy (no variable), policy 0, policy 2 on a length the cache does not hold; timing of a cache hit
     prog = ("import os, sys, time, json; sys.path.insert(0, %r); import fourier_amd as fa\n"
             "fa.create_fft_f32(4096)\n"  # the HIP runtime and the library are up before the clock starts
-            "t0 = time.perf_counter(); p = fa.create_fft_f32(5005); dt = time.perf_counter() - t0\n"
-            "print(json.dumps({'d5005': p.describe(), 'create_s': dt, 'd3003': fa.create_fft_f32(3003).describe(), 'policy': fa.get_default_option('specialise_at_create')}))\n"
+            "t0 = time.perf_counter(); p = fa.create_fft_f32(4459); dt = time.perf_counter() - t0\n"
+            "print(json.dumps({'d4459': p.describe(), 'create_s': dt, 'd3773': fa.create_fft_f32(3773).describe(), 'policy': fa.get_default_option('specialise_at_create')}))\n"
             % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     def child(policy):
         env = {k: v for k, v in os.environ.items() if k != "FOURIER_HIP_SPECIALISE"}
@@ -1275,48 +1281,48 @@ def test_code_object_cache_and_the_library_wide_specialise_policy(torch, fa, ora
         assert out.returncode == 0, out.stderr[-2000:]
         return json.loads(out.stdout.strip().splitlines()[-1])
     r = child(None)
-    assert r["policy"] == 1 and "specialised" in r["d5005"] and "specialised" not in r["d3003"], r
+    assert r["policy"] == 1 and "specialised" in r["d4459"] and "specialised" not in r["d3773"], r
     assert r["create_s"] < 0.6, r  # a cache hit: read 1 file, load 1 module (a compilation takes a second or more; loose: a loaded box)
     r = child("0")
-    assert r["policy"] == 0 and "specialised" not in r["d5005"], r
+    assert r["policy"] == 0 and "specialised" not in r["d4459"], r
     r = child("2")
-    assert "specialised" in r["d5005"] and "specialised" in r["d3003"], r
+    assert "specialised" in r["d4459"] and "specialised" in r["d3773"], r
     # a cache directory that cannot be created, or none at all (empty variable): compilation still works, nothing is cached
     for bad in ("/proc/fourier-hip-no-such-dir/x", ""):
         env = {k: v for k, v in os.environ.items() if k != "FOURIER_HIP_SPECIALISE"}
         env.update(FOURIER_HIP_CACHE_DIR=bad, FOURIER_HIP_SPECIALISE="2")
         out = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
-        assert "specialised" in json.loads(out.stdout.strip().splitlines()[-1])["d5005"], (bad, out.stdout)
+        assert "specialised" in json.loads(out.stdout.strip().splitlines()[-1])["d4459"], (bad, out.stdout)
     # a cache file somebody else could have written is not trusted (a code object runs on the device): ignored, left alone
-    victim = next(p for p in cache.iterdir() if "-n5005-" in p.name)
+    victim = next(p for p in cache.iterdir() if "-n4459-" in p.name)
     victim.chmod(0o666)
     r = child(None)
-    assert "specialised" not in r["d5005"] and victim.exists(), r
+    assert "specialised" not in r["d4459"] and victim.exists(), r
     victim.chmod(0o600)
-    assert "specialised" in child(None)["d5005"]
+    assert "specialised" in child(None)["d4459"]
     # ... nor is an entry in a directory somebody else may write, nor one behind a symbolic link (another user of a shared
     # cache directory could link one of the victim's own entries under another length's name -- a wrong-length kernel would then run out
     # of bounds on the device); an entry also names its own key, so a renamed copy is refused (and discarded: the file is ours)
     cache.chmod(0o777)
-    assert "specialised" not in child(None)["d5005"]
+    assert "specialised" not in child(None)["d4459"]
     cache.chmod(0o700)
-    assert "specialised" in child(None)["d5005"]
-    other = next(p for p in cache.iterdir() if "-n9009-" in p.name)
+    assert "specialised" in child(None)["d4459"]
+    other = next(p for p in cache.iterdir() if "-n11011-" in p.name)
     good = victim.read_bytes()
     victim.unlink()
     victim.symlink_to(other)
     r = child(None)
-    assert "specialised" not in r["d5005"] and victim.is_symlink(), r
+    assert "specialised" not in r["d4459"] and victim.is_symlink(), r
     victim.unlink()
     victim.write_bytes(other.read_bytes())  # a well-formed entry of ANOTHER length under this name
     victim.chmod(0o600)
     r = child(None)
-    assert "specialised" not in r["d5005"] and not victim.exists(), r
+    assert "specialised" not in r["d4459"] and not victim.exists(), r
     victim.write_bytes(good[:-7])  # truncated
     victim.chmod(0o600)
     r = child(None)
-    assert "specialised" not in r["d5005"] and not victim.exists(), r
+    assert "specialised" not in r["d4459"] and not victim.exists(), r
     # a damaged cache file (here: the format of round 5) is discarded, not trusted
     victim.write_bytes(b"FOURIER-HIP-CO-1\nnot_a_kernel\n" + b"\x00" * 100)
     victim.chmod(0o600)
@@ -1324,18 +1330,18 @@ def test_code_object_cache_and_the_library_wide_specialise_policy(torch, fa, ora
     try:
         # the process cache still holds the kernel of this process; a fresh process must fall back to its default route, silently
         r = child(None)
-        assert "specialised" not in r["d5005"] and not victim.exists(), r
+        assert "specialised" not in r["d4459"] and not victim.exists(), r
     finally:
         fa.set_default_option("specialise_at_create", prev)
     # the install step (packaging/warm_cache.c, python -m fourier_amd.warm_cache): after it, a plain create of a length with factors
-    # 7 / 11 / 13 runs on its own kernel -- f64 5005 leaves Bluestein -- in a process that never heard of any option
+    # 7 / 11 / 13 runs on its own kernel -- f64 4459 leaves Bluestein -- in a process that never heard of any option
     env = {k: v for k, v in os.environ.items() if k != "FOURIER_HIP_SPECIALISE"}
     env["FOURIER_HIP_CACHE_DIR"] = str(tmp_path / "warm")
-    out = subprocess.run([sys.executable, "-m", "fourier_amd.warm_cache", "5005", "1001", "3003"], env=env, capture_output=True, text=True, timeout=600,
+    out = subprocess.run([sys.executable, "-m", "fourier_amd.warm_cache", "4459", "4802", "3773"], env=env, capture_output=True, text=True, timeout=600,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0 and "6 plans run on kernels of their own" in out.stdout, (out.stdout, out.stderr[-1500:])
     prog2 = ("import sys, json; sys.path.insert(0, %r); import fourier_amd as fa\n"
-             "print(json.dumps([fa.create_fft_f32(5005).describe(), fa.create_fft_f64(5005).describe(), fa.create_fft_f64(1001).describe()]))\n"
+             "print(json.dumps([fa.create_fft_f32(4459).describe(), fa.create_fft_f64(4459).describe(), fa.create_fft_f64(4802).describe()]))\n"
              % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     out = subprocess.run([sys.executable, "-c", prog2], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -1346,23 +1352,25 @@ def test_code_object_cache_and_the_library_wide_specialise_policy(torch, fa, ora
 def test_plan_option_specialise_compiles_the_lengths_own_kernel_with_hiprtc(torch, fa, oracle):
     """Plan option "specialise" (rtc.cpp): a length whose prime factors stop at 13 but that has no ahead-of-time per-length
     kernel gets mixed_radix_kernel_ct<T, n> compiled with hipRTC on request.  Lengths on the runtime-parameterised kernel
-    (1001, 5005, 4095), lengths beyond its reach that default to Bluestein (9009 f32, 4095 f64, 15015 f32 = 117 KiB of
-    LDS), a length that already has its kernel (1000: OK, unchanged), and lengths outside the family (1013, 2^12:
-    UNSUPPORTED, the plan keeps working).  Values against the oracle and against the plan's default route."""
+    (f32 175, 4459, 3773; f64 4802), lengths beyond its reach that default to Bluestein (11011 f32, 4459 f64, 15015 f32 = 117 KiB of
+    LDS), lengths that already have a kernel of their own (1000: per-length LDS kernel; 1001, 5005: register stages, regfft_shapes.h, round 6 --
+    OK, unchanged), and lengths outside the family (1013, 2^12: UNSUPPORTED, the plan keeps working).  Values against the oracle and
+    against the plan's default route."""
     import shutil
 
     if not (os.path.exists("/opt/rocm/lib/libhiprtc.so") or shutil.which("hipcc")):
         pytest.skip("libhiprtc not installed")
-    for n, dtype in ((1001, np.complex64), (5005, np.complex64), (4095, np.complex64), (9009, np.complex64), (15015, np.complex64),  # 15015: 117 KiB of (static) LDS
-                     (1001, np.complex128), (4095, np.complex128), (1000, np.complex64)):
+    for n, dtype in ((175, np.complex64), (4459, np.complex64), (3773, np.complex64), (11011, np.complex64), (15015, np.complex64),  # 15015: 117 KiB of (static) LDS
+                     (4802, np.complex128), (4459, np.complex128), (1000, np.complex64), (1001, np.complex64), (5005, np.complex128)):
         batch = 37
         x = np.stack([hash_normal(2500 + b, n) for b in range(batch)]).astype(dtype)
         base, spec = make(fa, n, dtype), make(fa, n, dtype)
         before = spec.describe()
         spec.set_option("specialise", 1)
         after = spec.describe()
-        if n == 1000:
+        if n in (1000, 1001, 5005):
             assert after == before and "specialised" not in after  # already a per-length kernel
+            assert ("registers" in after) == (n != 1000), after
         else:
             assert "mixed-radix" in after and "specialised" in after, (n, before, after)
         tol = 2e-6 if dtype == np.complex64 else 5e-11

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Development tool (round 6, sessions 48 / 49): lengths with factors 5 ... 13 as a direct transform on register stages (kernels_regfft.h; the
+product library's route for the lengths of regfft_shapes.h) against the route they had before (the LDS mixed-radix kernels, per length or
+runtime-parameterised, or tile passes: the experiments library under FOURIER_NO_REGFFT=1), alternating on shared buffers: median ms of REPS by
+HIP events on the launch stream, fraction of the 8 TB/s HBM peak, rel-L2 error of four transforms against numpy's f64 FFT.
+REGFFT_SPECIALISED=n,n,...: a third arm for these lengths, the length's own LDS kernel compiled at run time (plan option "specialise")."""
+import ctypes, json, os, re, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from fourier_amd import fft as F, _lib, build as B
+
+
+def listed():
+    with open(os.path.join(ROOT, "fourier_amd", "csrc", "regfft_shapes.h")) as f:
+        return [int(m.group(1)) for m in re.finditer(r"^FOURIER_REGFFT_ROW\((\d+),", f.read(), re.M)]
+
+
+SIZES = [int(v) for v in os.environ.get("REGFFT_SIZES", "").split(",") if v] or listed()
+SPECIALISED = {int(v) for v in os.environ.get("REGFFT_SPECIALISED", "").split(",") if v}
+REPS = int(os.environ.get("REGFFT_REPS", "7"))
+BYTES = 1 << 29
+
+
+def main():
+    base = _lib.lib()
+    exp = _lib.bind(ctypes.CDLL(B.OUT_EXPERIMENTS), strict=False)
+    st = torch.cuda.current_stream().cuda_stream
+    for real, cdt, esz in (("f32", torch.complex64, 8), ("f64", torch.complex128, 16)):
+        xbuf = torch.empty(BYTES // esz, dtype=cdt, device="cuda"); torch.view_as_real(xbuf).uniform_(-1, 1); ybuf = torch.empty_like(xbuf)
+        mk = F.create_fft_f32 if real == "f32" else F.create_fft_f64
+        for n in SIZES:
+            batch = max(1, BYTES // (n * esz))
+            x, y = xbuf[: batch * n].view(batch, n), ybuf[: batch * n].view(batch, n)
+            ref = np.fft.fft(x[:4].cpu().numpy().astype(np.complex128), axis=1)
+            plans = [("registers", mk(n, 0), [])]
+            os.environ["FOURIER_NO_REGFFT"] = "1"
+            _lib._lib = exp
+            plans.append(("before", mk(n, 0), []))
+            if n in SPECIALISED:
+                p = mk(n, 0)
+                try:
+                    p.set_option("specialise", 1)
+                    plans.append(("specialised", p, []))
+                except Exception as e:  # noqa: BLE001 -- a length the run-time route refuses stays out of the table
+                    print(f"specialise({n}) refused: {e}", file=sys.stderr)
+            _lib._lib = base
+            del os.environ["FOURIER_NO_REGFFT"]
+            if "registers" not in plans[0][1].describe():  # no kernel in this precision
+                continue
+            errs = {}
+            for name, plan, ts in plans:
+                y[:4].zero_()
+                plan.transform_batch_ptr(x.data_ptr(), y.data_ptr(), batch, 0, st); torch.cuda.synchronize()
+                got = y[:4].cpu().numpy().astype(np.complex128)
+                errs[name] = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+            for _ in range(REPS):
+                for name, plan, ts in plans:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); plan.transform_batch_ptr(x.data_ptr(), y.data_ptr(), batch, 0, st); e1.record(); e1.synchronize()
+                    ts.append(e0.elapsed_time(e1) * 1e-3)
+            for name, plan, ts in plans:
+                t = sorted(ts)[len(ts) // 2]
+                print(json.dumps(dict(real=real, n=n, arm=name, plan=plan.describe(), batch=batch, ms=round(t * 1e3, 4), ms_min=round(min(ts) * 1e3, 4),
+                                      frac8=round(batch * 2.0 * n * esz / t / 8e12, 4), rel_l2_vs_numpy_f64=errs[name])), flush=True)
+            del plans
+        del xbuf, ybuf
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
