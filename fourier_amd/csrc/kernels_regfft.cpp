@@ -10,16 +10,16 @@ namespace fourier_hip {
 
 typedef FOURIER_TU_REAL TUReal;
 
-template <typename T, uint32_t R1, uint32_t R2, uint32_t R3> static ChirpzKernel make_regfft() {
+template <typename T, uint32_t R1, uint32_t R2, uint32_t R3, bool SPLIT> static ChirpzKernel make_regfft() {
   ChirpzKernel k;
   if constexpr (R3 == 0) {
     using C = ChirpzRegCfg<T, R1, R2>;
     k.fn = &regfft_kernel<T, R1, R2>;
     k.m = C::M; k.r1 = R1; k.r2 = R2; k.tpw = C::TPW; k.smem = C::SMEM;
-  } else if constexpr (Chirpz3Cfg<T, R1, R2, R3>::SMEM <= (size_t)160 * 1024 && Chirpz3Cfg<T, R1, R2, R3>::NT <= 1024) {
-    using C = Chirpz3Cfg<T, R1, R2, R3>;  // (a transform -- in f32 a pair -- with its padding within a compute unit's LDS, a stage within 1024 lanes)
-    k.fn = &regfft3_kernel<T, R1, R2, R3>;
-    k.m = C::M; k.r1 = R1; k.r2 = R2; k.r3 = R3; k.tpw = C::NV; k.threads = C::NT; k.smem = C::SMEM;
+  } else if constexpr (Regfft3Cfg<T, R1, R2, R3, SPLIT>::SMEM <= (size_t)160 * 1024 && Regfft3Cfg<T, R1, R2, R3, SPLIT>::NT <= 1024) {
+    using C = Regfft3Cfg<T, R1, R2, R3, SPLIT>;  // (a transform -- in f32 a pair -- with its padding within a compute unit's LDS, a stage within 1024 lanes)
+    k.fn = &regfft3_kernel<T, R1, R2, R3, SPLIT>;
+    k.m = C::M; k.r1 = R1; k.r2 = R2; k.r3 = R3; k.tpw = C::NV; k.threads = C::NT; k.smem = C::SMEM; k.split = SPLIT;
   }
   return k;
 }
@@ -31,13 +31,17 @@ enum { REGFFT_COUNTER_BASE = __COUNTER__ };
 #define FOURIER_REGFFT_BUILT(EMU) 1
 #endif
 #define FOURIER_REGFFT_ROW(NN, A, B, C, F32, F64, EMU) FOURIER_REGFFT_ROW_I(NN, A, B, C, F32, F64, EMU, (__COUNTER__ - REGFFT_COUNTER_BASE - 1))
+// a precision's flag: 0 = not listed, 1 = listed, 2 = listed with the split-plane exchanges (three stages), 3 = both built, 1 the default (A/B builds)
 #define FOURIER_REGFFT_ROW_I(NN, A, B, C, F32, F64, EMU, IDX)                                                          \
   case NN:                                                                                                             \
-    if constexpr ((IDX) % FOURIER_REGFFT_SHARDS == FOURIER_REGFFT_SHARD && (sizeof(T) == 4 ? (F32) : (F64)) && FOURIER_REGFFT_BUILT(EMU)) \
-      return make_regfft<T, A, B, C>();                                                                                \
+    if constexpr ((IDX) % FOURIER_REGFFT_SHARDS == FOURIER_REGFFT_SHARD && (sizeof(T) == 4 ? (F32) : (F64)) != 0 && FOURIER_REGFFT_BUILT(EMU)) { \
+      constexpr int F = sizeof(T) == 4 ? (F32) : (F64);                                                                \
+      if constexpr (F == 3 && (C) != 0) return variant == 2 ? make_regfft<T, A, B, C, true>() : make_regfft<T, A, B, C, false>(); \
+      else return make_regfft<T, A, B, C, F == 2 && (C) != 0>();                                                       \
+    }                                                                                                                  \
     return ChirpzKernel();
 
-template <typename T> static ChirpzKernel lookup(uint32_t n) {
+template <typename T> static ChirpzKernel lookup(uint32_t n, int variant) {
   switch (n) {
 #include "regfft_shapes.h"
     default: return ChirpzKernel();
@@ -48,11 +52,11 @@ template <typename T> static ChirpzKernel lookup(uint32_t n) {
 
 #define FOURIER_REGFFT_SHARD_FN_(I) get_regfft_kernel_s##I
 #define FOURIER_REGFFT_SHARD_FN(I) FOURIER_REGFFT_SHARD_FN_(I)
-ChirpzKernel FOURIER_REGFFT_SHARD_FN(FOURIER_REGFFT_SHARD)(Real<TUReal>, uint32_t n) { return lookup<TUReal>(n); }
+ChirpzKernel FOURIER_REGFFT_SHARD_FN(FOURIER_REGFFT_SHARD)(Real<TUReal>, uint32_t n, int variant) { return lookup<TUReal>(n, variant); }
 
 #if FOURIER_REGFFT_SHARD == 0
-ChirpzKernel get_regfft_kernel(Real<TUReal>, uint32_t n) {
-#define FOURIER_REGFFT_TRY(I, T) if (ChirpzKernel k = get_regfft_kernel_s##I(Real<T>{}, n); k.fn) return k;
+ChirpzKernel get_regfft_kernel(Real<TUReal>, uint32_t n, int variant) {
+#define FOURIER_REGFFT_TRY(I, T) if (ChirpzKernel k = get_regfft_kernel_s##I(Real<T>{}, n, variant); k.fn) return k;
   FOURIER_REGFFT_SHARD_LIST(FOURIER_REGFFT_TRY, TUReal)
 #undef FOURIER_REGFFT_TRY
   return ChirpzKernel();

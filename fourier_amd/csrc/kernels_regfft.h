@@ -74,24 +74,88 @@ __global__ void __launch_bounds__(64, (ChirpzRegCfg<T, R1, R2>::MINW)) regfft_ke
 }
 
 // N = R1 x R2 x R3: a workgroup per transform (f32: per pair), lanes and exchanges as the forward half of chirpz_reg3_kernel; X[a + R1R2*k3] leaves
-// stage C's lanes a = k1 + R1*k2 coalesced
-template <typename T, uint32_t R1, uint32_t R2, uint32_t R3>
-__global__ void __launch_bounds__((Chirpz3Cfg<T, R1, R2, R3>::NT), (Chirpz3Cfg<T, R1, R2, R3>::MINW)) regfft3_kernel(ChirpzArgs a) {
-  using C = Chirpz3Cfg<T, R1, R2, R3>;
+// stage C's lanes a = k1 + R1*k2 coalesced.  SPLIT: the two exchanges carry the real parts, then the imaginary parts, through a buffer of HALF the
+// size (two more barriers each): a workgroup holds N x 8 bytes of LDS instead of N x 16 and TWO share a compute unit from 5000 points on -- one
+// loads while the other computes and stores (sessions 53 / 54).
+template <typename T, uint32_t R1, uint32_t R2, uint32_t R3, bool SPLIT> struct Regfft3Cfg : Chirpz3Cfg<T, R1, R2, R3> {
+  using B = Chirpz3Cfg<T, R1, R2, R3>;
+  using P = typename B::P;
+  static constexpr uint32_t X12 = R2 * B::S1 > R3 * B::S2 ? R2 * B::S1 : R3 * B::S2;  // the forward exchanges only
+  static constexpr size_t SMEM = (size_t)X12 * (SPLIT ? sizeof(P) : sizeof(cpx<P>));
+  static constexpr uint32_t LDS_WG = (uint32_t)((160u * 1024u) / SMEM);
+  static constexpr uint32_t WAVES = LDS_WG * (B::NT / 64u) / 4u;  // per SIMD, as far as the LDS goes
+  static constexpr uint32_t MINW = WAVES < 1u ? 1u : (WAVES > 3u ? 3u : WAVES);
+};
+// one exchange: the writer lanes (t < LW) put their R values at widx(r), the reader lanes (t < LR) take theirs from ridx(r)
+template <bool SPLIT, typename P, uint32_t RW, uint32_t RR, typename WI, typename RI>
+__device__ __forceinline__ void regfft_exchange(void* smem, bool writer, bool reader, const cpx<P>* w, cpx<P>* r, WI widx, RI ridx, int note) {
+  if constexpr (!SPLIT) {
+    cpx<P>* xb = (cpx<P>*)smem;
+    if (writer) {
+#pragma unroll
+      for (uint32_t i = 0; i < RW; ++i) {
+        cpx<P>* p = xb + widx(i);
+        LDS_NOTE(p, (uint32_t)sizeof(cpx<P>), true, note);
+        *p = w[i];
+      }
+    }
+    __syncthreads();
+    if (reader) {
+#pragma unroll
+      for (uint32_t i = 0; i < RR; ++i) {
+        const cpx<P>* p = xb + ridx(i);
+        LDS_NOTE(p, (uint32_t)sizeof(cpx<P>), false, note + 1);
+        r[i] = *p;
+      }
+    }
+  } else {
+    P* xs = (P*)smem;
+    if (writer) {
+#pragma unroll
+      for (uint32_t i = 0; i < RW; ++i) {
+        P* p = xs + widx(i);
+        LDS_NOTE(p, (uint32_t)sizeof(P), true, note);
+        *p = w[i].re;
+      }
+    }
+    __syncthreads();
+    if (reader) {
+#pragma unroll
+      for (uint32_t i = 0; i < RR; ++i) {
+        const P* p = xs + ridx(i);
+        LDS_NOTE(p, (uint32_t)sizeof(P), false, note + 1);
+        r[i].re = *p;
+      }
+    }
+    __syncthreads();
+    if (writer) {
+#pragma unroll
+      for (uint32_t i = 0; i < RW; ++i) xs[widx(i)] = w[i].im;
+    }
+    __syncthreads();
+    if (reader) {
+#pragma unroll
+      for (uint32_t i = 0; i < RR; ++i) r[i].im = xs[ridx(i)];
+    }
+  }
+}
+
+template <typename T, uint32_t R1, uint32_t R2, uint32_t R3, bool SPLIT>
+__global__ void __launch_bounds__((Regfft3Cfg<T, R1, R2, R3, SPLIT>::NT), (Regfft3Cfg<T, R1, R2, R3, SPLIT>::MINW)) regfft3_kernel(ChirpzArgs a) {
+  using C = Regfft3Cfg<T, R1, R2, R3, SPLIT>;
   using P = typename C::P;
   using LV = LaneVal<P, T>;
   constexpr uint32_t NV = C::NV, LA = C::LA, LB = C::LB, LC = C::LC, S1 = C::S1, S2 = C::S2, N = C::M;
-  constexpr uint32_t EB = (uint32_t)sizeof(cpx<T>), XB = (uint32_t)sizeof(cpx<P>), TB = 8u;
+  constexpr uint32_t EB = (uint32_t)sizeof(cpx<T>), TB = 8u;
   FOURIER_DYN_SMEM(smem);
-  cpx<P>* xb = (cpx<P>*)smem;
   const uint32_t t = threadIdx.x;
   const uint64_t b0 = (uint64_t)blockIdx.x * NV;
   const uint32_t nb = a.batch - b0 < NV ? (uint32_t)(a.batch - b0) : NV;
   const BufRsrc rin = make_rsrc((const cpx<T>*)a.in + b0 * N, nb * N * EB), rout = make_rsrc((cpx<T>*)a.out + b0 * N, nb * N * EB);
   const cpx<T>* t1 = (const cpx<T>*)a.tw;   // [j2 < R2][lane k1*R3 + j3]: W_N^{(j3 + R3*j2) * k1}
   const cpx<T>* t2 = t1 + (size_t)R2 * LB;  // [k2 < R2][j3 < R3]: W_{R2R3}^{j3 * k2}
+  cpx<P> x[R1], y[R2], z[R3];
   if (t < LA) {
-    cpx<P> x[R1];
     cpx<T> d[NV][R1];
 #pragma unroll
     for (uint32_t j1 = 0; j1 < R1; ++j1)
@@ -105,47 +169,25 @@ __global__ void __launch_bounds__((Chirpz3Cfg<T, R1, R2, R3>::NT), (Chirpz3Cfg<T
       x[j1] = a.swap ? cpx<P>{LV::make(im), LV::make(re)} : cpx<P>{LV::make(re), LV::make(im)};
     }
     dft_any<P, (int)R1>(x);
-    const uint32_t j2 = t / R3, j3 = t - j2 * R3;
-#pragma unroll
-    for (uint32_t k1 = 0; k1 < R1; ++k1) {
-      cpx<P>* p = xb + j2 * S1 + k1 * R3 + j3;
-      LDS_NOTE(p, XB, true, 350);
-      *p = x[k1];
-    }
   }
-  __syncthreads();
-  cpx<P> y[R2];
+  {  // exchange 1: rows j2, the reader's lane k1*R3 + j3
+    const uint32_t j2 = t / R3, j3 = t - j2 * R3;
+    regfft_exchange<SPLIT, P, R1, R2>(smem, t < LA, t < LB, x, y, [&](uint32_t k1) { return j2 * S1 + k1 * R3 + j3; },
+                                      [&](uint32_t r) { return r * S1 + t; }, 350);
+  }
   if (t < LB) {
-#pragma unroll
-    for (uint32_t j2 = 0; j2 < R2; ++j2) {
-      const cpx<P>* p = xb + j2 * S1 + t;
-      LDS_NOTE(p, XB, false, 351);
-      y[j2] = *p;
-    }
     chirpz_table_product<P, T, R2, TB>(y, t1 + t, LB, false);
     dft_any<P, (int)R2>(y);
     FOURIER_SCHED_FENCE();
     chirpz_table_product<P, T, R2, TB>(y, t2 + t % R3, R3, false);
   }
   __syncthreads();  // exchange 1 is read
-  if (t < LB) {
+  {  // exchange 2: rows j3, the reader's lane k1 + R1*k2
     const uint32_t k1 = t / R3, j3 = t - k1 * R3;
-#pragma unroll
-    for (uint32_t k2 = 0; k2 < R2; ++k2) {
-      cpx<P>* p = xb + j3 * S2 + k1 + R1 * k2;
-      LDS_NOTE(p, XB, true, 352);
-      *p = y[k2];
-    }
+    regfft_exchange<SPLIT, P, R2, R3>(smem, t < LB, t < LC, y, z, [&](uint32_t k2) { return j3 * S2 + k1 + R1 * k2; },
+                                      [&](uint32_t r) { return r * S2 + t; }, 352);
   }
-  __syncthreads();
   if (t < LC) {
-    cpx<P> z[R3];
-#pragma unroll
-    for (uint32_t j3 = 0; j3 < R3; ++j3) {
-      const cpx<P>* p = xb + j3 * S2 + t;
-      LDS_NOTE(p, XB, false, 353);
-      z[j3] = *p;
-    }
     dft_any<P, (int)R3>(z);
     const T scale = (T)a.scale;
 #pragma unroll

@@ -3,7 +3,9 @@
 product library's route for the lengths of regfft_shapes.h) against the route they had before (the LDS mixed-radix kernels, per length or
 runtime-parameterised, or tile passes: the experiments library under FOURIER_NO_REGFFT=1), alternating on shared buffers: median ms of REPS by
 HIP events on the launch stream, fraction of the 8 TB/s HBM peak, rel-L2 error of four transforms against numpy's f64 FFT.
-REGFFT_SPECIALISED=n,n,...: a third arm for these lengths, the length's own LDS kernel compiled at run time (plan option "specialise")."""
+REGFFT_SPECIALISED=n,n,...: a third arm for these lengths, the length's own LDS kernel compiled at run time (plan option "specialise").
+REGFFT_VARIANTS=1 (an --ab-build of regfft_shapes.h, sessions 53 / 54): the three-stage lengths only, arms plain / split (whole or split-plane
+exchanges, FOURIER_REGFFT_VARIANT = 1 / 2) / before, all three on the experiments library."""
 import ctypes, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,9 +14,12 @@ import torch
 from fourier_amd import fft as F, _lib, build as B
 
 
+VARIANTS = os.environ.get("REGFFT_VARIANTS") == "1"
+
+
 def listed():
     with open(os.path.join(ROOT, "fourier_amd", "csrc", "regfft_shapes.h")) as f:
-        return [int(m.group(1)) for m in re.finditer(r"^FOURIER_REGFFT_ROW\((\d+),", f.read(), re.M)]
+        return [int(m.group(1)) for m in re.finditer(r"^FOURIER_REGFFT_ROW\((\d+), \d+, \d+, (\d+),", f.read(), re.M) if not VARIANTS or int(m.group(2))]
 
 
 SIZES = [int(v) for v in os.environ.get("REGFFT_SIZES", "").split(",") if v] or listed()
@@ -34,19 +39,27 @@ def main():
             batch = max(1, BYTES // (n * esz))
             x, y = xbuf[: batch * n].view(batch, n), ybuf[: batch * n].view(batch, n)
             ref = np.fft.fft(x[:4].cpu().numpy().astype(np.complex128), axis=1)
-            plans = [("registers", mk(n, 0), [])]
-            os.environ["FOURIER_NO_REGFFT"] = "1"
-            _lib._lib = exp
-            plans.append(("before", mk(n, 0), []))
+            def under(env, lib):
+                os.environ.update(env)
+                _lib._lib = lib
+                try:
+                    return mk(n, 0)
+                finally:
+                    _lib._lib = base
+                    for k in env:
+                        del os.environ[k]
+            if VARIANTS:
+                plans = [("plain", under({"FOURIER_REGFFT_VARIANT": "1"}, exp), []), ("split", under({"FOURIER_REGFFT_VARIANT": "2"}, exp), [])]
+            else:
+                plans = [("registers", mk(n, 0), [])]
+            plans.append(("before", under({"FOURIER_NO_REGFFT": "1"}, exp), []))
             if n in SPECIALISED:
-                p = mk(n, 0)
+                p = under({"FOURIER_NO_REGFFT": "1"}, exp)
                 try:
                     p.set_option("specialise", 1)
                     plans.append(("specialised", p, []))
                 except Exception as e:  # noqa: BLE001 -- a length the run-time route refuses stays out of the table
                     print(f"specialise({n}) refused: {e}", file=sys.stderr)
-            _lib._lib = base
-            del os.environ["FOURIER_NO_REGFFT"]
             if "registers" not in plans[0][1].describe():  # no kernel in this precision
                 continue
             errs = {}
