@@ -174,7 +174,7 @@ typedef void (*TiledKernelFn)(TiledArgs);
 // r1 != 0: the register-resident kernel of kernels_regtile.h (L = r1 x r2; its `tw` table is W_L^{j2 * k1}, [r1][r2])
 struct TiledKernel { TiledKernelFn fn = nullptr; uint32_t L = 0, cols = 0, threads = 0; size_t smem = 0; uint32_t r1 = 0, r2 = 0; };
 typedef void (*ChirpzKernelFn)(ChirpzArgs);
-struct ChirpzKernel { ChirpzKernelFn fn = nullptr; uint32_t m = 0, r1 = 0, r2 = 0, r3 = 0, tpw = 0, threads = 64; size_t smem = 0; bool split = false; };  // tpw: transforms per workgroup; split: re / im planes exchanged one after the other
+struct ChirpzKernel { ChirpzKernelFn fn = nullptr; uint32_t m = 0, r1 = 0, r2 = 0, r3 = 0, tpw = 0, threads = 64; size_t smem = 0; bool split = false, fact = false; };  // tpw: transforms per workgroup; split: re / im planes exchanged one after the other; fact: factored twiddle tables
 // a mixed-radix LDS kernel with its launch shape: transforms per workgroup, LDS buffers of `group` transforms, threads
 struct MixKernel { MixKernelFn fn; uint32_t group; size_t nbuf; uint32_t threads; };
 
@@ -255,7 +255,7 @@ template <typename T> struct Real {};
   ChirpzKernel get_chirpz_kernel_s2(Real<T>, uint32_t m); ChirpzKernel get_chirpz_kernel_s3(Real<T>, uint32_t m);     \
   /* kernels_regfft.cpp (FOURIER_REGFFT_SHARDS shards): a length with factors 5 ... 13 as a direct transform on the same register */ \
   /* stages, n = R1 x R2 [x R3], the lengths of regfft_shapes.h; fn == nullptr: none                                              */ \
-  /* variant: 0 = as listed; 1 / 2 = whole / split-plane exchanges where an A/B build holds both                               */ \
+  /* variant: 0 = as listed; 1 ... 4 = one of the exchange / table variants where an A/B build holds all four                    */ \
   ChirpzKernel get_regfft_kernel(Real<T>, uint32_t n, int variant = 0);                                               \
   FOURIER_REGFFT_SHARD_LIST(FOURIER_DECLARE_REGFFT_SHARD, T)                                                           \
   /* kernels_experiments.cpp (experiments library) or env_product.cpp (product: nothing available) */                  \

@@ -406,7 +406,7 @@ template <typename T> class BluRegEngine {
   }
   // direct: the same register stages as a plain transform of n_user = m points (kernels_regfft.h) -- lengths with factors 5 ... 13
   static bool has_direct(size_t n) { return n <= 16384 && !dev_env("FOURIER_NO_REGFFT") && get_regfft_kernel(Real<T>{}, (uint32_t)n).fn != nullptr; }
-  // (A/B builds hold both exchange variants of a three-stage length: FOURIER_REGFFT_VARIANT = 1 whole, 2 split planes; experiments library)
+  // (A/B builds hold the four variants of a three-stage length: FOURIER_REGFFT_VARIANT = 1 ... 4, kernels_regfft.cpp; experiments library)
   static int direct_variant() { const char* v = dev_env("FOURIER_REGFFT_VARIANT"); return v ? atoi(v) : 0; }
   BluRegEngine(size_t n_user, uint32_t m, bool direct = false)
       : n_(n_user), direct_(direct), k_(direct ? get_regfft_kernel(Real<T>{}, m, direct_variant()) : get_chirpz_kernel(Real<T>{}, m)) {
@@ -423,6 +423,13 @@ template <typename T> class BluRegEngine {
     if (r3 == 0) {  // [j2][k1]: W_M^{j2 * k1}
       for (uint64_t j2 = 0; j2 < r2; ++j2)
         for (uint64_t k1 = 0; k1 < r1; ++k1) root(j2 * k1, k_.m);
+    } else if (k_.fact) {  // regfft3_kernel<FACT>: W_M^{(j3 + R3 j2) k1} in two factors
+      for (uint64_t j2 = 0; j2 < r2; ++j2)  // [j2][k1]: W_{R1 R2}^{j2 * k1}
+        for (uint64_t k1 = 0; k1 < r1; ++k1) root(j2 * k1, r1 * r2);
+      for (uint64_t k1 = 0; k1 < r1; ++k1)  // [k1 * R3 + j3]: W_M^{j3 * k1}
+        for (uint64_t j3 = 0; j3 < r3; ++j3) root(j3 * k1, k_.m);
+      for (uint64_t k2 = 0; k2 < r2; ++k2)  // [k2][j3]: W_{R2 R3}^{j3 * k2}
+        for (uint64_t j3 = 0; j3 < r3; ++j3) root(j3 * k2, r2 * r3);
     } else {  // the four tables of chirpz_reg3_kernel, one after the other
       for (uint64_t j2 = 0; j2 < r2; ++j2)  // [j2][k1 * R3 + j3]: W_M^{(j3 + R3 * j2) * k1}
         for (uint64_t k1 = 0; k1 < r1; ++k1)

@@ -10,7 +10,7 @@ namespace fourier_hip {
 
 typedef FOURIER_TU_REAL TUReal;
 
-template <typename T, uint32_t R1, uint32_t R2, uint32_t R3, bool SPLIT> static ChirpzKernel make_regfft() {
+template <typename T, uint32_t R1, uint32_t R2, uint32_t R3, bool SPLIT, bool FACT> static ChirpzKernel make_regfft() {
   ChirpzKernel k;
   if constexpr (R3 == 0) {
     using C = ChirpzRegCfg<T, R1, R2>;
@@ -18,8 +18,8 @@ template <typename T, uint32_t R1, uint32_t R2, uint32_t R3, bool SPLIT> static 
     k.m = C::M; k.r1 = R1; k.r2 = R2; k.tpw = C::TPW; k.smem = C::SMEM;
   } else if constexpr (Regfft3Cfg<T, R1, R2, R3, SPLIT>::SMEM <= (size_t)160 * 1024 && Regfft3Cfg<T, R1, R2, R3, SPLIT>::NT <= 1024) {
     using C = Regfft3Cfg<T, R1, R2, R3, SPLIT>;  // (a transform -- in f32 a pair -- with its padding within a compute unit's LDS, a stage within 1024 lanes)
-    k.fn = &regfft3_kernel<T, R1, R2, R3, SPLIT>;
-    k.m = C::M; k.r1 = R1; k.r2 = R2; k.r3 = R3; k.tpw = C::NV; k.threads = C::NT; k.smem = C::SMEM; k.split = SPLIT;
+    k.fn = &regfft3_kernel<T, R1, R2, R3, SPLIT, FACT>;
+    k.m = C::M; k.r1 = R1; k.r2 = R2; k.r3 = R3; k.tpw = C::NV; k.threads = C::NT; k.smem = C::SMEM; k.split = SPLIT; k.fact = FACT;
   }
   return k;
 }
@@ -31,13 +31,18 @@ enum { REGFFT_COUNTER_BASE = __COUNTER__ };
 #define FOURIER_REGFFT_BUILT(EMU) 1
 #endif
 #define FOURIER_REGFFT_ROW(NN, A, B, C, F32, F64, EMU) FOURIER_REGFFT_ROW_I(NN, A, B, C, F32, F64, EMU, (__COUNTER__ - REGFFT_COUNTER_BASE - 1))
-// a precision's flag: 0 = not listed, 1 = listed, 2 = listed with the split-plane exchanges (three stages), 3 = both built, 1 the default (A/B builds)
+// a precision's flag: 0 = not listed; 1 = listed; three stages: 2 = split-plane exchanges, 3 = factored twiddle tables, 4 = both;
+// 9 = all four built, 1 the default (A/B builds; variant = 1 ... 4 picks one)
 #define FOURIER_REGFFT_ROW_I(NN, A, B, C, F32, F64, EMU, IDX)                                                          \
   case NN:                                                                                                             \
     if constexpr ((IDX) % FOURIER_REGFFT_SHARDS == FOURIER_REGFFT_SHARD && (sizeof(T) == 4 ? (F32) : (F64)) != 0 && FOURIER_REGFFT_BUILT(EMU)) { \
       constexpr int F = sizeof(T) == 4 ? (F32) : (F64);                                                                \
-      if constexpr (F == 3 && (C) != 0) return variant == 2 ? make_regfft<T, A, B, C, true>() : make_regfft<T, A, B, C, false>(); \
-      else return make_regfft<T, A, B, C, F == 2 && (C) != 0>();                                                       \
+      if constexpr (F == 9 && (C) != 0) {                                                                              \
+        return variant == 4 ? make_regfft<T, A, B, C, true, true>() : variant == 3 ? make_regfft<T, A, B, C, false, true>()  \
+             : variant == 2 ? make_regfft<T, A, B, C, true, false>() : make_regfft<T, A, B, C, false, false>();        \
+      } else {                                                                                                         \
+        return make_regfft<T, A, B, C, (F == 2 || F == 4) && (C) != 0, (F == 3 || F == 4) && (C) != 0>();              \
+      }                                                                                                                \
     }                                                                                                                  \
     return ChirpzKernel();
 

@@ -140,7 +140,10 @@ __device__ __forceinline__ void regfft_exchange(void* smem, bool writer, bool re
   }
 }
 
-template <typename T, uint32_t R1, uint32_t R2, uint32_t R3, bool SPLIT>
+// FACT: the twiddle between stages A and B, W_N^{(j3 + R3 j2) k1}, as W_{R1R2}^{j2 k1} (R1 R2 entries, the lanes of one k1 share an address) before
+// DFT_R2 and W_N^{j3 k1} (one entry per lane) after it: tables of R1R2 + R1R3 + R2R3 entries that stay in the L1 instead of N + R2R3 entries
+// streamed from the L2 beside the data (a third of a compute unit's read traffic at 8000 points); R2 more complex multiplies per lane.
+template <typename T, uint32_t R1, uint32_t R2, uint32_t R3, bool SPLIT, bool FACT>
 __global__ void __launch_bounds__((Regfft3Cfg<T, R1, R2, R3, SPLIT>::NT), (Regfft3Cfg<T, R1, R2, R3, SPLIT>::MINW)) regfft3_kernel(ChirpzArgs a) {
   using C = Regfft3Cfg<T, R1, R2, R3, SPLIT>;
   using P = typename C::P;
@@ -152,8 +155,10 @@ __global__ void __launch_bounds__((Regfft3Cfg<T, R1, R2, R3, SPLIT>::NT), (Regff
   const uint64_t b0 = (uint64_t)blockIdx.x * NV;
   const uint32_t nb = a.batch - b0 < NV ? (uint32_t)(a.batch - b0) : NV;
   const BufRsrc rin = make_rsrc((const cpx<T>*)a.in + b0 * N, nb * N * EB), rout = make_rsrc((cpx<T>*)a.out + b0 * N, nb * N * EB);
-  const cpx<T>* t1 = (const cpx<T>*)a.tw;   // [j2 < R2][lane k1*R3 + j3]: W_N^{(j3 + R3*j2) * k1}
-  const cpx<T>* t2 = t1 + (size_t)R2 * LB;  // [k2 < R2][j3 < R3]: W_{R2R3}^{j3 * k2}
+  // whole table: [j2 < R2][lane k1*R3 + j3]: W_N^{(j3 + R3*j2) * k1}; FACT: [j2 < R2][k1 < R1]: W_{R1R2}^{j2 * k1}, then [lane k1*R3 + j3]: W_N^{j3 * k1}
+  const cpx<T>* t1 = (const cpx<T>*)a.tw;
+  const cpx<T>* tb = t1 + (size_t)R1 * R2;
+  const cpx<T>* t2 = FACT ? tb + LB : t1 + (size_t)R2 * LB;  // [k2 < R2][j3 < R3]: W_{R2R3}^{j3 * k2}
   cpx<P> x[R1], y[R2], z[R3];
   if (t < LA) {
     cpx<T> d[NV][R1];
@@ -176,10 +181,20 @@ __global__ void __launch_bounds__((Regfft3Cfg<T, R1, R2, R3, SPLIT>::NT), (Regff
                                       [&](uint32_t r) { return r * S1 + t; }, 350);
   }
   if (t < LB) {
-    chirpz_table_product<P, T, R2, TB>(y, t1 + t, LB, false);
-    dft_any<P, (int)R2>(y);
-    FOURIER_SCHED_FENCE();
-    chirpz_table_product<P, T, R2, TB>(y, t2 + t % R3, R3, false);
+    if constexpr (FACT) {
+      const cpx<T> base = tb[t];
+      chirpz_table_product<P, T, R2, TB>(y, t1 + t / R3, R1, false);
+      dft_any<P, (int)R2>(y);
+      FOURIER_SCHED_FENCE();
+      chirpz_table_product<P, T, R2, TB>(y, t2 + t % R3, R3, false);
+#pragma unroll
+      for (uint32_t k2 = 0; k2 < R2; ++k2) y[k2] = cmul_tab(y[k2], base);
+    } else {
+      chirpz_table_product<P, T, R2, TB>(y, t1 + t, LB, false);
+      dft_any<P, (int)R2>(y);
+      FOURIER_SCHED_FENCE();
+      chirpz_table_product<P, T, R2, TB>(y, t2 + t % R3, R3, false);
+    }
   }
   __syncthreads();  // exchange 1 is read
   {  // exchange 2: rows j3, the reader's lane k1 + R1*k2

@@ -7,9 +7,9 @@ schedule, autosort/mod.rs:24-46), where it splits into two stages of at most 32 
 lane group's R1 lanes -- or, failing that, into three (descending, the smallest largest stage; stages of 33 ... 40 points where nothing shorter exists;
 49-point stages spill to 0.12 ... 0.2 of the peak, profiles/r06_s50_*; at most 1024 lanes per stage).  Without --ab every candidate is adopted in both precisions (the A/B build); with --ab FILE (rows of
 tools/gpu_r06_regfft_ab.py: real, n, arm = registers | before, ms) a length is adopted in a precision where the register kernel is at least
-MARGIN faster than the route it had (median of 7, alternating on shared buffers).  --split-ab FILE (arms plain | split | before): a three-stage
-length takes the split-plane exchanges where they are SPLIT_MARGIN faster, and is judged against the route it had with the better variant.
---ab-build: every candidate, both variants.  The emulator build keeps the lengths its test names.
+MARGIN faster than the route it had (median of 7, alternating on shared buffers).  --split-ab FILE (arms plain | split | fact | splitfact | before): a three-stage
+length takes the fastest variant (whole / split-plane exchanges x whole / factored twiddle tables) where that is VARIANT_MARGIN faster than the
+plain one, and is judged against the route it had with it.  --ab-build: every candidate, all four variants.  The emulator build keeps the lengths its test names.
 
     python tools/gen_regfft_shapes.py [--ab profiles/r06_s49_regfft_ab.jsonl ...] [--split-ab profiles/r06_s53_regfft_split_ab.jsonl]"""
 import json
@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "fourier_amd", "csrc", "regfft_shapes.h")
 NMIN, NMAX, RMAX, RMAX_LONG = 14, 10240, 32, 40
 MARGIN = 1.04
-SPLIT_MARGIN = 1.05
+VARIANT_MARGIN = 1.03
 EMU = {22, 77, 143, 175, 200, 245, 350, 385, 400, 560, 700, 800, 1001, 2000, 2002, 2904, 4000, 5005, 8000, 8960, 9009}
 
 
@@ -89,28 +89,31 @@ def main(argv):
     rows, kept = [], {"f32": 0, "f64": 0, "split": 0}
     for n, s, f32, f64 in candidates():
         if "--ab-build" in argv:  # every candidate, both exchange variants of the three-stage ones
-            f32 = f64 = 3 if s[2] else 1
+            f32 = f64 = 9 if s[2] else 1
         elif files:
             def flag(real):
                 t = dict(ab.get((real, n), {}))
                 v = 1
-                if s[2] and (real, n) in sab:  # three stages: arms plain / split / before of the split-plane session
+                if s[2] and (real, n) in sab:  # three stages: arms plain / split / fact / splitfact / before of the variant sessions
                     u = sab[(real, n)]
-                    if "split" in u and ("plain" not in u or u["plain"] >= SPLIT_MARGIN * u["split"]):
-                        v = 2
-                    if "before" in u and ("plain" in u or "split" in u):
-                        t = {"registers": u["split"] if v == 2 else u["plain"], "before": u["before"]}
+                    arms = [(u[a], i + 1) for i, a in enumerate(("plain", "split", "fact", "splitfact")) if a in u]
+                    if arms:
+                        best, v = min(arms)
+                        if "plain" in u and u["plain"] < VARIANT_MARGIN * best:
+                            best, v = u["plain"], 1
+                        if "before" in u:
+                            t = {"registers": best, "before": u["before"]}
                 return v if "registers" in t and "before" in t and t["before"] >= MARGIN * t["registers"] else 0
             f32, f64 = f32 and flag("f32"), f64 and flag("f64")
         if f32 or f64:
             rows.append((n, s, f32, f64))
             kept["f32"] += bool(f32)
             kept["f64"] += bool(f64)
-            kept["split"] += (f32 == 2) + (f64 == 2)
+            kept["split"] += (f32 > 1) + (f64 > 1)
     with open(OUT, "w") as f:
         f.write("// regfft_shapes.h -- GENERATED by tools/gen_regfft_shapes.py" + "".join(" --ab " + os.path.relpath(x, ROOT) for x in files) + "".join(" --split-ab " + os.path.relpath(x, ROOT) for x in split_files) + (" --ab-build" if "--ab-build" in argv else "") + "\n")
         f.write("// the lengths of kernels_regfft.h: FOURIER_REGFFT_ROW(N, R1, R2, R3 (0: two stages), f32, f64, in the emulator build); a precision's flag:\n")
-        f.write("// 0 = not adopted, 1 = adopted, 2 = adopted with the split-plane exchanges (three stages), 3 = both variants built (A/B builds)\n")
+        f.write("// 0 = not adopted, 1 = adopted; three stages: 2 = split-plane exchanges, 3 = factored twiddle tables, 4 = both; 9 = all four built (A/B builds)\n")
         f.write(f"// {len(rows)} lengths: {kept['f32']} in f32, {kept['f64']} in f64" + (f" (at least {MARGIN:.2f} x the route they had)" if files else " (every candidate: the A/B build)") + "\n")
         for n, (r1, r2, r3), f32, f64 in rows:
             assert r1 * r2 * (r3 or 1) == n

@@ -4,8 +4,8 @@ product library's route for the lengths of regfft_shapes.h) against the route th
 runtime-parameterised, or tile passes: the experiments library under FOURIER_NO_REGFFT=1), alternating on shared buffers: median ms of REPS by
 HIP events on the launch stream, fraction of the 8 TB/s HBM peak, rel-L2 error of four transforms against numpy's f64 FFT.
 REGFFT_SPECIALISED=n,n,...: a third arm for these lengths, the length's own LDS kernel compiled at run time (plan option "specialise").
-REGFFT_VARIANTS=1 (an --ab-build of regfft_shapes.h, sessions 53 / 54): the three-stage lengths only, arms plain / split (whole or split-plane
-exchanges, FOURIER_REGFFT_VARIANT = 1 / 2) / before, all three on the experiments library."""
+REGFFT_VARIANTS=1 (an --ab-build of regfft_shapes.h, sessions 53 / 54): the three-stage lengths only, arms plain / split / fact / splitfact
+(whole or split-plane exchanges x whole or factored twiddle tables, FOURIER_REGFFT_VARIANT = 1 ... 4) / before, all on the experiments library."""
 import ctypes, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -49,7 +49,7 @@ def main():
                     for k in env:
                         del os.environ[k]
             if VARIANTS:
-                plans = [("plain", under({"FOURIER_REGFFT_VARIANT": "1"}, exp), []), ("split", under({"FOURIER_REGFFT_VARIANT": "2"}, exp), [])]
+                plans = [(name, under({"FOURIER_REGFFT_VARIANT": str(i + 1)}, exp), []) for i, name in enumerate(("plain", "split", "fact", "splitfact"))]
             else:
                 plans = [("registers", mk(n, 0), [])]
             plans.append(("before", under({"FOURIER_NO_REGFFT": "1"}, exp), []))
