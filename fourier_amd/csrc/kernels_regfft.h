@@ -75,8 +75,9 @@ __global__ void __launch_bounds__(64, (ChirpzRegCfg<T, R1, R2>::MINW)) regfft_ke
 
 // N = R1 x R2 x R3: a workgroup per transform (f32: per pair), lanes and exchanges as the forward half of chirpz_reg3_kernel; X[a + R1R2*k3] leaves
 // stage C's lanes a = k1 + R1*k2 coalesced.  SPLIT: the two exchanges carry the real parts, then the imaginary parts, through a buffer of HALF the
-// size (two more barriers each): a workgroup holds N x 8 bytes of LDS instead of N x 16 and TWO share a compute unit from 5000 points on -- one
-// loads while the other computes and stores (sessions 53 / 54).
+// size (two more barriers each): a workgroup holds N x 8 bytes of LDS instead of N x 16, so that a second one fits beside it -- one loads while
+// the other computes and stores -- where the registers allow it too (154 - 168 of them: three waves per SIMD, i.e. workgroups of at most six
+// waves); 1.2 - 1.33 x there, 2 - 5 % slower elsewhere: regfft_shapes.h names the variant per length (sessions 53, 55, 56).
 template <typename T, uint32_t R1, uint32_t R2, uint32_t R3, bool SPLIT> struct Regfft3Cfg : Chirpz3Cfg<T, R1, R2, R3> {
   using B = Chirpz3Cfg<T, R1, R2, R3>;
   using P = typename B::P;
