@@ -228,8 +228,8 @@ constexpr uint32_t chirpz3_pitch_runs(uint32_t lanes, uint32_t run) {  // >= lan
   while (p % 16u != run % 16u) ++p;
   return p;
 }
-template <typename T, uint32_t R1, uint32_t R2, uint32_t R3> struct Chirpz3Cfg {
-  static constexpr bool VEC2 = sizeof(T) == 4;
+template <typename T, uint32_t R1, uint32_t R2, uint32_t R3, bool PAIR = true> struct Chirpz3Cfg {
+  static constexpr bool VEC2 = sizeof(T) == 4 && PAIR;  // (PAIR = false: kernels_regfft.h, one f32 transform per workgroup)
   using P = typename ChirpzSelect<VEC2, Pk2, T>::type;
   static constexpr uint32_t NV = VEC2 ? 2u : 1u;
   static constexpr uint32_t M = R1 * R2 * R3, LA = R2 * R3, LB = R1 * R3, LC = R1 * R2;  // lanes of the stages

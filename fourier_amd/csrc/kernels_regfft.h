@@ -78,14 +78,17 @@ __global__ void __launch_bounds__(64, (ChirpzRegCfg<T, R1, R2>::MINW)) regfft_ke
 // size (two more barriers each): a workgroup holds N x 8 bytes of LDS instead of N x 16, so that a second one fits beside it -- one loads while
 // the other computes and stores -- where the registers allow it too (154 - 168 of them: three waves per SIMD, i.e. workgroups of at most six
 // waves); 1.2 - 1.33 x there, 2 - 5 % slower elsewhere: regfft_shapes.h names the variant per length (sessions 53, 55, 56).
-template <typename T, uint32_t R1, uint32_t R2, uint32_t R3, bool SPLIT> struct Regfft3Cfg : Chirpz3Cfg<T, R1, R2, R3> {
-  using B = Chirpz3Cfg<T, R1, R2, R3>;
+// PAIR = false (f32): ONE transform per workgroup on scalar arithmetic -- half the registers and half the LDS of the packed pair, so that two
+// workgroups of seven or eight waves share a compute unit (the packed arithmetic saves nothing here: the waves issue VALU work 13 % of their cycles).
+template <typename T, uint32_t R1, uint32_t R2, uint32_t R3, bool SPLIT, bool PAIR = true> struct Regfft3Cfg : Chirpz3Cfg<T, R1, R2, R3, PAIR> {
+  using B = Chirpz3Cfg<T, R1, R2, R3, PAIR>;
   using P = typename B::P;
   static constexpr uint32_t X12 = R2 * B::S1 > R3 * B::S2 ? R2 * B::S1 : R3 * B::S2;  // the forward exchanges only
   static constexpr size_t SMEM = (size_t)X12 * (SPLIT ? sizeof(P) : sizeof(cpx<P>));
   static constexpr uint32_t LDS_WG = (uint32_t)((160u * 1024u) / SMEM);
   static constexpr uint32_t WAVES = LDS_WG * (B::NT / 64u) / 4u;  // per SIMD, as far as the LDS goes
-  static constexpr uint32_t MINW = WAVES < 1u ? 1u : (WAVES > 3u ? 3u : WAVES);
+  // (unpaired f32: no bound -- the kernels take 70 ... 100 registers; any bound here is turned into one on whole workgroups and spills)
+  static constexpr uint32_t MINW = !PAIR || WAVES < 1u ? 1u : (WAVES > 3u ? 3u : WAVES);
 };
 // one exchange: the writer lanes (t < LW) put their R values at widx(r), the reader lanes (t < LR) take theirs from ridx(r)
 template <bool SPLIT, typename P, uint32_t RW, uint32_t RR, typename WI, typename RI>
@@ -144,9 +147,9 @@ __device__ __forceinline__ void regfft_exchange(void* smem, bool writer, bool re
 // FACT: the twiddle between stages A and B, W_N^{(j3 + R3 j2) k1}, as W_{R1R2}^{j2 k1} (R1 R2 entries, the lanes of one k1 share an address) before
 // DFT_R2 and W_N^{j3 k1} (one entry per lane) after it: tables of R1R2 + R1R3 + R2R3 entries that stay in the L1 instead of N + R2R3 entries
 // streamed from the L2 beside the data (a third of a compute unit's read traffic at 8000 points); R2 more complex multiplies per lane.
-template <typename T, uint32_t R1, uint32_t R2, uint32_t R3, bool SPLIT, bool FACT>
-__global__ void __launch_bounds__((Regfft3Cfg<T, R1, R2, R3, SPLIT>::NT), (Regfft3Cfg<T, R1, R2, R3, SPLIT>::MINW)) regfft3_kernel(ChirpzArgs a) {
-  using C = Regfft3Cfg<T, R1, R2, R3, SPLIT>;
+template <typename T, uint32_t R1, uint32_t R2, uint32_t R3, bool SPLIT, bool FACT, bool PAIR = true>
+__global__ void __launch_bounds__((Regfft3Cfg<T, R1, R2, R3, SPLIT, PAIR>::NT), (Regfft3Cfg<T, R1, R2, R3, SPLIT, PAIR>::MINW)) regfft3_kernel(ChirpzArgs a) {
+  using C = Regfft3Cfg<T, R1, R2, R3, SPLIT, PAIR>;
   using P = typename C::P;
   using LV = LaneVal<P, T>;
   constexpr uint32_t NV = C::NV, LA = C::LA, LB = C::LB, LC = C::LC, S1 = C::S1, S2 = C::S2, N = C::M;

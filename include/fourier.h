@@ -98,7 +98,7 @@ enum {
  *     lengths <= 576 (12288 ... 331776)
  *   2^a * 3^b, a >= 12, every other length          "stockham <L1>x...x<27|9|3>": the power-of-two passes over 2^a, then radix-27 / 9 / 3 passes
  *   a length of 14 ... 10240 points with a factor   "stockham registers <R1>x<R2>[x<R3>] one-launch" (round 6): the whole transform in one launch on two or
- *     5 ... 13 that fourier_amd/csrc/regfft_shapes.h  three register-resident stages of at most 40 points -- 533 lengths in f32, 585 in f64, each one
+ *     5 ... 13 that fourier_amd/csrc/regfft_shapes.h  three register-resident stages of at most 40 points -- 539 lengths in f32, 585 in f64, each one
  *     lists in the precision                          measured at least 1.04 x faster than the route below it had (5005: f32 0.24 -> 0.40 of the HBM
  *                                                   peak, f64 0.14 (Bluestein) -> 0.47; 1001: 0.35 -> 0.54, 0.25 -> 0.68)
  *   2^a * 3^b * 5^c * 7^d * 11^e * 13^f that fit    "stockham mixed-radix <r1>.<r2>...." (+ " specialised" for a kernel compiled at run time):

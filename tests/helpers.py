@@ -91,7 +91,7 @@ def regfft_shape(n, dtype, emu=False):
         path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fourier_amd", "csrc", "regfft_shapes.h")
         with open(path) as f:
             rows = _REGFFT_ROWS = {int(m.group(1)): tuple(int(v) for v in m.groups()[1:])
-                                   for m in re.finditer(r"^FOURIER_REGFFT_ROW\((\d+), (\d+), (\d+), (\d+), (\d), (\d), (\d)\)", f.read(), re.M)}
+                                   for m in re.finditer(r"^FOURIER_REGFFT_ROW\((\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d)\)", f.read(), re.M)}
     r = rows.get(int(n))
     if r is None or not r[3 if np.dtype(dtype).itemsize == 8 else 4] or (emu and not r[5]):
         return None

@@ -355,7 +355,7 @@ def test_lengths_with_factors_5_to_13_as_one_launch_on_register_stages(fa, oracl
     the precision runs as a direct transform in ONE launch -- n = j2 + R2 j1, DFT_R1, twiddle, DFT_R2 (, DFT_R3) with one LDS exchange per
     step -- instead of the LDS mixed-radix kernel's round trip per small radix (the reference: Bluestein, fourier/src/lib.rs:38-42; the oracle's
     chirp-z is the comparison, numpy's f64 transform the truth).  All five codes, in place, batches that do not fill the last wave.  The
-    emulator build holds the lengths below of the table's 593 (those the A/B left on their earlier route keep it here too)."""
+    emulator build holds the lengths below of the table's 594 (those the A/B left on their earlier route keep it here too)."""
     seen = 0
     for dtype, tol, tol_truth in ((np.complex64, 2e-6, 4e-7), (np.complex128, 5e-12, 1e-15)):  # (f64: the ORACLE's unreduced chirp angle, 1.4e-12 at 8000)
         for n in REGFFT_LENGTHS:

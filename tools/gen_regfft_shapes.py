@@ -9,7 +9,8 @@ lane group's R1 lanes -- or, failing that, into three (descending, the smallest 
 tools/gpu_r06_regfft_ab.py: real, n, arm = registers | before, ms) a length is adopted in a precision where the register kernel is at least
 MARGIN faster than the route it had (median of 7, alternating on shared buffers).  --split-ab FILE (arms plain | split | fact | splitfact | before): a three-stage
 length takes the fastest variant (whole / split-plane exchanges x whole / factored twiddle tables) where that is VARIANT_MARGIN faster than the
-plain one, and is judged against the route it had with it.  --ab-build: every candidate, all four variants.  The emulator build keeps the lengths its test names.
+plain one, and is judged against the route it had with it.  --ab-build: every candidate, all four variants.  --unpaired-ab FILE (f32, arms listed | unpaired | unpairedfact | before): one transform per
+workgroup where that is VARIANT_MARGIN faster than the listed variant; --unpaired-build: the listed variant and both unpaired ones.  The emulator build keeps the lengths its test names.
 
     python tools/gen_regfft_shapes.py [--ab profiles/r06_s49_regfft_ab.jsonl ...] [--split-ab profiles/r06_s53_regfft_split_ab.jsonl]"""
 import json
@@ -86,6 +87,7 @@ def main(argv):
     files = [argv[i + 1] for i, a in enumerate(argv) if a == "--ab"]
     split_files = [argv[i + 1] for i, a in enumerate(argv) if a == "--split-ab"]
     ab, sab = read_ab(files), read_ab(split_files)
+    up = read_ab([argv[i + 1] for i, a in enumerate(argv) if a == "--unpaired-ab"])
     rows, kept = [], {"f32": 0, "f64": 0, "split": 0}
     for n, s, f32, f64 in candidates():
         if "--ab-build" in argv:  # every candidate, both exchange variants of the three-stage ones
@@ -105,15 +107,27 @@ def main(argv):
                             t = {"registers": best, "before": u["before"]}
                 return v if "registers" in t and "before" in t and t["before"] >= MARGIN * t["registers"] else 0
             f32, f64 = f32 and flag("f32"), f64 and flag("f64")
+        if up:  # f32, three stages: the unpaired variants against the listed one (arms listed / unpaired / unpairedfact / before)
+            u = up.get(("f32", n), {})
+            if s[2] and "before" in u:
+                cur = u.get("listed") if f32 else None
+                arms = [(u[a], v) for a, v in (("unpaired", 5), ("unpairedfact", 6)) if a in u]
+                if arms:
+                    best, v = min(arms)
+                    if cur is None or cur >= VARIANT_MARGIN * best:
+                        f32 = v if u["before"] >= MARGIN * best else f32
+        if "--unpaired-build" in argv and s[2]:  # the listed variant (or the plain kernel) and the two unpaired ones
+            f32 = 10 + (f32 or 1)
         if f32 or f64:
             rows.append((n, s, f32, f64))
             kept["f32"] += bool(f32)
             kept["f64"] += bool(f64)
             kept["split"] += (f32 > 1) + (f64 > 1)
     with open(OUT, "w") as f:
-        f.write("// regfft_shapes.h -- GENERATED by tools/gen_regfft_shapes.py" + "".join(" --ab " + os.path.relpath(x, ROOT) for x in files) + "".join(" --split-ab " + os.path.relpath(x, ROOT) for x in split_files) + (" --ab-build" if "--ab-build" in argv else "") + "\n")
+        f.write("// regfft_shapes.h -- GENERATED by tools/gen_regfft_shapes.py" + "".join(" --ab " + os.path.relpath(x, ROOT) for x in files) + "".join(" --split-ab " + os.path.relpath(x, ROOT) for x in split_files) + "".join(" --unpaired-ab " + os.path.relpath(argv[i + 1], ROOT) for i, a in enumerate(argv) if a == "--unpaired-ab") + (" --ab-build" if "--ab-build" in argv else "") + (" --unpaired-build" if "--unpaired-build" in argv else "") + "\n")
         f.write("// the lengths of kernels_regfft.h: FOURIER_REGFFT_ROW(N, R1, R2, R3 (0: two stages), f32, f64, in the emulator build); a precision's flag:\n")
-        f.write("// 0 = not adopted, 1 = adopted; three stages: 2 = split-plane exchanges, 3 = factored twiddle tables, 4 = both; 9 = all four built (A/B builds)\n")
+        f.write("// 0 = not adopted, 1 = adopted; three stages: 2 = split-plane exchanges, 3 = factored twiddle tables, 4 = both, f32 5 / 6 = one transform per\n")
+        f.write("// workgroup (unpaired) without / with factored tables; A/B builds: 9 = 1 ... 4 built, 10 + F = the listed F and 5 / 6 built\n")
         f.write(f"// {len(rows)} lengths: {kept['f32']} in f32, {kept['f64']} in f64" + (f" (at least {MARGIN:.2f} x the route they had)" if files else " (every candidate: the A/B build)") + "\n")
         for n, (r1, r2, r3), f32, f64 in rows:
             assert r1 * r2 * (r3 or 1) == n

@@ -14,7 +14,8 @@ import torch
 from fourier_amd import fft as F, _lib, build as B
 
 
-VARIANTS = os.environ.get("REGFFT_VARIANTS") == "1"
+VARIANTS = os.environ.get("REGFFT_VARIANTS") in ("1", "2")
+UNPAIRED = os.environ.get("REGFFT_VARIANTS") == "2"  # an --unpaired-build: f32 only, arms listed / unpaired / unpairedfact / before
 
 
 def listed():
@@ -32,7 +33,7 @@ def main():
     base = _lib.lib()
     exp = _lib.bind(ctypes.CDLL(B.OUT_EXPERIMENTS), strict=False)
     st = torch.cuda.current_stream().cuda_stream
-    for real, cdt, esz in (("f32", torch.complex64, 8), ("f64", torch.complex128, 16)):
+    for real, cdt, esz in (("f32", torch.complex64, 8), ("f64", torch.complex128, 16))[: 1 if UNPAIRED else 2]:
         xbuf = torch.empty(BYTES // esz, dtype=cdt, device="cuda"); torch.view_as_real(xbuf).uniform_(-1, 1); ybuf = torch.empty_like(xbuf)
         mk = F.create_fft_f32 if real == "f32" else F.create_fft_f64
         for n in SIZES:
@@ -49,7 +50,8 @@ def main():
                     for k in env:
                         del os.environ[k]
             if VARIANTS:
-                plans = [(name, under({"FOURIER_REGFFT_VARIANT": str(i + 1)}, exp), []) for i, name in enumerate(("plain", "split", "fact", "splitfact"))]
+                arms = (("listed", 0), ("unpaired", 5), ("unpairedfact", 6)) if UNPAIRED else (("plain", 1), ("split", 2), ("fact", 3), ("splitfact", 4))
+                plans = [(name, under({"FOURIER_REGFFT_VARIANT": str(v)}, exp), []) for name, v in arms]
             else:
                 plans = [("registers", mk(n, 0), [])]
             plans.append(("before", under({"FOURIER_NO_REGFFT": "1"}, exp), []))
