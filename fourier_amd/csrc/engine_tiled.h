@@ -405,9 +405,11 @@ template <typename T> class BluRegEngine {
     return 0;
   }
   // direct: the same register stages as a plain transform of n_user = m points (kernels_regfft.h) -- lengths with factors 5 ... 13
-  static bool has_direct(size_t n) { return n <= 16384 && !dev_env("FOURIER_NO_REGFFT") && get_regfft_kernel(Real<T>{}, (uint32_t)n).fn != nullptr; }
-  // (A/B builds hold the four variants of a three-stage length: FOURIER_REGFFT_VARIANT = 1 ... 4, kernels_regfft.cpp; experiments library)
+  // (A/B builds hold several variants of a three-stage length: FOURIER_REGFFT_VARIANT = 1 ... 6, kernels_regfft.cpp; experiments library)
   static int direct_variant() { const char* v = dev_env("FOURIER_REGFFT_VARIANT"); return v ? atoi(v) : 0; }
+  static bool has_direct(size_t n) {
+    return n <= 20480 && !dev_env("FOURIER_NO_REGFFT") && get_regfft_kernel(Real<T>{}, (uint32_t)n, direct_variant()).fn != nullptr;
+  }
   BluRegEngine(size_t n_user, uint32_t m, bool direct = false)
       : n_(n_user), direct_(direct), k_(direct ? get_regfft_kernel(Real<T>{}, m, direct_variant()) : get_chirpz_kernel(Real<T>{}, m)) {
     if (!k_.fn || (direct ? (uint64_t)m != n_user : (uint64_t)m < 2 * (uint64_t)n_user - 1))

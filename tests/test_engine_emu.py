@@ -347,7 +347,7 @@ def test_one_launch_chirpz_on_a_smooth_m_in_registers(fa, oracle):
             assert rel_l2(back, x) <= (2e-6 if dtype == np.complex64 else 6e-15), m
 
 
-REGFFT_LENGTHS = (22, 77, 143, 175, 200, 245, 350, 385, 400, 560, 700, 800, 1001, 2000, 2002, 2904, 4000, 5005, 8000, 8960, 9009)  # gen_regfft_shapes.py: EMU
+REGFFT_LENGTHS = (22, 77, 143, 175, 200, 245, 350, 385, 400, 560, 700, 800, 1001, 2000, 2002, 2904, 4000, 5005, 8000, 8960, 9009, 12000)  # gen_regfft_shapes.py: EMU
 
 
 def test_lengths_with_factors_5_to_13_as_one_launch_on_register_stages(fa, oracle, monkeypatch):
@@ -355,7 +355,7 @@ def test_lengths_with_factors_5_to_13_as_one_launch_on_register_stages(fa, oracl
     the precision runs as a direct transform in ONE launch -- n = j2 + R2 j1, DFT_R1, twiddle, DFT_R2 (, DFT_R3) with one LDS exchange per
     step -- instead of the LDS mixed-radix kernel's round trip per small radix (the reference: Bluestein, fourier/src/lib.rs:38-42; the oracle's
     chirp-z is the comparison, numpy's f64 transform the truth).  All five codes, in place, batches that do not fill the last wave.  The
-    emulator build holds the lengths below of the table's 594 (those the A/B left on their earlier route keep it here too)."""
+    emulator build holds the lengths below of the table's 791 (those the A/B left on their earlier route keep it here too)."""
     seen = 0
     for dtype, tol, tol_truth in ((np.complex64, 2e-6, 4e-7), (np.complex128, 5e-12, 1e-15)):  # (f64: the ORACLE's unreduced chirp angle, 1.4e-12 at 8000)
         for n in REGFFT_LENGTHS:

@@ -1202,10 +1202,10 @@ def test_prefetching_last_pass_matches_the_plain_last_pass(torch, fa, fa_exp, or
 def test_lengths_with_factors_5_and_7_beyond_the_lds_kernels_run_as_tile_passes_by_default(torch, fa, oracle):
     """Round 5: tile-pass kernels for every length 64 ... 512 whose prime factors stop at 7 are compiled ahead of time, so that the
     lengths the reference sends to Bluestein (fourier/src/lib.rs:38-42) but that factor into two or three such tile lengths take
-    direct Stockham passes from plain create_fft_*: 10^5, 44100, 48000, 96000, 10^6, 19600 (between the runtime kernel's reach and
-    the LDS limit; 9800, the case of round 5, runs on three register stages since round 6, regfft_shapes.h), a ragged case (tile length without a factor 16).  Values against the oracle (chirp-z) and the f64 truth."""
+    direct Stockham passes from plain create_fft_*: 10^5, 44100, 48000, 96000, 10^6, f64 19600 (beyond the
+    LDS limit; 9800 and f32 19600, the cases of rounds 5 / 6, run on three register stages since, regfft_shapes.h), a ragged case (tile length without a factor 16).  Values against the oracle (chirp-z) and the f64 truth."""
     for n, dtype, want in ((100000, np.complex64, "400x250"), (44100, np.complex64, "210x210"), (1000000, np.complex64, "1000x1000"), (1000000, np.complex128, "100x100x100"),
-                           (48000, np.complex64, None), (96000, np.complex64, None), (19600, np.complex64, None), (30870, np.complex64, None),
+                           (48000, np.complex64, None), (96000, np.complex64, None), (19600, np.complex128, None), (30870, np.complex64, None),
                            (100000, np.complex128, "400x250"), (44100, np.complex128, "210x210"), (5 * 7 * 7 * 7 * 7 * 3, np.complex128, None),
                            # round 6: tile lengths of 513 ... 1024 points (register tiles on 64-byte rows): two passes where there were three, or Bluestein
                            (390625, np.complex64, "625x625"), (500000, np.complex128, "800x625"), (640000, np.complex64, "800x800"), (729000, np.complex128, "900x810"),

@@ -20,9 +20,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "fourier_amd", "csrc", "regfft_shapes.h")
 NMIN, NMAX, RMAX, RMAX_LONG = 14, 10240, 32, 40
+NMAX_F32 = 20480  # f32 with one transform per workgroup (N x 8 bytes of LDS): the unpaired variants only
 MARGIN = 1.04
 VARIANT_MARGIN = 1.03
-EMU = {22, 77, 143, 175, 200, 245, 350, 385, 400, 560, 700, 800, 1001, 2000, 2002, 2904, 4000, 5005, 8000, 8960, 9009}
+EMU = {22, 77, 143, 175, 200, 245, 350, 385, 400, 560, 700, 800, 1001, 2000, 2002, 2904, 4000, 5005, 8000, 8960, 9009, 12000}
 
 
 def smooth(n, primes):
@@ -56,14 +57,14 @@ def split3(n, rmax):
 
 def candidates():
     rows = []
-    for n in range(NMIN, NMAX + 1):
+    for n in range(NMIN, NMAX_F32 + 1):
         if not smooth(n, (2, 3, 5, 7, 11, 13)) or smooth(n, (2, 3)):
             continue
         s = split2(n, RMAX) or split3(n, RMAX)
         if s is None:
             s = split3(n, RMAX_LONG)
         if s:
-            rows.append((n, s, 1, 1))
+            rows.append((n, s, 1, 1 if n <= NMAX else 0))
     return rows
 
 
@@ -91,7 +92,7 @@ def main(argv):
     rows, kept = [], {"f32": 0, "f64": 0, "split": 0}
     for n, s, f32, f64 in candidates():
         if "--ab-build" in argv:  # every candidate, both exchange variants of the three-stage ones
-            f32 = f64 = 9 if s[2] else 1
+            f32, f64 = (9 if s[2] else 1) if n <= NMAX else 0, (9 if s[2] else 1) if f64 else 0
         elif files:
             def flag(real):
                 t = dict(ab.get((real, n), {}))
@@ -106,7 +107,7 @@ def main(argv):
                         if "before" in u:
                             t = {"registers": best, "before": u["before"]}
                 return v if "registers" in t and "before" in t and t["before"] >= MARGIN * t["registers"] else 0
-            f32, f64 = f32 and flag("f32"), f64 and flag("f64")
+            f32, f64 = (f32 and flag("f32")) if n <= NMAX else 0, f64 and flag("f64")
         if up:  # f32, three stages: the unpaired variants against the listed one (arms listed / unpaired / unpairedfact / before)
             u = up.get(("f32", n), {})
             if s[2] and "before" in u:

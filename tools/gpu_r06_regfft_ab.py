@@ -62,7 +62,8 @@ def main():
                     plans.append(("specialised", p, []))
                 except Exception as e:  # noqa: BLE001 -- a length the run-time route refuses stays out of the table
                     print(f"specialise({n}) refused: {e}", file=sys.stderr)
-            if "registers" not in plans[0][1].describe():  # no kernel in this precision
+            plans = [p for p in plans if p[0] in ("before", "specialised") or "registers" in p[1].describe()]  # (an arm without a kernel in this precision)
+            if plans[0][0] in ("before", "specialised"):
                 continue
             errs = {}
             for name, plan, ts in plans:
