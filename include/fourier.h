@@ -98,8 +98,8 @@ enum {
  *     lengths <= 576 (12288 ... 331776)
  *   2^a * 3^b, a >= 12, every other length          "stockham <L1>x...x<27|9|3>": the power-of-two passes over 2^a, then radix-27 / 9 / 3 passes
  *   a length of 14 ... 20480 points with a factor   "stockham registers <R1>x<R2>[x<R3>] one-launch" (round 6): the whole transform in one launch on two or
- *     5 ... 13 that fourier_amd/csrc/regfft_shapes.h  three register-resident stages of at most 40 points -- 736 lengths in f32 (to 20475 points:
- *     lists in the precision (f64: to 10240 points)   one transform per workgroup above 10240), 585 in f64, each one measured at least 1.04 x faster
+ *     5 ... 13 that fourier_amd/csrc/regfft_shapes.h  three register-resident stages of at most 40 points -- 736 lengths in f32, 763 in f64 (to 20475 points:
+ *     lists in the precision                          above 10240 f32 one transform per workgroup, f64 split planes), each one at least 1.04 x faster
  *                                                   than the route below it had (5005: f32 0.24 -> 0.49 of the HBM peak, f64 0.14 (Bluestein)
  *                                                   -> 0.50; 1001: 0.42 -> 0.60, 0.27 -> 0.69; f32 15625: 0.33 -> 0.42)
  *   2^a * 3^b * 5^c * 7^d * 11^e * 13^f that fit    "stockham mixed-radix <r1>.<r2>...." (+ " specialised" for a kernel compiled at run time):

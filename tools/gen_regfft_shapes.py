@@ -20,7 +20,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "fourier_amd", "csrc", "regfft_shapes.h")
 NMIN, NMAX, RMAX, RMAX_LONG = 14, 10240, 32, 40
-NMAX_F32 = 20480  # f32 with one transform per workgroup (N x 8 bytes of LDS): the unpaired variants only
+NMAX_F32 = 20480  # N x 8 bytes of LDS: f32 with one transform per workgroup (the unpaired variants), f64 on split-plane exchanges
 MARGIN = 1.04
 VARIANT_MARGIN = 1.03
 EMU = {22, 77, 143, 175, 200, 245, 350, 385, 400, 560, 700, 800, 1001, 2000, 2002, 2904, 4000, 5005, 8000, 8960, 9009, 12000}
@@ -64,7 +64,7 @@ def candidates():
         if s is None:
             s = split3(n, RMAX_LONG)
         if s:
-            rows.append((n, s, 1, 1 if n <= NMAX else 0))
+            rows.append((n, s, 1, 1))  # (beyond NMAX: f32 unpaired, f64 on split-plane exchanges only -- N x 8 bytes of LDS)
     return rows
 
 
@@ -117,6 +117,8 @@ def main(argv):
                     best, v = min(arms)
                     if cur is None or cur >= VARIANT_MARGIN * best:
                         f32 = v if u["before"] >= MARGIN * best else f32
+        if "--long-f64-build" in argv and s[2] and n > NMAX:  # f64 beyond NMAX: the split-plane variants are the ones that fit the LDS
+            f64 = 9
         if "--unpaired-build" in argv and s[2]:  # the listed variant (or the plain kernel) and the two unpaired ones
             f32 = 10 + (f32 or 1)
         if f32 or f64:
@@ -125,7 +127,7 @@ def main(argv):
             kept["f64"] += bool(f64)
             kept["split"] += (f32 > 1) + (f64 > 1)
     with open(OUT, "w") as f:
-        f.write("// regfft_shapes.h -- GENERATED by tools/gen_regfft_shapes.py" + "".join(" --ab " + os.path.relpath(x, ROOT) for x in files) + "".join(" --split-ab " + os.path.relpath(x, ROOT) for x in split_files) + "".join(" --unpaired-ab " + os.path.relpath(argv[i + 1], ROOT) for i, a in enumerate(argv) if a == "--unpaired-ab") + (" --ab-build" if "--ab-build" in argv else "") + (" --unpaired-build" if "--unpaired-build" in argv else "") + "\n")
+        f.write("// regfft_shapes.h -- GENERATED by tools/gen_regfft_shapes.py" + "".join(" --ab " + os.path.relpath(x, ROOT) for x in files) + "".join(" --split-ab " + os.path.relpath(x, ROOT) for x in split_files) + "".join(" --unpaired-ab " + os.path.relpath(argv[i + 1], ROOT) for i, a in enumerate(argv) if a == "--unpaired-ab") + (" --ab-build" if "--ab-build" in argv else "") + (" --unpaired-build" if "--unpaired-build" in argv else "") + (" --long-f64-build" if "--long-f64-build" in argv else "") + "\n")
         f.write("// the lengths of kernels_regfft.h: FOURIER_REGFFT_ROW(N, R1, R2, R3 (0: two stages), f32, f64, in the emulator build); a precision's flag:\n")
         f.write("// 0 = not adopted, 1 = adopted; three stages: 2 = split-plane exchanges, 3 = factored twiddle tables, 4 = both, f32 5 / 6 = one transform per\n")
         f.write("// workgroup (unpaired) without / with factored tables; A/B builds: 9 = 1 ... 4 built, 10 + F = the listed F and 5 / 6 built\n")

@@ -33,7 +33,10 @@ def main():
     base = _lib.lib()
     exp = _lib.bind(ctypes.CDLL(B.OUT_EXPERIMENTS), strict=False)
     st = torch.cuda.current_stream().cuda_stream
-    for real, cdt, esz in (("f32", torch.complex64, 8), ("f64", torch.complex128, 16))[: 1 if UNPAIRED else 2]:
+    reals = [v for v in os.environ.get("REGFFT_REALS", "").split(",") if v] or (["f32"] if UNPAIRED else ["f32", "f64"])
+    for real, cdt, esz in (("f32", torch.complex64, 8), ("f64", torch.complex128, 16)):
+        if real not in reals:
+            continue
         xbuf = torch.empty(BYTES // esz, dtype=cdt, device="cuda"); torch.view_as_real(xbuf).uniform_(-1, 1); ybuf = torch.empty_like(xbuf)
         mk = F.create_fft_f32 if real == "f32" else F.create_fft_f64
         for n in SIZES:
