@@ -19,4 +19,6 @@ FOURIER_EMU_ASAN=$MODE LD_PRELOAD="$PRE" ASAN_OPTIONS=detect_leaks=0:detect_stac
   python -m pytest tests/test_engine_emu.py -q -m "not gpu" -p no:cacheprovider "${@:--n 6}"
 rc=$?
 if ls /tmp/fourier_asan.* > /dev/null 2>&1; then echo "AddressSanitizer reports:"; head -30 /tmp/fourier_asan.*; exit 1; fi
+# (the sanitizer objects must not stay in the tree: gpurun refuses a snapshot that holds -fsanitize=address objects under tests/)
+rm -rf tests/emu/obj_asan* tests/emu/libfourier_emu_asan*
 echo "AddressSanitizer${UBSAN:+ / UndefinedBehaviorSanitizer}: no report"; exit $rc
