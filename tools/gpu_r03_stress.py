@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Round 3 one-off stress: every 2^a*3^b up to 6e6 (LDS, global-pass and tiled routes), every length up to 18432 whose prime
+"""Round 3 one-off stress: every 2^a*3^b up to 6e6 (LDS, global-pass and tiled routes), every length up to 20480 whose prime
 factors stop at 13 (the radix-5/7/11/13 LDS kernels), random other sizes, random codes,
 in and out of place, f32 and f64, against the oracle.  Prints one line per failure and a summary."""
 import json, os, sys, time
@@ -18,7 +18,7 @@ def _smooth(limit, primes):
     for p in primes:
         vals = {v * p ** e for v in vals for e in range(0, 16) if v * p ** e <= limit}
     return vals
-smooth13 = sorted(v for v in _smooth(18432, [2, 3, 5, 7, 11, 13]) if any(v % p == 0 for p in (5, 7, 11, 13)))  # the prime-radix LDS kernels
+smooth13 = sorted(v for v in _smooth(20480, [2, 3, 5, 7, 11, 13]) if any(v % p == 0 for p in (5, 7, 11, 13)))  # the prime-radix LDS kernels
 # round 5: lengths with factors 5 / 7 beyond the LDS kernels (ahead-of-time tile passes): a random 120 of the 7-smooth lengths up to 3e6
 smooth7_big = sorted(v for v in _smooth(3_000_000, [2, 3, 5, 7]) if v > 8192 and (v % 5 == 0 or v % 7 == 0))
 smooth7_big = sorted({int(v) for v in rng.choice(smooth7_big, size=min(120, len(smooth7_big)), replace=False)})
