@@ -410,8 +410,11 @@ template <typename T> class BluRegEngine {
   static bool has_direct(size_t n) {
     return n <= 20480 && !dev_env("FOURIER_NO_REGFFT") && get_regfft_kernel(Real<T>{}, (uint32_t)n, direct_variant()).fn != nullptr;
   }
-  BluRegEngine(size_t n_user, uint32_t m, bool direct = false)
-      : n_(n_user), direct_(direct), k_(direct ? get_regfft_kernel(Real<T>{}, m, direct_variant()) : get_chirpz_kernel(Real<T>{}, m)) {
+  // (variant 100: a 2^a 3^b length on request, plan option "register_stages")
+  static bool has_direct_on_request(size_t n) { return n <= 20480 && get_regfft_kernel(Real<T>{}, (uint32_t)n, 100).fn != nullptr; }
+  BluRegEngine(size_t n_user, uint32_t m, bool direct = false, int variant = -1)
+      : n_(n_user), direct_(direct),
+        k_(direct ? get_regfft_kernel(Real<T>{}, m, variant < 0 ? direct_variant() : variant) : get_chirpz_kernel(Real<T>{}, m)) {
     if (!k_.fn || (direct ? (uint64_t)m != n_user : (uint64_t)m < 2 * (uint64_t)n_user - 1))
       throw EngineError(::fourier::c::FOURIER_HIP_UNSUPPORTED, "no one-launch register kernel of this length");
     raise_smem_limit((const void*)k_.fn, k_.smem);

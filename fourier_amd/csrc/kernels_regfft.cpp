@@ -51,6 +51,18 @@ enum { REGFFT_COUNTER_BASE = __COUNTER__ };
     }                                                                                                                  \
     return ChirpzKernel();
 
+// a 2^a 3^b length: by default such lengths keep the reference's own schedule (bit-identical to the CPU restatement, plan.h); the register-stage
+// kernel is handed out only to a caller that asks for it (variant >= 100: plan option "register_stages")
+#define FOURIER_REGFFT_OPT_ROW(NN, A, B, C, F32, F64, EMU) FOURIER_REGFFT_OPT_ROW_I(NN, A, B, C, F32, F64, EMU, (__COUNTER__ - REGFFT_COUNTER_BASE - 1))
+#define FOURIER_REGFFT_OPT_ROW_I(NN, A, B, C, F32, F64, EMU, IDX)                                                      \
+  case NN:                                                                                                             \
+    if constexpr ((IDX) % FOURIER_REGFFT_SHARDS == FOURIER_REGFFT_SHARD && (sizeof(T) == 4 ? (F32) : (F64)) != 0 && FOURIER_REGFFT_BUILT(EMU)) { \
+      constexpr int F = sizeof(T) == 4 ? (F32) : (F64);                                                                \
+      if (variant < 100) return ChirpzKernel();                                                                        \
+      return make_regfft<T, A, B, C, (F == 2 || F == 4) && (C) != 0, (F == 3 || F == 4 || F == 6) && (C) != 0, !((F == 5 || F == 6) && (C) != 0 && sizeof(T) == 4)>(); \
+    }                                                                                                                  \
+    return ChirpzKernel();
+
 template <typename T> static ChirpzKernel lookup(uint32_t n, int variant) {
   switch (n) {
 #include "regfft_shapes.h"
@@ -59,6 +71,8 @@ template <typename T> static ChirpzKernel lookup(uint32_t n, int variant) {
 }
 #undef FOURIER_REGFFT_ROW
 #undef FOURIER_REGFFT_ROW_I
+#undef FOURIER_REGFFT_OPT_ROW
+#undef FOURIER_REGFFT_OPT_ROW_I
 
 #define FOURIER_REGFFT_SHARD_FN_(I) get_regfft_kernel_s##I
 #define FOURIER_REGFFT_SHARD_FN(I) FOURIER_REGFFT_SHARD_FN_(I)

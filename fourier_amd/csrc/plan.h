@@ -306,6 +306,22 @@ template <typename T> class Plan {
       }
       return 0;
     }
+    // "register_stages" = 1: a 2^a 3^b length that runs the LDS kernel on the reference's own schedule (bit-identical to the CPU restatement)
+    // takes the register-stage kernel regfft_shapes.h lists for it instead (kernels_regfft.h: within the tolerance, not the bits; 1.04 ... 1.6 x);
+    // 0 brings the default back.  UNSUPPORTED where no such kernel is listed; OK unchanged on a plan that runs register stages by default.
+    if (key == "register_stages" && (v == 0 || v == 1)) {
+      if (v == 1) {
+        if (regf_) return ::fourier::c::FOURIER_HIP_OK;
+        if (!mix_ || !BluRegEngine<T>::has_direct_on_request(n_)) return ::fourier::c::FOURIER_HIP_UNSUPPORTED;
+        try { regf_.reset(new BluRegEngine<T>(n_, (uint32_t)n_, true, 100)); } catch (const EngineError& e) { return e.status; }
+        regf_on_request_ = true;
+      } else if (regf_on_request_) {
+        regf_.reset();
+        regf_on_request_ = false;
+      }
+      refresh_desc();
+      return ::fourier::c::FOURIER_HIP_OK;
+    }
     // "specialise" = 1: compile this length's own LDS mixed-radix kernel with hipRTC (about a second, now) and run it from the
     // next call on -- for a length whose prime factors stop at 13, that fits a compute unit's LDS and has no ahead-of-time
     // per-length kernel (it runs the runtime-parameterised kernel, or Bluestein beyond that kernel's reach).  A plan that
@@ -852,6 +868,7 @@ template <typename T> class Plan {
   std::unique_ptr<BluTiledEngine<T>> blut_;       // Bluestein on a smooth M (then eng_ is empty)
   std::unique_ptr<BluRegEngine<T>> blur_;         // ... of a short transform: one launch, transforms in registers (then eng_ is empty)
   std::unique_ptr<BluRegEngine<T>> regf_;         // a length with factors 5 ... 13 as a direct transform on the same register stages
+  bool regf_on_request_ = false;                  // ... of a 2^a 3^b length, by plan option "register_stages" (mix_ stays allocated)
   int smooth_m_mode_ = 1;                         // option "bluestein_smooth_m"
   std::unique_ptr<MixedEngine<T>> mix_;
   std::unique_ptr<TiledMixedEngine<T>> tiled_;  // 2^a*3^b, a < 12, beyond the LDS kernels: column tiles of mixed length

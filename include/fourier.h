@@ -188,7 +188,7 @@ int fourier_hip_last_status_float(const FOURIER_STRUCT fourier_fft_float *);
 int fourier_hip_last_status_double(const FOURIER_STRUCT fourier_fft_double *);
 const char *fourier_hip_status_string(int status);
 
-/* Tunables (return FOURIER_HIP_OK or FOURIER_HIP_INVALID_ARGUMENT; "specialise" also FOURIER_HIP_UNSUPPORTED).  A handle is Send, not
+/* Tunables (return FOURIER_HIP_OK or FOURIER_HIP_INVALID_ARGUMENT; "specialise" and "register_stages" also FOURIER_HIP_UNSUPPORTED).  A handle is Send, not
  * Sync, as in the reference (RefCell scratch, autosort/mod.rs:54): fourier_hip_set_option_* must not run concurrently with a
  * transform or another call on the SAME handle ("specialise" swaps the engine the plan executes with).
  *   "chunk_bytes"  bytes of one batch chunk pushed through all passes before the next chunk starts
@@ -243,6 +243,12 @@ const char *fourier_hip_status_string(int status);
  *                  below (launch and event latency); what it buys is MEMORY -- an in-place call then needs the ring (two chunks) instead of a
  *                  scratch of the whole batch.  The call stays stream-ordered on the caller's stream (forked into and joined from the internal
  *                  streams; capturable after fourier_hip_reserve_*).  0 = off (default).  INVALID_ARGUMENT on any other plan.
+ *   "register_stages" 1 = a 2^a * 3^b length that runs the LDS kernel on the reference's own schedule (bit-identical to the reference's CPU
+ *                  arithmetic as restated in oracle/) takes the register-stage kernel that fourier_amd/csrc/regfft_shapes.h lists for it ON REQUEST
+ *                  instead ("stockham registers <R1>x<R2>[x<R3>] one-launch": the same values within rounding, not the same bits; 24 lengths in
+ *                  f32, 34 in f64, each 1.04 ... 1.44 x faster -- 4608 f32 0.46 -> 0.56 of the HBM peak, 13122 f32 0.32 -> 0.41, 2592 f64 0.57 -> 0.72);
+ *                  0 = back to the default.  FOURIER_HIP_UNSUPPORTED where no such kernel is listed (the plan is unchanged); OK and
+ *                  unchanged on a plan that runs register stages by default.
  *   "l2_fused"     (lib/libfourier_experiments.so only; INVALID_ARGUMENT in the product library; so is
  *                  "last_pass_prefetch", the persistent prefetching last pass of DESIGN.md section 4) 1 = run both
  *                  passes of a two-pass plan in ONE launch with the intermediate parked in the XCD's L2 (persistent

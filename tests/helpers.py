@@ -78,10 +78,11 @@ def max_rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
 
 
-def regfft_shape(n, dtype, emu=False):
+def regfft_shape(n, dtype, emu=False, on_request=False):
     """The register stages "R1xR2[xR3]" of a length that runs as a direct transform in one launch (fourier_amd/csrc/regfft_shapes.h, generated from
-    the A/B tables of sessions 49 - 51 by tools/gen_regfft_shapes.py), or None where the length keeps another route in this precision
-    (emu: in the CPU emulation build, which holds the subset its test names)."""
+    the A/B tables of sessions 49 - 66 by tools/gen_regfft_shapes.py), or None where the length keeps another route in this precision
+    (emu: in the CPU emulation build, which holds the subset its test names; on_request: the 2^a 3^b lengths that take register stages only
+    under plan option "register_stages")."""
     import re
 
     global _REGFFT_ROWS
@@ -90,9 +91,11 @@ def regfft_shape(n, dtype, emu=False):
     except NameError:
         path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fourier_amd", "csrc", "regfft_shapes.h")
         with open(path) as f:
-            rows = _REGFFT_ROWS = {int(m.group(1)): tuple(int(v) for v in m.groups()[1:])
-                                   for m in re.finditer(r"^FOURIER_REGFFT_ROW\((\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d)\)", f.read(), re.M)}
-    r = rows.get(int(n))
+            text = f.read()
+        rows = _REGFFT_ROWS = {kind: {int(m.group(1)): tuple(int(v) for v in m.groups()[1:])
+                                      for m in re.finditer(r"^FOURIER_REGFFT_%sROW\((\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d)\)" % kind, text, re.M)}
+                               for kind in ("", "OPT_")}
+    r = rows["OPT_" if on_request else ""].get(int(n))
     if r is None or not r[3 if np.dtype(dtype).itemsize == 8 else 4] or (emu and not r[5]):
         return None
     return f"{r[0]}x{r[1]}" + (f"x{r[2]}" if r[2] else "")

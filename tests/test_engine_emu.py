@@ -379,6 +379,49 @@ def test_lengths_with_factors_5_to_13_as_one_launch_on_register_stages(fa, oracl
     assert "mixed-radix" in make(fa, 1001, np.complex64).describe() and "mixed-radix" in make(fa, 350, np.complex128).describe()
 
 
+def test_plan_option_register_stages_moves_a_2a3b_length_off_the_reference_schedule_on_request(fa, oracle):
+    """Round 6 (sessions 66 / 67): 2^a 3^b lengths keep the reference's own schedule by default -- bit-identical to the CPU restatement -- and
+    take the register-stage kernel regfft_shapes.h lists for them (FOURIER_REGFFT_OPT_ROW) only under plan option "register_stages" = 1:
+    the same values within rounding, every code, in place; 0 restores the bits; a length without such a kernel refuses, a plan that runs
+    register stages by default returns OK unchanged."""
+    seen = 0
+    for n in (729, 1536, 4608):
+        for dtype, tol, close in ((np.complex64, 1e-6, 4e-7), (np.complex128, 2e-14, 2e-15)):
+            plan = make(fa, n, dtype)
+            base = plan.describe()
+            assert "mixed-radix" in base
+            if regfft_shape(n, dtype, emu=True, on_request=True) is None:  # not listed in this precision (the A/B of session 66)
+                with pytest.raises(fa.FourierError):
+                    plan.set_option("register_stages", 1)
+                assert plan.describe() == base
+                continue
+            seen += 1
+            x = np.stack([hash_normal(70 + b, n) for b in range(3)]).astype(dtype)
+            want = {code: run_batch(plan, x, code) for code in range(5)}
+            assert all(np.array_equal(want[code], oracle.transform_batch(x, code)) for code in range(5)), n
+            plan.set_option("register_stages", 1)
+            assert plan.describe().startswith("stockham registers " + regfft_shape(n, dtype, emu=True, on_request=True) + " one-launch"), plan.describe()
+            for code in range(5):
+                got = run_batch(plan, x, code)
+                assert rel_l2(got, oracle.transform_batch(x, code)) <= tol and rel_l2(got, want[code]) <= close, (n, code, rel_l2(got, want[code]))
+                assert np.array_equal(run_batch(plan, x, code, inplace=True), got), (n, code)
+            plan.set_option("register_stages", 1)  # twice: unchanged
+            plan.set_option("register_stages", 0)
+            assert plan.describe() == base and np.array_equal(run_batch(plan, x, 0), want[0]), n
+    assert seen >= 5, seen
+    for n in (1024, 1013, 3 * 4096):  # a power of two, a Bluestein length, 2^a 3^b on tile passes: no kernel on request
+        plan = make(fa, n, np.complex64)
+        desc = plan.describe()
+        with pytest.raises(fa.FourierError):
+            plan.set_option("register_stages", 1)
+        assert plan.describe() == desc
+    plan = make(fa, 1001, np.complex64)
+    desc = plan.describe()
+    plan.set_option("register_stages", 1)
+    plan.set_option("register_stages", 0)
+    assert plan.describe() == desc and "registers" in desc
+
+
 def test_bluestein_fusion_matches_unfused(fa):
     """The fused Bluestein forms (whole chirp-z in one launch for M <= 2^15; chirp steps fused into the
     inner passes above) give the same values, to rounding, as the separate blu_pre / blu_post sweeps

@@ -1504,6 +1504,43 @@ def test_register_resident_tile_passes_against_the_lds_tile_passes(torch, fa, fa
         assert not np.array_equal(gpu_batch(torch, fa, reg, x, 0), gpu_batch(torch, fa, lds, x, 0))  # two different kernels really ran
 
 
+@pytest.mark.gpu
+def test_plan_option_register_stages_moves_a_2a3b_length_off_the_reference_schedule_on_request(torch, fa, oracle):
+    """Round 6 (sessions 66 / 67): by default a 2^a 3^b length runs the reference's own schedule, bit-identical to the CPU restatement; under plan
+    option "register_stages" = 1 it takes the register-stage kernel regfft_shapes.h lists for it on request (kernels_regfft.h: the same values
+    within rounding, 1.04 ... 1.44 x): every code, in place, a ragged batch; 0 restores the bits; lengths without such a kernel refuse."""
+    for n, dtype in ((729, np.complex64), (729, np.complex128), (4608, np.complex64), (2592, np.complex128), (13122, np.complex64), (19683, np.complex64),
+                     (9216, np.complex128)):
+        shape = regfft_shape(n, dtype, on_request=True)
+        assert shape is not None, (n, dtype)
+        plan = make(fa, n, dtype)
+        base = plan.describe()
+        assert "mixed-radix" in base
+        batch = 67 if n < 5000 else 9
+        x = np.stack([hash_normal(5200 + b, n) for b in range(batch)]).astype(dtype)
+        want = {code: gpu_batch(torch, fa, plan, x, code) for code in range(5)}
+        assert np.array_equal(want[0][:3], oracle.transform_batch(x[:3], 0)), n
+        plan.set_option("register_stages", 1)
+        assert plan.describe().startswith(f"stockham registers {shape} one-launch"), plan.describe()
+        tol, close = (1e-6, 4e-7) if dtype == np.complex64 else (5e-14, 3e-15)
+        for code in range(5):
+            got = gpu_batch(torch, fa, plan, x, code)
+            assert rel_l2(got[:3], oracle.transform_batch(x[:3], code)) <= tol and rel_l2(got, want[code]) <= close, (n, code, rel_l2(got, want[code]))
+            assert np.array_equal(gpu_batch(torch, fa, plan, x, code, inplace=True), got), (n, code)
+        assert not np.array_equal(gpu_batch(torch, fa, plan, x, 0), want[0])  # another kernel really ran
+        plan.set_option("register_stages", 0)
+        assert plan.describe() == base and np.array_equal(gpu_batch(torch, fa, plan, x, 0), want[0]), n
+    for n in (1024, 1013, 3 * 4096, 96):  # a power of two, a Bluestein length, 2^a 3^b on tile passes, a 2^a 3^b length the A/B left out
+        plan = make(fa, n, np.complex64)
+        desc = plan.describe()
+        with pytest.raises(fa.FourierError):
+            plan.set_option("register_stages", 1)
+        assert plan.describe() == desc
+    plan = make(fa, 1001, np.complex64)
+    plan.set_option("register_stages", 1)
+    assert "registers 13x11x7" in plan.describe()
+
+
 CHIRPZ_REG3_MENU = [1296, 1440, 1600, 2304, 2560, 3072, 8820, 9261]  # M = R1 x R2 x R3
 CHIRPZ_REG_MENU = [36, 49, 64, 81, 100, 120, 144, 168, 196, 225, 256, 288, 324, 360, 400, 441, 480, 525, 576, 625, 675, 729, 784, 840, 900, 960, 1024]
 

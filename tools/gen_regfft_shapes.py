@@ -23,6 +23,7 @@ NMIN, NMAX, RMAX, RMAX_LONG = 14, 10240, 32, 40
 NMAX_F32 = 20480  # N x 8 bytes of LDS: f32 with one transform per workgroup (the unpaired variants), f64 on split-plane exchanges
 MARGIN = 1.04
 VARIANT_MARGIN = 1.03
+EMU_OPT = {729, 1536, 4608}
 EMU = {22, 77, 143, 175, 200, 245, 350, 385, 400, 560, 700, 800, 1001, 2000, 2002, 2904, 4000, 5005, 8000, 8960, 9009, 12000}
 
 
@@ -65,6 +66,19 @@ def candidates():
             s = split3(n, RMAX_LONG)
         if s:
             rows.append((n, s, 1, 1))  # (beyond NMAX: f32 unpaired, f64 on split-plane exchanges only -- N x 8 bytes of LDS)
+    return rows
+
+
+def optin_candidates():
+    """2^a 3^b lengths that are not powers of two: on request only (plan option "register_stages"; by default they keep the reference's schedule).
+    Up to NMAX the plain kernel; beyond, the variants that fit the LDS (f32 unpaired with factored tables, f64 split planes with factored tables)."""
+    rows = []
+    for n in range(NMIN, NMAX_F32 + 1):
+        if not smooth(n, (2, 3)) or n & (n - 1) == 0:
+            continue
+        s = split2(n, RMAX) or split3(n, RMAX) or split3(n, RMAX_LONG)
+        if s:
+            rows.append((n, s, 1 if n <= NMAX else 6, 1 if n <= NMAX else 4))
     return rows
 
 
@@ -126,8 +140,18 @@ def main(argv):
             kept["f32"] += bool(f32)
             kept["f64"] += bool(f64)
             kept["split"] += (f32 > 1) + (f64 > 1)
+    opt = read_ab([argv[i + 1] for i, a in enumerate(argv) if a == "--optin-ab"])
+    opt_rows = []
+    for n, s3, f32, f64 in optin_candidates():
+        if "--optin-build" not in argv:
+            def won(real):
+                t = opt.get((real, n), {})
+                return "registers" in t and "before" in t and t["before"] >= MARGIN * t["registers"]
+            f32, f64 = f32 if won("f32") else 0, f64 if won("f64") else 0
+        if f32 or f64:
+            opt_rows.append((n, s3, f32, f64))
     with open(OUT, "w") as f:
-        f.write("// regfft_shapes.h -- GENERATED by tools/gen_regfft_shapes.py" + "".join(" --ab " + os.path.relpath(x, ROOT) for x in files) + "".join(" --split-ab " + os.path.relpath(x, ROOT) for x in split_files) + "".join(" --unpaired-ab " + os.path.relpath(argv[i + 1], ROOT) for i, a in enumerate(argv) if a == "--unpaired-ab") + (" --ab-build" if "--ab-build" in argv else "") + (" --unpaired-build" if "--unpaired-build" in argv else "") + (" --long-f64-build" if "--long-f64-build" in argv else "") + "\n")
+        f.write("// regfft_shapes.h -- GENERATED by tools/gen_regfft_shapes.py" + "".join(" --ab " + os.path.relpath(x, ROOT) for x in files) + "".join(" --split-ab " + os.path.relpath(x, ROOT) for x in split_files) + "".join(" --unpaired-ab " + os.path.relpath(argv[i + 1], ROOT) for i, a in enumerate(argv) if a == "--unpaired-ab") + (" --ab-build" if "--ab-build" in argv else "") + (" --unpaired-build" if "--unpaired-build" in argv else "") + (" --long-f64-build" if "--long-f64-build" in argv else "") + "".join(" --optin-ab " + os.path.relpath(argv[i + 1], ROOT) for i, a in enumerate(argv) if a == "--optin-ab") + (" --optin-build" if "--optin-build" in argv else "") + "\n")
         f.write("// the lengths of kernels_regfft.h: FOURIER_REGFFT_ROW(N, R1, R2, R3 (0: two stages), f32, f64, in the emulator build); a precision's flag:\n")
         f.write("// 0 = not adopted, 1 = adopted; three stages: 2 = split-plane exchanges, 3 = factored twiddle tables, 4 = both, f32 5 / 6 = one transform per\n")
         f.write("// workgroup (unpaired) without / with factored tables; A/B builds: 9 = 1 ... 4 built, 10 + F = the listed F and 5 / 6 built\n")
@@ -135,6 +159,10 @@ def main(argv):
         for n, (r1, r2, r3), f32, f64 in rows:
             assert r1 * r2 * (r3 or 1) == n
             f.write(f"FOURIER_REGFFT_ROW({n}, {r1}, {r2}, {r3}, {f32}, {f64}, {int(n in EMU)})\n")
+        f.write(f"// on request (plan option \"register_stages\"): {len(opt_rows)} lengths 2^a 3^b, {sum(bool(r[2]) for r in opt_rows)} in f32, {sum(bool(r[3]) for r in opt_rows)} in f64\n")
+        for n, (r1, r2, r3), f32, f64 in opt_rows:
+            assert r1 * r2 * (r3 or 1) == n
+            f.write(f"FOURIER_REGFFT_OPT_ROW({n}, {r1}, {r2}, {r3}, {f32}, {f64}, {int(n in EMU_OPT)})\n")
     print(f"{OUT}: {len(rows)} lengths, f32 {kept['f32']}, f64 {kept['f64']}, split {kept['split']}")
 
 

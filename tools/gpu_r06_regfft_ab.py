@@ -15,11 +15,14 @@ from fourier_amd import fft as F, _lib, build as B
 
 
 VARIANTS = os.environ.get("REGFFT_VARIANTS") in ("1", "2")
+OPTIN = os.environ.get("REGFFT_VARIANTS") == "3"  # the 2^a 3^b lengths listed on request: plan option "register_stages" = 1 against the default plan
 UNPAIRED = os.environ.get("REGFFT_VARIANTS") == "2"  # an --unpaired-build: f32 only, arms listed / unpaired / unpairedfact / before
 
 
 def listed():
     with open(os.path.join(ROOT, "fourier_amd", "csrc", "regfft_shapes.h")) as f:
+        if OPTIN:
+            return [int(m.group(1)) for m in re.finditer(r"^FOURIER_REGFFT_OPT_ROW\((\d+),", f.read(), re.M)]
         return [int(m.group(1)) for m in re.finditer(r"^FOURIER_REGFFT_ROW\((\d+), \d+, \d+, (\d+),", f.read(), re.M) if not VARIANTS or int(m.group(2))]
 
 
@@ -52,12 +55,20 @@ def main():
                     _lib._lib = base
                     for k in env:
                         del os.environ[k]
-            if VARIANTS:
+            if OPTIN:
+                p = mk(n, 0)
+                try:
+                    p.set_option("register_stages", 1)
+                except Exception:  # noqa: BLE001 -- no kernel listed in this precision
+                    continue
+                plans = [("registers", p, []), ("before", mk(n, 0), [])]
+            elif VARIANTS:
                 arms = (("listed", 0), ("unpaired", 5), ("unpairedfact", 6)) if UNPAIRED else (("plain", 1), ("split", 2), ("fact", 3), ("splitfact", 4))
                 plans = [(name, under({"FOURIER_REGFFT_VARIANT": str(v)}, exp), []) for name, v in arms]
             else:
                 plans = [("registers", mk(n, 0), [])]
-            plans.append(("before", under({"FOURIER_NO_REGFFT": "1"}, exp), []))
+            if not OPTIN:
+                plans.append(("before", under({"FOURIER_NO_REGFFT": "1"}, exp), []))
             if n in SPECIALISED:
                 p = under({"FOURIER_NO_REGFFT": "1"}, exp)
                 try:
