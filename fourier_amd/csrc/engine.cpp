@@ -109,15 +109,30 @@ int specialise_policy() {
   return v;
 }
 void set_specialise_policy(int v) { g_specialise_policy.store(v, std::memory_order_relaxed); }
+namespace {
+std::atomic<int> g_register_stages{-1};
+}
+int register_stages_default() {
+  int v = g_register_stages.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("FOURIER_HIP_REGISTER_STAGES");
+    v = (e && e[0] == '1' && !e[1]) ? 1 : 0;
+    g_register_stages.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+void set_register_stages_default(int v) { g_register_stages.store(v, std::memory_order_relaxed); }
 }  // namespace fourier_hip
 
 extern "C" int fourier_hip_set_default_option(const char* key, long long v) {
   if (!key) return fc::FOURIER_HIP_INVALID_ARGUMENT;
   if (std::string(key) == "specialise_at_create" && v >= 0 && v <= 2) { set_specialise_policy((int)v); return fc::FOURIER_HIP_OK; }
+  if (std::string(key) == "register_stages_at_create" && (v == 0 || v == 1)) { set_register_stages_default((int)v); return fc::FOURIER_HIP_OK; }
   return fc::FOURIER_HIP_INVALID_ARGUMENT;
 }
 extern "C" long long fourier_hip_get_default_option(const char* key) {
   if (key && std::string(key) == "specialise_at_create") return specialise_policy();
+  if (key && std::string(key) == "register_stages_at_create") return register_stages_default();
   return -1;
 }
 

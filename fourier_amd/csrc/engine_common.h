@@ -209,6 +209,10 @@ bool rtc_cached(bool f64, uint32_t n, size_t lds_bytes, bool tile_pass);
 // where the cache has none (about a second per new length and machine)
 int specialise_policy();
 void set_specialise_policy(int v);
+// ... and whether a 2^a 3^b length with a register-stage kernel listed on request takes it at create ("register_stages_at_create", or
+// FOURIER_HIP_REGISTER_STAGES=1 read once): 0 (default) = the reference's schedule and its bits, 1 = the faster kernel, within rounding
+int register_stages_default();
+void set_register_stages_default(int v);
 
 // ---------------------------------------------------------------------------------------------
 // Kernel registry.  Real<T> selects the precision; every function is defined once per precision in the translation unit

@@ -106,6 +106,11 @@ template <typename T> class Plan {
     } else if (MixedEngine<T>::handles(n) && try_mixed(n)) {
       // a length on the runtime-parameterised kernel takes its own kernel where the code-object cache has it (policy 2: compiles it)
       if (specialise_policy() >= 1) (void)mix_->specialise(nullptr, specialise_policy() >= 2);
+      // ... and a 2^a 3^b length the register-stage kernel listed for it on request, where the library-wide default says so
+      if (register_stages_default() == 1 && BluRegEngine<T>::has_direct_on_request(n)) {
+        regf_.reset(new BluRegEngine<T>(n, (uint32_t)n, true, 100));
+        regf_on_request_ = true;
+      }
     } else if (TiledMixedEngine<T>::handles(n)) {
       tiled_.reset(new TiledMixedEngine<T>(n));  // two or three HBM round trips on column tiles of mixed length
     } else if (GenericEngine<T>::handles(n)) {

@@ -260,7 +260,7 @@ const char *fourier_hip_status_string(int status);
 int fourier_hip_set_option_float(FOURIER_STRUCT fourier_fft_float *, const char *key, long long value);
 int fourier_hip_set_option_double(FOURIER_STRUCT fourier_fft_double *, const char *key, long long value);
 
-/* Library-wide defaults for plans created AFTERWARDS (any thread; plans that exist keep what they have).  The one key:
+/* Library-wide defaults for plans created AFTERWARDS (any thread; plans that exist keep what they have).  The keys:
  *   "specialise_at_create"  what `create` does for a length whose prime factors stop at 13 and that has no ahead-of-time route
  *                  (it would run the runtime-parameterised LDS kernel or Bluestein):
  *                    0  nothing: run-time kernels only through fourier_hip_set_option_*(h, "specialise", 1)
@@ -270,7 +270,10 @@ int fourier_hip_set_option_double(FOURIER_STRUCT fourier_fft_double *, const cha
  *                  so that a drop-in caller of fourier_create_float / create_fft_f32 reaches the specialised kernels with one call at
  *                  start-up, or with NO code change through the environment variable FOURIER_HIP_SPECIALISE=0|1|2 (read once, before the
  *                  first plan; the function overrides it).
- * Environment the library reads, all of it: FOURIER_HIP_VERBOSE (error text on stderr), FOURIER_HIP_SPECIALISE (above) and the
+ *   "register_stages_at_create"  0 (default) / 1: a 2^a * 3^b length with a register-stage kernel listed on request (plan option
+ *                  "register_stages" above) takes it at create -- faster by 1.04 ... 1.44 x, the reference's values within rounding instead of
+ *                  its bits; environment variable FOURIER_HIP_REGISTER_STAGES=1 (read once, before the first plan; the function overrides it).
+ * Environment the library reads, all of it: FOURIER_HIP_VERBOSE (error text on stderr), FOURIER_HIP_SPECIALISE, FOURIER_HIP_REGISTER_STAGES (above) and the
  * location of the code-object cache: $FOURIER_HIP_CACHE_DIR, else $XDG_CACHE_HOME/fourier-hip, else $HOME/.cache/fourier-hip (an EMPTY
  * FOURIER_HIP_CACHE_DIR switches the disk cache off).  Cache files are keyed by device architecture, precision, kernel kind, length
  * and a hash of the embedded kernel sources, the compile options and the HIP runtime's version: a library or ROCm update never loads a stale

@@ -420,6 +420,20 @@ def test_plan_option_register_stages_moves_a_2a3b_length_off_the_reference_sched
     plan.set_option("register_stages", 1)
     plan.set_option("register_stages", 0)
     assert plan.describe() == desc and "registers" in desc
+    # the library-wide default (fourier_hip_set_default_option / FOURIER_HIP_REGISTER_STAGES=1): plans created afterwards take the kernel at create
+    assert fa.get_default_option("register_stages_at_create") == 0
+    fa.set_default_option("register_stages_at_create", 1)
+    try:
+        plan = make(fa, 729, np.complex128)
+        assert plan.describe().startswith("stockham registers 27x27 one-launch"), plan.describe()
+        x = np.stack([hash_normal(80 + b, 729) for b in range(2)]).astype(np.complex128)
+        assert rel_l2(run_batch(plan, x, 0), oracle.transform_batch(x, 0)) <= 2e-14
+        plan.set_option("register_stages", 0)  # a handle can still go back
+        assert "mixed-radix" in plan.describe() and np.array_equal(run_batch(plan, x, 0), oracle.transform_batch(x, 0))
+        assert "mixed-radix" in make(fa, 96, np.complex64).describe() and "registers" in make(fa, 1001, np.complex64).describe()
+    finally:
+        fa.set_default_option("register_stages_at_create", 0)
+    assert "mixed-radix" in make(fa, 729, np.complex128).describe()
 
 
 def test_bluestein_fusion_matches_unfused(fa):

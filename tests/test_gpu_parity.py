@@ -1539,6 +1539,18 @@ def test_plan_option_register_stages_moves_a_2a3b_length_off_the_reference_sched
     plan = make(fa, 1001, np.complex64)
     plan.set_option("register_stages", 1)
     assert "registers 13x11x7" in plan.describe()
+    # library-wide (fourier_hip_set_default_option "register_stages_at_create" / FOURIER_HIP_REGISTER_STAGES=1): for callers that only know create
+    prev = fa.get_default_option("register_stages_at_create")
+    fa.set_default_option("register_stages_at_create", 1)
+    try:
+        plan = make(fa, 4608, np.complex64)
+        assert plan.describe().startswith("stockham registers 18x16x16 one-launch"), plan.describe()
+        x = np.stack([hash_normal(5300 + b, 4608) for b in range(5)]).astype(np.complex64)
+        assert rel_l2(gpu_batch(torch, fa, plan, x, 0), oracle.transform_batch(x, 0)) <= 1e-6
+        assert "mixed-radix" in make(fa, 96, np.complex64).describe()
+    finally:
+        fa.set_default_option("register_stages_at_create", prev)
+    assert "mixed-radix" in make(fa, 4608, np.complex64).describe()
 
 
 CHIRPZ_REG3_MENU = [1296, 1440, 1600, 2304, 2560, 3072, 8820, 9261]  # M = R1 x R2 x R3
